@@ -1,0 +1,278 @@
+/*
+ * ORACLE (test infrastructure, NOT product code).
+ *
+ * CPU restatement of the reference hot path: trace / constraint low-degree extension + BLAKE3 Merkle commitment
+ * (/root/reference/prover/src/lib.rs:615-715).  See oracle.h for the exported functions and fft_generic.inc,
+ * field_f64.h, field_f128.h, blake3_ref.c for the pieces.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the product (starkpack-winterfell_amd/) never does.
+ *
+ * Pinning status: the reference cannot be built here (Rust, no toolchain) and its tests hold no literal
+ * expected outputs for this path, so there are no reference-run vectors.  The oracle is pinned instead by
+ * (1) every definitional / known-answer check the reference's tests make for the path, re-run on it
+ * (tests/test_oracle_*.py), (2) independent Python big-integer arithmetic (oracle/pyref.py) and (3) golden
+ * digests of the official BLAKE3 C implementation (tests/golden/, oracle/gen_golden.py).
+ */
+#include "oracle.h"
+
+#include <omp.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "blake3_ref.h"
+#include "field_f128.h"
+#include "field_f64.h"
+
+/* ------------------------------------------------------------------ f64 instantiation */
+#define FE uint64_t
+#define FN(x) orc_f64_##x
+#define FE_ADD(a, b) f64_add((a), (b))
+#define FE_SUB(a, b) f64_sub((a), (b))
+#define FE_MUL(a, b) f64_mul((a), (b))
+#define FE_ONE f64_new(1)
+#define FE_ZERO ((uint64_t)0)
+#define FE_FROM_U64(v) f64_new(v)
+#define FE_INV(a) f64_inv(a)
+#define FE_EXP_U64(b, e) f64_exp((b), (e))
+#define FE_ROOT(n) f64_root_of_unity(n)
+#define FE_TWO_ADICITY F64_TWO_ADICITY
+#include "fft_generic.inc"
+#undef FE
+#undef FN
+#undef FE_ADD
+#undef FE_SUB
+#undef FE_MUL
+#undef FE_ONE
+#undef FE_ZERO
+#undef FE_FROM_U64
+#undef FE_INV
+#undef FE_EXP_U64
+#undef FE_ROOT
+#undef FE_TWO_ADICITY
+
+/* ------------------------------------------------------------------ f128 instantiation */
+#define FE f128e
+#define FN(x) orc_f128_##x
+#define FE_ADD(a, b) f128_add((a), (b))
+#define FE_SUB(a, b) f128_sub((a), (b))
+#define FE_MUL(a, b) f128_mul((a), (b))
+#define FE_ONE ((f128e)1)
+#define FE_ZERO ((f128e)0)
+#define FE_FROM_U64(v) ((f128e)(v))
+#define FE_INV(a) f128_inv(a)
+#define FE_EXP_U64(b, e) f128_exp((b), (f128e)(e))
+#define FE_ROOT(n) f128_root_of_unity(n)
+#define FE_TWO_ADICITY F128_TWO_ADICITY
+#include "fft_generic.inc"
+#undef FE
+#undef FN
+
+/* ------------------------------------------------------------------ scalar field API (for the parity tests) */
+uint64_t orc_f64_new(uint64_t v) { return f64_new(v); }
+uint64_t orc_f64_as_int(uint64_t x) { return f64_as_int(x); }
+uint64_t orc_f64_add(uint64_t a, uint64_t b) { return f64_add(a, b); }
+uint64_t orc_f64_sub(uint64_t a, uint64_t b) { return f64_sub(a, b); }
+uint64_t orc_f64_mul(uint64_t a, uint64_t b) { return f64_mul(a, b); }
+uint64_t orc_f64_inv(uint64_t a) { return f64_inv(a); }
+uint64_t orc_f64_exp(uint64_t a, uint64_t e) { return f64_exp(a, e); }
+uint64_t orc_f64_get_root_of_unity(uint32_t n) { return f64_root_of_unity(n); }
+
+void orc_f128_add(const void *a, const void *b, void *out) {
+    f128e x, y;
+    memcpy(&x, a, 16);
+    memcpy(&y, b, 16);
+    x = f128_add(x, y);
+    memcpy(out, &x, 16);
+}
+void orc_f128_sub(const void *a, const void *b, void *out) {
+    f128e x, y;
+    memcpy(&x, a, 16);
+    memcpy(&y, b, 16);
+    x = f128_sub(x, y);
+    memcpy(out, &x, 16);
+}
+void orc_f128_mul(const void *a, const void *b, void *out) {
+    f128e x, y;
+    memcpy(&x, a, 16);
+    memcpy(&y, b, 16);
+    x = f128_mul(x, y);
+    memcpy(out, &x, 16);
+}
+void orc_f128_inv(const void *a, void *out) {
+    f128e x;
+    memcpy(&x, a, 16);
+    x = f128_inv(x);
+    memcpy(out, &x, 16);
+}
+void orc_f128_get_root_of_unity(uint32_t n, void *out) {
+    f128e x = f128_root_of_unity(n);
+    memcpy(out, &x, 16);
+}
+
+/* ------------------------------------------------------------------ hashing */
+
+/* Blake3_256::hash_elements, crypto/src/hash/blake/mod.rs:46-59.
+ * f128 (IS_CANONICAL): raw element bytes.  f64: every element's canonical as_int() as 8 LE bytes
+ * (f64/mod.rs:605-610 via utils/core/src/serde/mod.rs:38-42,82-86; no length prefix). */
+void orc_hash_elements(int field, const void *elems, size_t n_base, uint8_t out[32]) {
+    if (field == ORC_FIELD_F128) {
+        orc_blake3_hash((const uint8_t *)elems, n_base * 16, out);
+        return;
+    }
+    const uint64_t *e = (const uint64_t *)elems;
+    uint8_t stackbuf[2048];
+    uint8_t *buf = n_base * 8 <= sizeof(stackbuf) ? stackbuf : (uint8_t *)malloc(n_base * 8);
+    for (size_t i = 0; i < n_base; i++) {
+        uint64_t v = f64_as_int(e[i]);
+        for (int b = 0; b < 8; b++) buf[8 * i + b] = (uint8_t)(v >> (8 * b));
+    }
+    orc_blake3_hash(buf, n_base * 8, out);
+    if (buf != stackbuf) free(buf);
+}
+
+/* Blake3_256::merge, blake/mod.rs:31-33 */
+void orc_merge(const uint8_t left[32], const uint8_t right[32], uint8_t out[32]) {
+    uint8_t buf[64];
+    memcpy(buf, left, 32);
+    memcpy(buf + 32, right, 32);
+    orc_blake3_hash(buf, 64, out);
+}
+
+/* Blake3_256::merge_with_int, blake/mod.rs:35-40 */
+void orc_merge_with_int(const uint8_t seed[32], uint64_t value, uint8_t out[32]) {
+    uint8_t buf[40];
+    memcpy(buf, seed, 32);
+    for (int b = 0; b < 8; b++) buf[32 + b] = (uint8_t)(value >> (8 * b));
+    orc_blake3_hash(buf, 40, out);
+}
+
+/* build_merkle_nodes, crypto/src/merkle/mod.rs:350-374 (threads<=1) and merkle/concurrent.rs:21-70 (threads>1).
+ * nodes has n_leaves digests: nodes[0] = zero digest, nodes[1] = root. */
+int orc_build_merkle_nodes(const uint8_t *leaves, size_t n_leaves, uint8_t *nodes, int threads) {
+    if (n_leaves < 2) return -1;                    /* merkle/mod.rs:118-120 */
+    if (n_leaves & (n_leaves - 1)) return -2;       /* :121-123 */
+    size_t n = n_leaves / 2;
+    memset(nodes, 0, 32);
+#pragma omp parallel for num_threads(threads) schedule(static) if (threads > 1 && n > 512)
+    for (size_t i = 0; i < n; i++) orc_blake3_hash(leaves + 64 * i, 64, nodes + 32 * (n + i));
+    /* levels above: level with first index `lo` has `lo` nodes; children are already final */
+    for (size_t lo = n / 2; lo >= 1; lo /= 2) {
+#pragma omp parallel for num_threads(threads) schedule(static) if (threads > 1 && lo > 512)
+        for (size_t i = lo; i < 2 * lo; i++) orc_blake3_hash(nodes + 64 * i, 64, nodes + 32 * i);
+    }
+    return 0;
+}
+
+/* RowMatrix::commit_to_comb_rows (row_matrix.rs:204-238); with n_traces == 1 it is commit_to_rows (:183-203).
+ * lde[t]: row-major matrices of n_rows x row_width base values; a row contributes its first elements_per_row. */
+int orc_commit_to_comb_rows(int field, const void *const *lde, size_t n_traces, size_t n_rows, size_t row_width,
+                            size_t elements_per_row, uint8_t *leaves, uint8_t *nodes, int threads) {
+    size_t eb = field == ORC_FIELD_F128 ? 16 : 8;
+    if (threads < 1) threads = 1;
+    int err = 0;
+#pragma omp parallel num_threads(threads) if (threads > 1)
+    {
+        uint8_t *comb = (uint8_t *)malloc(n_traces * elements_per_row * eb);
+        if (!comb) err = 1;
+#pragma omp for schedule(static)
+        for (size_t i = 0; i < n_rows; i++) {
+            if (!comb) continue;
+            for (size_t t = 0; t < n_traces; t++)
+                memcpy(comb + t * elements_per_row * eb, (const uint8_t *)lde[t] + i * row_width * eb,
+                       elements_per_row * eb);
+            orc_hash_elements(field, comb, n_traces * elements_per_row, leaves + 32 * i);
+        }
+        free(comb);
+    }
+    if (err) return -3;
+    return orc_build_merkle_nodes(leaves, n_rows, nodes, threads);
+}
+
+/* ------------------------------------------------------------------ the path */
+
+static int check_params(int field, size_t ext, unsigned log2_R, unsigned log2_blowup, size_t n_cols) {
+    if (field != ORC_FIELD_F64 && field != ORC_FIELD_F128) return -10;
+    if (ext < 1 || ext > 3 || (field == ORC_FIELD_F128 && ext == 3)) return -11; /* f128/mod.rs:296-314 */
+    if (log2_R < 3) return -12;                           /* air/src/air/trace_info.rs:35 */
+    if (log2_blowup < 1 || log2_blowup > 7) return -13;   /* air/src/options.rs:19-20 */
+    unsigned adicity = field == ORC_FIELD_F64 ? F64_TWO_ADICITY : F128_TWO_ADICITY;
+    if (log2_R + log2_blowup > adicity) return -14;       /* fft/mod.rs:196-200 */
+    if (n_cols < 1 || n_cols > 255) return -15;           /* trace_info.rs:37 */
+    return 0;
+}
+
+/* Prover::build_trace_commitment, prover/src/lib.rs:615-670.
+ * trace_cols[t*n_cols + c]: R elements (ext coordinates each).  polys_out likewise.  lde_out[t]: N x row_width. */
+int orc_build_trace_commitment(int field, size_t ext, unsigned log2_R, unsigned log2_blowup, size_t n_cols,
+                               size_t n_traces, const uint8_t offset_le[16], const void *const *trace_cols,
+                               void *const *polys_out, void *const *lde_out, uint8_t *leaves, uint8_t *nodes,
+                               int threads) {
+    int rc = check_params(field, ext, log2_R, log2_blowup, n_cols);
+    if (rc) return rc;
+    if (n_traces < 1) return -16;
+    size_t R = (size_t)1 << log2_R, blowup = (size_t)1 << log2_blowup;
+    size_t base_cols = n_cols * ext, row_width = 8 * ((base_cols + 7) / 8);
+    f128e off128;
+    memcpy(&off128, offset_le, 16);
+    if (off128 == 0) return -17; /* fft/mod.rs:201 */
+    for (size_t t = 0; t < n_traces; t++) {
+        if (field == ORC_FIELD_F64) {
+            orc_f64_interpolate_columns((const uint64_t *const *)(trace_cols + t * n_cols), n_cols, ext, R,
+                                        (uint64_t *const *)(polys_out + t * n_cols), threads);
+            rc = orc_f64_evaluate_polys_over((const uint64_t *const *)(polys_out + t * n_cols), n_cols, ext, R, blowup,
+                                             f64_new((uint64_t)off128), (uint64_t *)lde_out[t], threads);
+        } else {
+            orc_f128_interpolate_columns((const f128e *const *)(trace_cols + t * n_cols), n_cols, ext, R,
+                                         (f128e *const *)(polys_out + t * n_cols), threads);
+            rc = orc_f128_evaluate_polys_over((const f128e *const *)(polys_out + t * n_cols), n_cols, ext, R, blowup,
+                                              off128, (f128e *)lde_out[t], threads);
+        }
+        if (rc) return rc;
+    }
+    return orc_commit_to_comb_rows(field, (const void *const *)lde_out, n_traces, R * blowup, row_width, base_cols,
+                                   leaves, nodes, threads);
+}
+
+/* Prover::build_constraint_commitment, prover/src/lib.rs:680-715: composition-poly columns (coefficients) ->
+ * row-major LDE -> commit_to_rows. */
+int orc_build_constraint_commitment(int field, size_t ext, unsigned log2_R, unsigned log2_blowup, size_t n_cols,
+                                    const uint8_t offset_le[16], const void *const *poly_cols, void *lde_out,
+                                    uint8_t *leaves, uint8_t *nodes, int threads) {
+    int rc = check_params(field, ext, log2_R, log2_blowup, n_cols);
+    if (rc) return rc;
+    size_t R = (size_t)1 << log2_R, blowup = (size_t)1 << log2_blowup;
+    size_t base_cols = n_cols * ext, row_width = 8 * ((base_cols + 7) / 8);
+    f128e off128;
+    memcpy(&off128, offset_le, 16);
+    if (off128 == 0) return -17;
+    if (field == ORC_FIELD_F64)
+        rc = orc_f64_evaluate_polys_over((const uint64_t *const *)poly_cols, n_cols, ext, R, blowup,
+                                         f64_new((uint64_t)off128), (uint64_t *)lde_out, threads);
+    else
+        rc = orc_f128_evaluate_polys_over((const f128e *const *)poly_cols, n_cols, ext, R, blowup, off128,
+                                          (f128e *)lde_out, threads);
+    if (rc) return rc;
+    const void *l = lde_out;
+    return orc_commit_to_comb_rows(field, &l, 1, R * blowup, row_width, base_cols, leaves, nodes, threads);
+}
+
+/* ------------------------------------------------------------------ ctypes-friendly wrappers (u128 by pointer) */
+int orc_f128_get_twiddles_p(void *out, size_t n, int inverse) { return orc_f128_get_twiddles((f128e *)out, n, inverse); }
+void orc_f128_evaluate_poly_with_offset_p(const void *p, size_t n, size_t ext, const void *tw, const void *off,
+                                          size_t blowup, void *result) {
+    f128e o;
+    memcpy(&o, off, 16);
+    orc_f128_evaluate_poly_with_offset((const f128e *)p, n, ext, (const f128e *)tw, o, blowup, (f128e *)result);
+}
+void orc_f128_interpolate_poly_with_offset_p(void *v, size_t n, size_t ext, const void *inv_tw, const void *off) {
+    f128e o;
+    memcpy(&o, off, 16);
+    orc_f128_interpolate_poly_with_offset((f128e *)v, n, ext, (const f128e *)inv_tw, o);
+}
+int orc_f128_evaluate_polys_over_p(const void *const *polys, size_t n_cols, size_t ext, size_t R, size_t blowup,
+                                   const void *off, void *out, int threads) {
+    f128e o;
+    memcpy(&o, off, 16);
+    return orc_f128_evaluate_polys_over((const f128e *const *)polys, n_cols, ext, R, blowup, o, (f128e *)out, threads);
+}
+
+int orc_max_threads(void) { return omp_get_max_threads(); }

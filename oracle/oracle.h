@@ -1,0 +1,90 @@
+/*
+ * ORACLE (test infrastructure, NOT product code) -- exported functions of oracle/liboracle.so.
+ * CPU restatement of the reference's LDE + BLAKE3 Merkle commitment path; every function cites the reference
+ * lines it follows in oracle.c / fft_generic.inc.  f64 values are Montgomery residues (as the reference keeps them
+ * in memory); f128 values are canonical little-endian u128.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_FIELD_F64 = 1, ORC_FIELD_F128 = 2 };
+
+/* --- f64 scalar ops (math/src/field/f64/mod.rs) */
+uint64_t orc_f64_new(uint64_t canonical);
+uint64_t orc_f64_as_int(uint64_t mont);
+uint64_t orc_f64_add(uint64_t a, uint64_t b);
+uint64_t orc_f64_sub(uint64_t a, uint64_t b);
+uint64_t orc_f64_mul(uint64_t a, uint64_t b);
+uint64_t orc_f64_inv(uint64_t a);
+uint64_t orc_f64_exp(uint64_t a, uint64_t e);
+uint64_t orc_f64_get_root_of_unity(uint32_t n);
+
+/* --- f128 scalar ops (math/src/field/f128/mod.rs); 16-byte little-endian operands by pointer */
+void orc_f128_add(const void *a, const void *b, void *out);
+void orc_f128_sub(const void *a, const void *b, void *out);
+void orc_f128_mul(const void *a, const void *b, void *out);
+void orc_f128_inv(const void *a, void *out);
+void orc_f128_get_root_of_unity(uint32_t n, void *out);
+
+/* --- math::fft over f64 (ext = coordinates per element) */
+int orc_f64_get_twiddles(uint64_t *out, size_t n, int inverse);
+void orc_f64_permute(uint64_t *v, size_t n, size_t ext);
+void orc_f64_fft_in_place(uint64_t *v, size_t n, size_t ext, const uint64_t *tw);
+void orc_f64_evaluate_poly(uint64_t *p, size_t n, size_t ext, const uint64_t *tw);
+void orc_f64_evaluate_poly_with_offset(const uint64_t *p, size_t n, size_t ext, const uint64_t *tw,
+                                       uint64_t domain_offset, size_t blowup, uint64_t *result);
+void orc_f64_interpolate_poly(uint64_t *v, size_t n, size_t ext, const uint64_t *inv_tw);
+void orc_f64_interpolate_poly_with_offset(uint64_t *v, size_t n, size_t ext, const uint64_t *inv_tw,
+                                          uint64_t domain_offset);
+void orc_f64_eval_many(const uint64_t *p, size_t n, const uint64_t *xs, size_t m, uint64_t *out);
+void orc_f64_interpolate_columns(const uint64_t *const *cols, size_t n_cols, size_t ext, size_t R,
+                                 uint64_t *const *out, int threads);
+int orc_f64_evaluate_polys_over(const uint64_t *const *polys, size_t n_cols, size_t ext, size_t R, size_t blowup,
+                                uint64_t domain_offset, uint64_t *out, int threads);
+
+/* --- math::fft over f128 (pointer-typed wrappers; the elements are 16-byte LE integers) */
+int orc_f128_get_twiddles_p(void *out, size_t n, int inverse);
+void orc_f128_permute(unsigned __int128 *v, size_t n, size_t ext);
+void orc_f128_fft_in_place(unsigned __int128 *v, size_t n, size_t ext, const unsigned __int128 *tw);
+void orc_f128_evaluate_poly(unsigned __int128 *p, size_t n, size_t ext, const unsigned __int128 *tw);
+void orc_f128_evaluate_poly_with_offset_p(const void *p, size_t n, size_t ext, const void *tw, const void *off,
+                                          size_t blowup, void *result);
+void orc_f128_interpolate_poly(unsigned __int128 *v, size_t n, size_t ext, const unsigned __int128 *inv_tw);
+void orc_f128_interpolate_poly_with_offset_p(void *v, size_t n, size_t ext, const void *inv_tw, const void *off);
+void orc_f128_eval_many(const unsigned __int128 *p, size_t n, const unsigned __int128 *xs, size_t m,
+                        unsigned __int128 *out);
+void orc_f128_interpolate_columns(const unsigned __int128 *const *cols, size_t n_cols, size_t ext, size_t R,
+                                  unsigned __int128 *const *out, int threads);
+int orc_f128_evaluate_polys_over_p(const void *const *polys, size_t n_cols, size_t ext, size_t R, size_t blowup,
+                                   const void *off, void *out, int threads);
+
+/* --- crypto::hash::Blake3_256 and crypto::merkle */
+void orc_hash_elements(int field, const void *elems, size_t n_base, uint8_t out[32]);
+void orc_merge(const uint8_t left[32], const uint8_t right[32], uint8_t out[32]);
+void orc_merge_with_int(const uint8_t seed[32], uint64_t value, uint8_t out[32]);
+int orc_build_merkle_nodes(const uint8_t *leaves, size_t n_leaves, uint8_t *nodes, int threads);
+int orc_commit_to_comb_rows(int field, const void *const *lde, size_t n_traces, size_t n_rows, size_t row_width,
+                            size_t elements_per_row, uint8_t *leaves, uint8_t *nodes, int threads);
+
+/* --- the path: Prover::build_trace_commitment / build_constraint_commitment (prover/src/lib.rs:615-715) */
+int orc_build_trace_commitment(int field, size_t ext, unsigned log2_R, unsigned log2_blowup, size_t n_cols,
+                               size_t n_traces, const uint8_t offset_le[16], const void *const *trace_cols,
+                               void *const *polys_out, void *const *lde_out, uint8_t *leaves, uint8_t *nodes,
+                               int threads);
+int orc_build_constraint_commitment(int field, size_t ext, unsigned log2_R, unsigned log2_blowup, size_t n_cols,
+                                    const uint8_t offset_le[16], const void *const *poly_cols, void *lde_out,
+                                    uint8_t *leaves, uint8_t *nodes, int threads);
+
+int orc_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

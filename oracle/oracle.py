@@ -1,0 +1,304 @@
+"""ORACLE (test infrastructure, NOT product code): ctypes/numpy front end of oracle/liboracle.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+f64 arrays are numpy uint64 (Montgomery residues, as the reference keeps them in memory);
+f128 arrays are numpy uint64 with a trailing dimension of 2 (lo, hi words of the canonical u128).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+F64, F128 = 1, 2
+ELEM_WORDS = {F64: 1, F128: 2}
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/liboracle.so with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        u64, sz, vp, i32, u32 = C.c_uint64, C.c_size_t, C.c_void_p, C.c_int, C.c_uint32
+        for name in ("new", "as_int", "inv"):
+            getattr(L, f"orc_f64_{name}").restype = u64
+            getattr(L, f"orc_f64_{name}").argtypes = [u64]
+        for name in ("add", "sub", "mul", "exp"):
+            getattr(L, f"orc_f64_{name}").restype = u64
+            getattr(L, f"orc_f64_{name}").argtypes = [u64, u64]
+        L.orc_f64_get_root_of_unity.restype = u64
+        L.orc_f64_get_root_of_unity.argtypes = [u32]
+        for name in ("add", "sub", "mul"):
+            getattr(L, f"orc_f128_{name}").argtypes = [vp, vp, vp]
+        L.orc_f128_inv.argtypes = [vp, vp]
+        L.orc_f128_get_root_of_unity.argtypes = [u32, vp]
+        L.orc_f64_get_twiddles.argtypes = [vp, sz, i32]
+        L.orc_f128_get_twiddles_p.argtypes = [vp, sz, i32]
+        for f in ("f64", "f128"):
+            getattr(L, f"orc_{f}_permute").argtypes = [vp, sz, sz]
+            getattr(L, f"orc_{f}_fft_in_place").argtypes = [vp, sz, sz, vp]
+            getattr(L, f"orc_{f}_evaluate_poly").argtypes = [vp, sz, sz, vp]
+            getattr(L, f"orc_{f}_interpolate_poly").argtypes = [vp, sz, sz, vp]
+            getattr(L, f"orc_{f}_eval_many").argtypes = [vp, sz, vp, sz, vp]
+            getattr(L, f"orc_{f}_interpolate_columns").argtypes = [vp, sz, sz, sz, vp, i32]
+        L.orc_f64_evaluate_poly_with_offset.argtypes = [vp, sz, sz, vp, u64, sz, vp]
+        L.orc_f64_interpolate_poly_with_offset.argtypes = [vp, sz, sz, vp, u64]
+        L.orc_f64_evaluate_polys_over.argtypes = [vp, sz, sz, sz, sz, u64, vp, i32]
+        L.orc_f128_evaluate_poly_with_offset_p.argtypes = [vp, sz, sz, vp, vp, sz, vp]
+        L.orc_f128_interpolate_poly_with_offset_p.argtypes = [vp, sz, sz, vp, vp]
+        L.orc_f128_evaluate_polys_over_p.argtypes = [vp, sz, sz, sz, sz, vp, vp, i32]
+        L.orc_hash_elements.argtypes = [i32, vp, sz, vp]
+        L.orc_merge.argtypes = [vp, vp, vp]
+        L.orc_merge_with_int.argtypes = [vp, u64, vp]
+        L.orc_build_merkle_nodes.argtypes = [vp, sz, vp, i32]
+        L.orc_commit_to_comb_rows.argtypes = [i32, vp, sz, sz, sz, sz, vp, vp, i32]
+        L.orc_build_trace_commitment.argtypes = [i32, sz, C.c_uint, C.c_uint, sz, sz, vp, vp, vp, vp, vp, vp, i32]
+        L.orc_build_constraint_commitment.argtypes = [i32, sz, C.c_uint, C.c_uint, sz, vp, vp, vp, vp, vp, i32]
+        L.orc_blake3_hash.argtypes = [vp, sz, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _ptr_array(arrs):
+    return (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+
+
+def _off_bytes(offset: int) -> np.ndarray:
+    return np.frombuffer(int(offset).to_bytes(16, "little"), dtype=np.uint8).copy()
+
+
+# ----------------------------------------------------------------------------------------------- field helpers
+
+def f64_new(values) -> np.ndarray:
+    """canonical ints (array-like of < 2^64) -> Montgomery uint64 array."""
+    L = lib()
+    v = np.asarray(values, dtype=np.uint64)
+    out = np.empty_like(v)
+    flat_in, flat_out = v.reshape(-1), out.reshape(-1)
+    for i in range(flat_in.size):
+        flat_out[i] = L.orc_f64_new(int(flat_in[i]))
+    return out
+
+
+def f64_as_int(values) -> np.ndarray:
+    L = lib()
+    v = np.asarray(values, dtype=np.uint64)
+    out = np.empty_like(v)
+    flat_in, flat_out = v.reshape(-1), out.reshape(-1)
+    for i in range(flat_in.size):
+        flat_out[i] = L.orc_f64_as_int(int(flat_in[i]))
+    return out
+
+
+def f128_from_ints(values) -> np.ndarray:
+    vals = list(values)
+    out = np.empty((len(vals), 2), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        out[i, 0] = v & 0xFFFFFFFFFFFFFFFF
+        out[i, 1] = v >> 64
+    return out
+
+
+def f128_to_ints(arr: np.ndarray):
+    a = np.asarray(arr, dtype=np.uint64).reshape(-1, 2)
+    return [int(a[i, 0]) | (int(a[i, 1]) << 64) for i in range(a.shape[0])]
+
+
+def f128_op(name: str, a: int, b: int | None = None) -> int:
+    L = lib()
+    abuf = (C.c_uint8 * 16).from_buffer_copy(int(a).to_bytes(16, "little"))
+    out = (C.c_uint8 * 16)()
+    if b is None:
+        getattr(L, f"orc_f128_{name}")(abuf, out)
+    else:
+        bbuf = (C.c_uint8 * 16).from_buffer_copy(int(b).to_bytes(16, "little"))
+        getattr(L, f"orc_f128_{name}")(abuf, bbuf, out)
+    return int.from_bytes(bytes(out), "little")
+
+
+def f128_root_of_unity(n: int) -> int:
+    out = (C.c_uint8 * 16)()
+    lib().orc_f128_get_root_of_unity(n, out)
+    return int.from_bytes(bytes(out), "little")
+
+
+# ----------------------------------------------------------------------------------------------- math::fft
+
+def get_twiddles(field: int, n: int, inverse: bool = False) -> np.ndarray:
+    w = ELEM_WORDS[field]
+    out = np.empty((n // 2, w) if w > 1 else (n // 2,), dtype=np.uint64)
+    fn = lib().orc_f64_get_twiddles if field == F64 else lib().orc_f128_get_twiddles_p
+    rc = fn(_p(out), n, int(inverse))
+    if rc:
+        raise ValueError(f"get_twiddles failed: {rc}")
+    return out
+
+
+def _fname(field, name):
+    return getattr(lib(), f"orc_{'f64' if field == F64 else 'f128'}_{name}")
+
+
+def fft_in_place(field: int, v: np.ndarray, n: int, ext: int, tw: np.ndarray):
+    _fname(field, "fft_in_place")(_p(v), n, ext, _p(tw))
+
+
+def permute(field: int, v: np.ndarray, n: int, ext: int = 1):
+    _fname(field, "permute")(_p(v), n, ext)
+
+
+def evaluate_poly(field: int, p: np.ndarray, n: int, ext: int, tw: np.ndarray):
+    _fname(field, "evaluate_poly")(_p(p), n, ext, _p(tw))
+
+
+def interpolate_poly(field: int, v: np.ndarray, n: int, ext: int, inv_tw: np.ndarray):
+    _fname(field, "interpolate_poly")(_p(v), n, ext, _p(inv_tw))
+
+
+def evaluate_poly_with_offset(field: int, p: np.ndarray, n: int, ext: int, tw: np.ndarray, offset_mem, blowup: int):
+    """offset_mem: f64 -> Montgomery u64; f128 -> python int."""
+    w = ELEM_WORDS[field]
+    shape = (n * blowup * ext, w) if w > 1 else (n * blowup * ext,)
+    out = np.empty(shape, dtype=np.uint64)
+    if field == F64:
+        lib().orc_f64_evaluate_poly_with_offset(_p(p), n, ext, _p(tw), int(offset_mem), blowup, _p(out))
+    else:
+        lib().orc_f128_evaluate_poly_with_offset_p(_p(p), n, ext, _p(tw), _p(_off_bytes(offset_mem)), blowup, _p(out))
+    return out
+
+
+def interpolate_poly_with_offset(field: int, v: np.ndarray, n: int, ext: int, inv_tw: np.ndarray, offset_mem):
+    if field == F64:
+        lib().orc_f64_interpolate_poly_with_offset(_p(v), n, ext, _p(inv_tw), int(offset_mem))
+    else:
+        lib().orc_f128_interpolate_poly_with_offset_p(_p(v), n, ext, _p(inv_tw), _p(_off_bytes(offset_mem)))
+
+
+def eval_many(field: int, p: np.ndarray, xs: np.ndarray) -> np.ndarray:
+    w = ELEM_WORDS[field]
+    n, m = p.size // w, xs.size // w
+    out = np.empty_like(xs)
+    _fname(field, "eval_many")(_p(p), n, _p(xs), m, _p(out))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- hashing / merkle
+
+def blake3(data: bytes) -> bytes:
+    out = (C.c_uint8 * 32)()
+    buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(data if data else b"\0")
+    lib().orc_blake3_hash(buf, len(data), out)
+    return bytes(out)
+
+
+def hash_elements(field: int, elems: np.ndarray) -> bytes:
+    out = (C.c_uint8 * 32)()
+    e = np.ascontiguousarray(elems, dtype=np.uint64)
+    lib().orc_hash_elements(field, _p(e), e.size // ELEM_WORDS[field], out)
+    return bytes(out)
+
+
+def merge(a: bytes, b: bytes) -> bytes:
+    out = (C.c_uint8 * 32)()
+    lib().orc_merge((C.c_uint8 * 32).from_buffer_copy(a), (C.c_uint8 * 32).from_buffer_copy(b), out)
+    return bytes(out)
+
+
+def merge_with_int(seed: bytes, value: int) -> bytes:
+    out = (C.c_uint8 * 32)()
+    lib().orc_merge_with_int((C.c_uint8 * 32).from_buffer_copy(seed), value, out)
+    return bytes(out)
+
+
+def build_merkle_nodes(leaves: np.ndarray, threads: int = 1) -> np.ndarray:
+    leaves = np.ascontiguousarray(leaves, dtype=np.uint8).reshape(-1, 32)
+    nodes = np.empty_like(leaves)
+    rc = lib().orc_build_merkle_nodes(_p(leaves), leaves.shape[0], _p(nodes), threads)
+    if rc:
+        raise ValueError(f"build_merkle_nodes failed: {rc}")
+    return nodes
+
+
+# ----------------------------------------------------------------------------------------------- the path
+
+def row_width(n_cols: int, ext: int) -> int:
+    return 8 * ((n_cols * ext + 7) // 8)
+
+
+def evaluate_polys_over(field: int, polys, ext: int, log2_R: int, log2_blowup: int, offset: int, threads: int = 1):
+    """polys: list of per-column arrays.  offset: canonical python int.  Returns (N, row_width[,2]) array."""
+    R, blowup = 1 << log2_R, 1 << log2_blowup
+    w = ELEM_WORDS[field]
+    rw = row_width(len(polys), ext)
+    shape = (R * blowup, rw, w) if w > 1 else (R * blowup, rw)
+    out = np.zeros(shape, dtype=np.uint64)
+    polys = [np.ascontiguousarray(p, dtype=np.uint64) for p in polys]
+    ptrs = _ptr_array(polys)
+    if field == F64:
+        rc = lib().orc_f64_evaluate_polys_over(ptrs, len(polys), ext, R, blowup, lib().orc_f64_new(offset), _p(out),
+                                               threads)
+    else:
+        rc = lib().orc_f128_evaluate_polys_over_p(ptrs, len(polys), ext, R, blowup, _p(_off_bytes(offset)), _p(out),
+                                                  threads)
+    if rc:
+        raise ValueError(f"evaluate_polys_over failed: {rc}")
+    return out
+
+
+def build_trace_commitment(field: int, traces, ext: int, log2_R: int, log2_blowup: int, offset: int,
+                           threads: int = 1):
+    """traces: list (per trace) of lists (per column) of arrays with R*ext elements.
+    Returns dict(polys=[[...]], lde=[...], leaves, nodes, root)."""
+    R, blowup = 1 << log2_R, 1 << log2_blowup
+    w = ELEM_WORDS[field]
+    n_traces, n_cols = len(traces), len(traces[0])
+    rw = row_width(n_cols, ext)
+    N = R * blowup
+    cols = [np.ascontiguousarray(c, dtype=np.uint64) for t in traces for c in t]
+    polys = [np.empty_like(c) for c in cols]
+    lde = [np.zeros((N, rw, w) if w > 1 else (N, rw), dtype=np.uint64) for _ in range(n_traces)]
+    leaves = np.empty((N, 32), dtype=np.uint8)
+    nodes = np.empty((N, 32), dtype=np.uint8)
+    rc = lib().orc_build_trace_commitment(field, ext, log2_R, log2_blowup, n_cols, n_traces, _p(_off_bytes(offset)),
+                                          _ptr_array(cols), _ptr_array(polys), _ptr_array(lde), _p(leaves), _p(nodes),
+                                          threads)
+    if rc:
+        raise ValueError(f"build_trace_commitment failed: {rc}")
+    polys = [polys[t * n_cols:(t + 1) * n_cols] for t in range(n_traces)]
+    return dict(polys=polys, lde=lde, leaves=leaves, nodes=nodes, root=bytes(nodes[1]))
+
+
+def build_constraint_commitment(field: int, poly_cols, ext: int, log2_R: int, log2_blowup: int, offset: int,
+                                threads: int = 1):
+    R, blowup = 1 << log2_R, 1 << log2_blowup
+    w = ELEM_WORDS[field]
+    n_cols = len(poly_cols)
+    rw = row_width(n_cols, ext)
+    N = R * blowup
+    cols = [np.ascontiguousarray(c, dtype=np.uint64) for c in poly_cols]
+    lde = np.zeros((N, rw, w) if w > 1 else (N, rw), dtype=np.uint64)
+    leaves = np.empty((N, 32), dtype=np.uint8)
+    nodes = np.empty((N, 32), dtype=np.uint8)
+    rc = lib().orc_build_constraint_commitment(field, ext, log2_R, log2_blowup, n_cols, _p(_off_bytes(offset)),
+                                               _ptr_array(cols), _p(lde), _p(leaves), _p(nodes), threads)
+    if rc:
+        raise ValueError(f"build_constraint_commitment failed: {rc}")
+    return dict(lde=lde, leaves=leaves, nodes=nodes, root=bytes(nodes[1]))
