@@ -1,0 +1,152 @@
+/*
+ * wf_lde.h -- C ABI of libwf_lde.so: MI355X (gfx950) implementation of the winter-prover hot path
+ *   trace / constraint low-degree extension (radix-2 NTT over the f64 and f128 base fields, coset evaluation)
+ *   + BLAKE3-256 Merkle commitment of the extended rows, including STARKPack's combined-row commitment.
+ *
+ * The reference (Rust) has no FFI layer; the seam these entry points replace is the pair of provided methods
+ *   Prover::build_trace_commitment       /root/reference/prover/src/lib.rs:615-670
+ *   Prover::build_constraint_commitment  /root/reference/prover/src/lib.rs:680-715
+ * plus the math::fft / crypto calls they are made of.  INTEGRATION.md shows the Rust `impl Prover` override that
+ * binds them.  Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *
+ * Element memory representation (identical to the reference's in-memory types):
+ *   WF_FIELD_F64  : uint64_t Montgomery residue x*2^64 mod p, p = 2^64-2^32+1   (math/src/field/f64/mod.rs:48-53)
+ *   WF_FIELD_F128 : 16-byte little-endian canonical integer < p = 2^128-45*2^40+1 (math/src/field/f128/mod.rs:35)
+ *   extension element (ext_degree 2 or 3): ext_degree consecutive base elements  (extensions/quadratic.rs:26-28)
+ * Column  = trace_len extension elements, contiguous (ColMatrix column, prover/src/matrix/col_matrix.rs:31).
+ * RowMatrix data = (trace_len*blowup) rows x row_width base elements, row_width = 8*ceil(n_cols*ext_degree/8),
+ *   unused lanes zero (prover/src/matrix/row_matrix.rs:31-39,118-133; segments.rs:65-72).
+ * Digest = 32 bytes (crypto/src/hash/mod.rs:84-85).  Merkle `nodes` = n_leaves digests, nodes[0] = zero digest,
+ *   nodes[1] = root, nodes[i] = BLAKE3(nodes[2i] || nodes[2i+1]) (crypto/src/merkle/mod.rs:87-90,350-374).
+ *
+ * All functions return 0 on success or a negative wf_status; wf_last_error() describes the last failure of the
+ * calling thread.  Nothing here aborts or falls back to a CPU path: without a usable HIP device every compute
+ * entry point fails with WF_ERR_HIP.
+ */
+#ifndef WF_LDE_H
+#define WF_LDE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wf_ctx wf_ctx;
+
+enum wf_field { WF_FIELD_F64 = 1, WF_FIELD_F128 = 2 };
+
+enum wf_status {
+    WF_OK = 0,
+    WF_ERR_FIELD = -10,        /* unknown field id */
+    WF_ERR_EXTENSION = -11,    /* ext_degree not in {1,2,3}, or 3 over f128 (f128/mod.rs:296-314) */
+    WF_ERR_TRACE_LENGTH = -12, /* trace length < 8 or not a power of two (air/src/air/trace_info.rs:35) */
+    WF_ERR_BLOWUP = -13,       /* blowup not a power of two in [2,128] (air/src/options.rs:19-20) */
+    WF_ERR_DOMAIN = -14,       /* log2(trace_len*blowup) exceeds the field's two-adicity (fft/mod.rs:196-200) */
+    WF_ERR_WIDTH = -15,        /* n_cols not in [1,255] (air/src/air/trace_info.rs:37) */
+    WF_ERR_TRACES = -16,       /* n_traces == 0 */
+    WF_ERR_OFFSET = -17,       /* domain offset == 0 or >= p (fft/mod.rs:201) */
+    WF_ERR_LEAVES = -18,       /* fewer than two leaves / not a power of two (merkle/mod.rs:118-123) */
+    WF_ERR_ARG = -19,          /* null pointer or other malformed argument */
+    WF_ERR_HIP = -30,          /* HIP runtime failure (no device, out of memory, launch failure) */
+    WF_ERR_DIGEST = -31        /* digest_bytes != 32 */
+};
+
+/* Parameters of one commitment.  Mirrors what StarkDomain + ProofOptions carry into the two Prover methods
+ * (prover/src/domain.rs:13-31; air/src/options.rs:199-201). */
+typedef struct wf_params {
+    uint32_t field;          /* enum wf_field */
+    uint32_t ext_degree;     /* E::EXTENSION_DEGREE: 1, 2 or 3 */
+    uint32_t log2_trace_len; /* log2 of the trace length R (polynomial size) */
+    uint32_t log2_blowup;    /* log2 of StarkDomain::trace_to_lde_blowup() */
+    uint32_t n_cols;         /* columns of E per trace (ColMatrix::num_cols) */
+    uint32_t n_traces;       /* STARKPack: traces committed under one tree (>= 1) */
+    uint32_t digest_bytes;   /* 32 (Blake3_256) */
+    uint32_t reserved;       /* must be 0 */
+    uint8_t domain_offset[16]; /* StarkDomain::offset() as a canonical little-endian integer (7 for f64, 3 for f128) */
+} wf_params;
+
+/* ---- context ------------------------------------------------------------------------------------------------- */
+
+/* Creates a context bound to HIP device `device` (twiddle tables, scratch and a stream live in it).
+ * One context per GPU; a context is not thread-safe, distinct contexts are independent. */
+int wf_ctx_create(int device, wf_ctx **out);
+void wf_ctx_destroy(wf_ctx *ctx);
+const char *wf_last_error(void);
+/* Number of HIP devices visible (0 if none / no driver). */
+int wf_device_count(void);
+/* Blocks until all work queued on the context's stream has finished. */
+int wf_ctx_synchronize(wf_ctx *ctx);
+/* The context's hipStream_t (as void*), for callers that interleave their own work. */
+void *wf_ctx_stream(wf_ctx *ctx);
+
+/* Validates a parameter block without touching the device (is_constraint != 0: n_traces must be 1).
+ * The preconditions are the reference's assert!s: SURVEY.md §8b "Error convention". */
+int wf_params_check(const wf_params *p, int is_constraint);
+
+/* Size helpers (bytes). */
+size_t wf_elem_bytes(uint32_t field);
+size_t wf_row_width(const wf_params *p);           /* base elements per RowMatrix row */
+size_t wf_column_bytes(const wf_params *p);        /* one input/poly column */
+size_t wf_lde_bytes(const wf_params *p);           /* one trace's RowMatrix data */
+size_t wf_digests_bytes(const wf_params *p);       /* leaves (== nodes) array */
+
+/* ---- the path, host-buffer ("copy-out") form ------------------------------------------------------------------- */
+
+/* Prover::build_trace_commitment (prover/src/lib.rs:615-670):
+ *   interpolate every column of every trace (ColMatrix::interpolate_columns, col_matrix.rs:196-206),
+ *   evaluate the polynomials over the LDE domain into row-major matrices (RowMatrix::evaluate_polys_over::<8>,
+ *   row_matrix.rs:82-98), hash row j of all traces concatenated (commit_to_comb_rows, row_matrix.rs:204-238) and
+ *   build the Merkle tree (MerkleTree::new, merkle/mod.rs:117-136).
+ * trace_cols[t*n_cols + c] -> column c of trace t (host memory).  Outputs are caller-allocated host buffers:
+ *   polys_out[t*n_cols + c] (same shape as the input column; may be NULL to skip the copy-out of all polys),
+ *   lde_out[t] (wf_lde_bytes each; the array pointer may be NULL to skip), leaves_out / nodes_out
+ *   (wf_digests_bytes each; either may be NULL), root_out (32 bytes, may be NULL). */
+int wf_trace_commit(wf_ctx *ctx, const wf_params *p, const void *const *trace_cols, void *const *polys_out,
+                    void *const *lde_out, uint8_t *leaves_out, uint8_t *nodes_out, uint8_t *root_out);
+
+/* Prover::build_constraint_commitment (prover/src/lib.rs:680-715): composition-polynomial columns (coefficient
+ * form, CompositionPoly::data(), constraints/composition_poly.rs:21-41) -> RowMatrix::evaluate_polys_over::<8> ->
+ * commit_to_rows (row_matrix.rs:183-203).  p->n_traces must be 1. */
+int wf_constraint_commit(wf_ctx *ctx, const wf_params *p, const void *const *poly_cols, void *lde_out,
+                         uint8_t *leaves_out, uint8_t *nodes_out, uint8_t *root_out);
+
+/* ---- the path, device-resident form ---------------------------------------------------------------------------- */
+
+/* Same computations on caller-owned DEVICE buffers, asynchronous on `stream` (NULL = the context's stream):
+ *   d_trace : [n_traces][n_cols] columns, contiguous (wf_column_bytes each)            (read)
+ *   d_polys : same shape                                                                (written)
+ *   d_lde   : [n_traces] row-major matrices (wf_lde_bytes each)                         (written)
+ *   d_leaves, d_nodes : wf_digests_bytes each                                           (written)
+ * No host synchronisation happens inside; scratch comes from the context and is reused across calls. */
+int wf_trace_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_trace, void *d_polys, void *d_lde,
+                        void *d_leaves, void *d_nodes, void *stream);
+int wf_constraint_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_polys, void *d_lde, void *d_leaves,
+                             void *d_nodes, void *stream);
+
+/* ---- building blocks (each mirrors one reference function; host buffers) ---------------------------------------- */
+
+/* fft::evaluate_poly (math/src/fft/mod.rs:85): in place, n elements of ext_degree coordinates, natural order. */
+int wf_fft_evaluate_poly(wf_ctx *ctx, uint32_t field, uint32_t ext_degree, void *poly_inout, size_t n);
+/* fft::evaluate_poly_with_offset (mod.rs:171): result has n*blowup elements. */
+int wf_fft_evaluate_poly_with_offset(wf_ctx *ctx, uint32_t field, uint32_t ext_degree, const void *poly, size_t n,
+                                     const uint8_t domain_offset[16], size_t blowup, void *result);
+/* fft::interpolate_poly (mod.rs:274): in place. */
+int wf_fft_interpolate_poly(wf_ctx *ctx, uint32_t field, uint32_t ext_degree, void *evals_inout, size_t n);
+/* fft::interpolate_poly_with_offset (mod.rs:362), used by ConstraintEvaluationTable::into_comb_poly
+ * (prover/src/constraints/evaluation_table.rs:180-181): in place. */
+int wf_fft_interpolate_poly_with_offset(wf_ctx *ctx, uint32_t field, uint32_t ext_degree, void *evals_inout, size_t n,
+                                        const uint8_t domain_offset[16]);
+/* RowMatrix::evaluate_polys_over::<8> alone (row_matrix.rs:82-98): polys -> one row-major matrix. */
+int wf_evaluate_polys_over(wf_ctx *ctx, const wf_params *p, const void *const *poly_cols, void *lde_out);
+/* ElementHasher::hash_elements for Blake3_256 (crypto/src/hash/blake/mod.rs:46-59) applied to n_rows rows of
+ * row_elems base elements each (rows contiguous): digests_out gets n_rows*32 bytes. */
+int wf_hash_rows(wf_ctx *ctx, uint32_t field, const void *rows, size_t n_rows, size_t row_elems, uint8_t *digests_out);
+/* MerkleTree::new (crypto/src/merkle/mod.rs:117-136): leaves -> nodes (both n_leaves*32 bytes). */
+int wf_merkle_build(wf_ctx *ctx, const uint8_t *leaves, size_t n_leaves, uint8_t *nodes_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WF_LDE_H */

@@ -1,0 +1,18 @@
+"""Compile the HIP library in-tree (csrc/libwf_lde.so) for gfx950.  hipcc cross-compiles without a GPU."""
+import os
+import subprocess
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB = os.path.join(CSRC, "libwf_lde.so")
+
+
+def build(force: bool = False) -> str:
+    args = ["make", "-C", CSRC, "libwf_lde.so"]
+    if force:
+        args.insert(1, "-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB
+
+
+def lib_path() -> str:
+    return LIB

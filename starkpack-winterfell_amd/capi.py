@@ -1,0 +1,232 @@
+"""ctypes binding of libwf_lde.so -- the C ABI of include/wf_lde.h, nothing more.
+
+Arrays follow the reference's in-memory element types: f64 = numpy uint64 Montgomery residues; f128 = numpy
+uint64 with a trailing dimension of 2 (lo, hi).  There is no fallback: if the library is missing or no HIP device
+is present, loading / context creation raises WfError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import lib_path
+
+F64, F128 = 1, 2
+ELEM_WORDS = {F64: 1, F128: 2}
+
+SYMBOLS = [
+    "wf_ctx_create", "wf_ctx_destroy", "wf_last_error", "wf_device_count", "wf_ctx_synchronize", "wf_ctx_stream",
+    "wf_params_check", "wf_elem_bytes", "wf_row_width", "wf_column_bytes", "wf_lde_bytes", "wf_digests_bytes",
+    "wf_trace_commit", "wf_constraint_commit", "wf_trace_commit_dev", "wf_constraint_commit_dev",
+    "wf_fft_evaluate_poly", "wf_fft_evaluate_poly_with_offset", "wf_fft_interpolate_poly",
+    "wf_fft_interpolate_poly_with_offset", "wf_evaluate_polys_over", "wf_hash_rows", "wf_merkle_build",
+]
+
+
+class WfError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"wf_lde error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("field", C.c_uint32), ("ext_degree", C.c_uint32), ("log2_trace_len", C.c_uint32),
+        ("log2_blowup", C.c_uint32), ("n_cols", C.c_uint32), ("n_traces", C.c_uint32),
+        ("digest_bytes", C.c_uint32), ("reserved", C.c_uint32), ("domain_offset", C.c_uint8 * 16),
+    ]
+
+
+def make_params(field, ext_degree, log2_trace_len, log2_blowup, n_cols, n_traces=1, offset=None) -> Params:
+    if offset is None:
+        offset = 7 if field == F64 else 3  # ProofOptions::domain_offset = B::GENERATOR, air/src/options.rs:199-201
+    p = Params(field, ext_degree, log2_trace_len, log2_blowup, n_cols, n_traces, 32, 0)
+    p.domain_offset[:] = list(int(offset).to_bytes(16, "little"))
+    return p
+
+
+_lib = None
+
+
+def load():
+    """dlopen libwf_lde.so (raises if it has not been built)."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise WfError(-30, f"{path} not built (run __graft_entry__.build() / make -C csrc)")
+        L = C.CDLL(path)
+        vp, sz, u32, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int
+        PP = C.POINTER(Params)
+        L.wf_last_error.restype = C.c_char_p
+        L.wf_ctx_create.argtypes = [i32, C.POINTER(vp)]
+        L.wf_ctx_destroy.argtypes = [vp]
+        L.wf_ctx_destroy.restype = None
+        L.wf_ctx_synchronize.argtypes = [vp]
+        L.wf_ctx_stream.argtypes = [vp]
+        L.wf_ctx_stream.restype = vp
+        L.wf_params_check.argtypes = [PP, i32]
+        L.wf_elem_bytes.argtypes = [u32]
+        L.wf_elem_bytes.restype = sz
+        for n in ("wf_row_width", "wf_column_bytes", "wf_lde_bytes", "wf_digests_bytes"):
+            getattr(L, n).argtypes = [PP]
+            getattr(L, n).restype = sz
+        L.wf_trace_commit.argtypes = [vp, PP, vp, vp, vp, vp, vp, vp]
+        L.wf_constraint_commit.argtypes = [vp, PP, vp, vp, vp, vp, vp]
+        L.wf_trace_commit_dev.argtypes = [vp, PP, vp, vp, vp, vp, vp, vp]
+        L.wf_constraint_commit_dev.argtypes = [vp, PP, vp, vp, vp, vp, vp]
+        L.wf_fft_evaluate_poly.argtypes = [vp, u32, u32, vp, sz]
+        L.wf_fft_interpolate_poly.argtypes = [vp, u32, u32, vp, sz]
+        L.wf_fft_interpolate_poly_with_offset.argtypes = [vp, u32, u32, vp, sz, vp]
+        L.wf_fft_evaluate_poly_with_offset.argtypes = [vp, u32, u32, vp, sz, vp, sz, vp]
+        L.wf_evaluate_polys_over.argtypes = [vp, PP, vp, vp]
+        L.wf_hash_rows.argtypes = [vp, u32, vp, sz, sz, vp]
+        L.wf_merkle_build.argtypes = [vp, vp, sz, vp]
+        _lib = L
+    return _lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise WfError(rc, load().wf_last_error().decode())
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _ptr_array(arrs):
+    return (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+
+
+def _off16(offset: int):
+    return (C.c_uint8 * 16).from_buffer_copy(int(offset).to_bytes(16, "little"))
+
+
+def device_count() -> int:
+    return load().wf_device_count()
+
+
+class Context:
+    """wf_ctx wrapper: one per GPU."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        _check(load().wf_ctx_create(device, C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            load().wf_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(load().wf_ctx_synchronize(self._h))
+
+    @property
+    def stream(self) -> int:
+        return load().wf_ctx_stream(self._h) or 0
+
+    # -- the path, host buffers ------------------------------------------------------------------------------
+    def trace_commit(self, params: Params, trace_cols, want_lde=True, want_polys=True):
+        """trace_cols: flat list [trace][col] of column arrays.  Returns dict(polys, lde, leaves, nodes, root)."""
+        L = load()
+        _check(L.wf_params_check(C.byref(params), 0))
+        w = ELEM_WORDS[params.field]
+        cols = [np.ascontiguousarray(c, dtype=np.uint64) for c in trace_cols]
+        n_rows = 1 << (params.log2_trace_len + params.log2_blowup)
+        rw = L.wf_row_width(C.byref(params))
+        polys = [np.empty_like(c) for c in cols] if want_polys else None
+        lde = ([np.empty((n_rows, rw, w) if w > 1 else (n_rows, rw), dtype=np.uint64) for _ in range(params.n_traces)]
+               if want_lde else None)
+        leaves = np.empty((n_rows, 32), dtype=np.uint8)
+        nodes = np.empty((n_rows, 32), dtype=np.uint8)
+        root = np.empty(32, dtype=np.uint8)
+        _check(L.wf_trace_commit(self._h, C.byref(params), _ptr_array(cols),
+                                 _ptr_array(polys) if polys else None, _ptr_array(lde) if lde else None,
+                                 _p(leaves), _p(nodes), _p(root)))
+        return dict(polys=polys, lde=lde, leaves=leaves, nodes=nodes, root=bytes(root))
+
+    def constraint_commit(self, params: Params, poly_cols, want_lde=True):
+        L = load()
+        _check(L.wf_params_check(C.byref(params), 1))
+        w = ELEM_WORDS[params.field]
+        cols = [np.ascontiguousarray(c, dtype=np.uint64) for c in poly_cols]
+        n_rows = 1 << (params.log2_trace_len + params.log2_blowup)
+        rw = L.wf_row_width(C.byref(params))
+        lde = np.empty((n_rows, rw, w) if w > 1 else (n_rows, rw), dtype=np.uint64) if want_lde else None
+        leaves = np.empty((n_rows, 32), dtype=np.uint8)
+        nodes = np.empty((n_rows, 32), dtype=np.uint8)
+        root = np.empty(32, dtype=np.uint8)
+        _check(L.wf_constraint_commit(self._h, C.byref(params), _ptr_array(cols), _p(lde), _p(leaves), _p(nodes),
+                                      _p(root)))
+        return dict(lde=lde, leaves=leaves, nodes=nodes, root=bytes(root))
+
+    # -- the path, device buffers (raw device addresses, e.g. torch.Tensor.data_ptr()) ---------------------------
+    def trace_commit_dev(self, params: Params, d_trace: int, d_polys: int, d_lde: int, d_leaves: int, d_nodes: int,
+                         stream: int = 0):
+        _check(load().wf_trace_commit_dev(self._h, C.byref(params), d_trace, d_polys, d_lde, d_leaves, d_nodes,
+                                          stream or None))
+
+    def constraint_commit_dev(self, params: Params, d_polys: int, d_lde: int, d_leaves: int, d_nodes: int,
+                              stream: int = 0):
+        _check(load().wf_constraint_commit_dev(self._h, C.byref(params), d_polys, d_lde, d_leaves, d_nodes,
+                                               stream or None))
+
+    # -- building blocks -----------------------------------------------------------------------------------------
+    def fft_evaluate_poly(self, field, ext, poly: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(poly, dtype=np.uint64).copy()
+        n = a.size // (ELEM_WORDS[field] * ext)
+        _check(load().wf_fft_evaluate_poly(self._h, field, ext, _p(a), n))
+        return a
+
+    def fft_interpolate_poly(self, field, ext, evals: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(evals, dtype=np.uint64).copy()
+        n = a.size // (ELEM_WORDS[field] * ext)
+        _check(load().wf_fft_interpolate_poly(self._h, field, ext, _p(a), n))
+        return a
+
+    def fft_interpolate_poly_with_offset(self, field, ext, evals: np.ndarray, offset: int) -> np.ndarray:
+        a = np.ascontiguousarray(evals, dtype=np.uint64).copy()
+        n = a.size // (ELEM_WORDS[field] * ext)
+        _check(load().wf_fft_interpolate_poly_with_offset(self._h, field, ext, _p(a), n, _off16(offset)))
+        return a
+
+    def fft_evaluate_poly_with_offset(self, field, ext, poly: np.ndarray, offset: int, blowup: int) -> np.ndarray:
+        a = np.ascontiguousarray(poly, dtype=np.uint64)
+        w = ELEM_WORDS[field]
+        n = a.size // (w * ext)
+        out = np.empty((n * blowup * ext, w) if w > 1 else (n * blowup * ext,), dtype=np.uint64)
+        _check(load().wf_fft_evaluate_poly_with_offset(self._h, field, ext, _p(a), n, _off16(offset), blowup, _p(out)))
+        return out
+
+    def evaluate_polys_over(self, params: Params, poly_cols) -> np.ndarray:
+        L = load()
+        _check(L.wf_params_check(C.byref(params), 1))
+        w = ELEM_WORDS[params.field]
+        cols = [np.ascontiguousarray(c, dtype=np.uint64) for c in poly_cols]
+        n_rows = 1 << (params.log2_trace_len + params.log2_blowup)
+        rw = L.wf_row_width(C.byref(params))
+        lde = np.empty((n_rows, rw, w) if w > 1 else (n_rows, rw), dtype=np.uint64)
+        _check(L.wf_evaluate_polys_over(self._h, C.byref(params), _ptr_array(cols), _p(lde)))
+        return lde
+
+    def hash_rows(self, field, rows: np.ndarray, n_rows: int, row_elems: int) -> np.ndarray:
+        a = np.ascontiguousarray(rows, dtype=np.uint64)
+        out = np.empty((n_rows, 32), dtype=np.uint8)
+        _check(load().wf_hash_rows(self._h, field, _p(a), n_rows, row_elems, _p(out)))
+        return out
+
+    def merkle_build(self, leaves: np.ndarray) -> np.ndarray:
+        lv = np.ascontiguousarray(leaves, dtype=np.uint8).reshape(-1, 32)
+        nodes = np.empty_like(lv)
+        _check(load().wf_merkle_build(self._h, _p(lv), lv.shape[0], _p(nodes)))
+        return nodes

@@ -1,0 +1,156 @@
+// BLAKE3 (default hash mode, 32-byte output) for gfx950, written from the public specification
+// (SURVEY.md Appendix C).  Replaces the `blake3` crate calls of /root/reference/crypto/src/hash/blake/mod.rs:27-59.
+// One lane hashes one message; all 16 state words and 16 message words live in VGPRs, the message permutation is
+// resolved at compile time (no register moves), rotations map to v_alignbit_b32.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wf {
+namespace b3 {
+
+enum : uint32_t { CHUNK_START = 1, CHUNK_END = 2, PARENT = 4, ROOT = 8 };
+
+__device__ __constant__ const uint32_t IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au,
+                                                0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+
+// message word index used at position i of round r (sigma applied r times)
+__host__ __device__ constexpr int sched(int r, int i) {
+    constexpr int P[16] = {2, 6, 3, 10, 7, 0, 4, 13, 1, 11, 12, 5, 9, 14, 15, 8};
+    int idx = i;
+    for (int k = 0; k < r; k++) idx = P[idx];
+    return idx;
+}
+
+__device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return __builtin_rotateright32(x, n); }
+
+#define WF_B3_G(a, b, c, d, mx, my) \
+    a = a + b + (mx);               \
+    d = rotr(d ^ a, 16);            \
+    c = c + d;                      \
+    b = rotr(b ^ c, 12);            \
+    a = a + b + (my);               \
+    d = rotr(d ^ a, 8);             \
+    c = c + d;                      \
+    b = rotr(b ^ c, 7);
+
+template <int R>
+__device__ __forceinline__ void round_fn(uint32_t (&v)[16], const uint32_t (&m)[16]) {
+    WF_B3_G(v[0], v[4], v[8], v[12], m[sched(R, 0)], m[sched(R, 1)])
+    WF_B3_G(v[1], v[5], v[9], v[13], m[sched(R, 2)], m[sched(R, 3)])
+    WF_B3_G(v[2], v[6], v[10], v[14], m[sched(R, 4)], m[sched(R, 5)])
+    WF_B3_G(v[3], v[7], v[11], v[15], m[sched(R, 6)], m[sched(R, 7)])
+    WF_B3_G(v[0], v[5], v[10], v[15], m[sched(R, 8)], m[sched(R, 9)])
+    WF_B3_G(v[1], v[6], v[11], v[12], m[sched(R, 10)], m[sched(R, 11)])
+    WF_B3_G(v[2], v[7], v[8], v[13], m[sched(R, 12)], m[sched(R, 13)])
+    WF_B3_G(v[3], v[4], v[9], v[14], m[sched(R, 14)], m[sched(R, 15)])
+}
+
+// cv <- first 8 words of compress(cv, m, counter, block_len, flags)
+__device__ __forceinline__ void compress(uint32_t (&cv)[8], const uint32_t (&m)[16], uint32_t counter_lo,
+                                         uint32_t counter_hi, uint32_t block_len, uint32_t flags) {
+    uint32_t v[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = cv[i];
+    v[8] = 0x6A09E667u;
+    v[9] = 0xBB67AE85u;
+    v[10] = 0x3C6EF372u;
+    v[11] = 0xA54FF53Au;
+    v[12] = counter_lo;
+    v[13] = counter_hi;
+    v[14] = block_len;
+    v[15] = flags;
+    round_fn<0>(v, m);
+    round_fn<1>(v, m);
+    round_fn<2>(v, m);
+    round_fn<3>(v, m);
+    round_fn<4>(v, m);
+    round_fn<5>(v, m);
+    round_fn<6>(v, m);
+#pragma unroll
+    for (int i = 0; i < 8; i++) cv[i] = v[i] ^ v[i + 8];
+}
+
+__device__ __forceinline__ void set_iv(uint32_t (&cv)[8]) {
+    cv[0] = 0x6A09E667u;
+    cv[1] = 0xBB67AE85u;
+    cv[2] = 0x3C6EF372u;
+    cv[3] = 0xA54FF53Au;
+    cv[4] = 0x510E527Fu;
+    cv[5] = 0x9B05688Cu;
+    cv[6] = 0x1F83D9ABu;
+    cv[7] = 0x5BE0CD19u;
+}
+
+// Blake3_256::merge (blake/mod.rs:31-33): hash of two concatenated 32-byte digests = one compression.
+__device__ __forceinline__ void merge(const uint32_t (&m)[16], uint32_t (&out)[8]) {
+    set_iv(out);
+    compress(out, m, 0, 0, 64, CHUNK_START | CHUNK_END | ROOT);
+}
+
+// Hash of a message of `len` bytes (len a multiple of 4) delivered block by block:
+// load(block_index, m) must fill the 16 words of 64-byte block `block_index`, zero-padded past `len`.
+// MAX_DEPTH bounds the subtree stack: messages up to 2^MAX_DEPTH KiB.
+template <class LoadBlock, int MAX_DEPTH = 20>
+__device__ __forceinline__ void hash_stream(uint64_t len, LoadBlock load, uint32_t (&out)[8]) {
+    uint32_t m[16];
+    if (len <= 1024) {
+        set_iv(out);
+        uint32_t nblocks = len == 0 ? 1u : (uint32_t)((len + 63) >> 6);
+        for (uint32_t b = 0; b < nblocks; b++) {
+            load((uint64_t)b, m);
+            uint32_t blen = (uint32_t)(len - (uint64_t)b * 64 < 64 ? len - (uint64_t)b * 64 : 64);
+            uint32_t flags = (b == 0 ? CHUNK_START : 0u) | (b == nblocks - 1 ? (CHUNK_END | ROOT) : 0u);
+            compress(out, m, 0, 0, blen, flags);
+        }
+        return;
+    }
+    uint32_t stack[MAX_DEPTH][8];
+    int sp = 0;
+    uint64_t nchunks = (len + 1023) >> 10;
+    uint32_t cv[8];
+    for (uint64_t c = 0; c < nchunks; c++) {
+        uint64_t clen = len - c * 1024 < 1024 ? len - c * 1024 : 1024;
+        uint32_t nblocks = (uint32_t)((clen + 63) >> 6);
+        set_iv(cv);
+        for (uint32_t b = 0; b < nblocks; b++) {
+            load(c * 16 + b, m);
+            uint32_t blen = (uint32_t)(clen - (uint64_t)b * 64 < 64 ? clen - (uint64_t)b * 64 : 64);
+            uint32_t flags = (b == 0 ? CHUNK_START : 0u) | (b == nblocks - 1 ? (uint32_t)CHUNK_END : 0u);
+            compress(cv, m, (uint32_t)c, (uint32_t)(c >> 32), blen, flags);
+        }
+        if (c + 1 < nchunks) {
+            uint64_t total = c + 1;
+            while ((total & 1) == 0) {  // merge completed subtrees
+                sp--;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    m[i] = stack[sp][i];
+                    m[8 + i] = cv[i];
+                }
+                set_iv(cv);
+                compress(cv, m, 0, 0, 64, PARENT);
+                total >>= 1;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) stack[sp][i] = cv[i];
+            sp++;
+        }
+    }
+    while (sp > 0) {
+        sp--;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            m[i] = stack[sp][i];
+            m[8 + i] = cv[i];
+        }
+        set_iv(cv);
+        compress(cv, m, 0, 0, 64, PARENT | (sp == 0 ? (uint32_t)ROOT : 0u));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = cv[i];
+}
+
+}  // namespace b3
+}  // namespace wf

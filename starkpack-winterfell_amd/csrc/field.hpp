@@ -1,0 +1,179 @@
+// Base-field arithmetic shared by host (table construction) and device (kernels).
+//
+// F64  : Goldilocks p = 2^64 - 2^32 + 1, values are Montgomery residues x*2^64 mod p in [0,p), i.e. exactly the
+//        in-memory form of the reference's f64::BaseElement (math/src/field/f64/mod.rs:48-53), so buffers can be
+//        handed to / taken from a winter-prover process without conversion.
+// F128 : p = 2^128 - 45*2^40 + 1, canonical integers in [0,p) (math/src/field/f128/mod.rs:35, IS_CANONICAL :73).
+//
+// Every operation returns the unique fully reduced representative, which is what makes results bit-identical to
+// the reference whatever the evaluation order.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WF_HD __host__ __device__ __forceinline__
+
+namespace wf {
+
+typedef unsigned __int128 u128;
+
+// ------------------------------------------------------------------------------------------------ F64
+struct F64 {
+    typedef uint64_t T;
+    static constexpr uint64_t P = 0xFFFFFFFF00000001ull;
+    static constexpr uint64_t R2 = 0xFFFFFFFE00000001ull;  // 2^128 mod p
+    static constexpr uint32_t TWO_ADICITY = 32;
+    static constexpr uint64_t TWO_ADIC_ROOT = 7277203076849721926ull;  // canonical; order 2^32
+    static constexpr int BYTES = 8;
+    static constexpr int FIELD_ID = 1;
+
+    static WF_HD T zero() { return 0; }
+    static WF_HD T one() { return 0xFFFFFFFFull; }  // 2^64 mod p
+
+    // x * 2^-64 mod p for x < p * 2^64
+    static WF_HD uint64_t mont_reduce(uint64_t xl, uint64_t xh) {
+        uint64_t a = xl + (xl << 32);
+        uint64_t e = a < xl;
+        uint64_t b = a - (a >> 32) - e;
+        uint64_t r = xh - b;
+        return xh < b ? r - 0xFFFFFFFFull : r;
+    }
+    static WF_HD T mul(T a, T b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint64_t lo = a * b, hi = __umul64hi(a, b);
+#else
+        u128 x = (u128)a * (u128)b;
+        uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+#endif
+        return mont_reduce(lo, hi);
+    }
+    static WF_HD T add(T a, T b) {
+        uint64_t t = P - b;
+        uint64_t r = a - t;
+        return a < t ? r - 0xFFFFFFFFull : r;
+    }
+    static WF_HD T sub(T a, T b) {
+        uint64_t r = a - b;
+        return a < b ? r - 0xFFFFFFFFull : r;
+    }
+    static WF_HD T from_canonical(uint64_t v) { return mul(v % P, R2); }
+    static WF_HD uint64_t to_canonical(T x) { return mont_reduce(x, 0); }
+    static WF_HD T from_u128_canonical(u128 v) { return from_canonical((uint64_t)(v % (u128)P)); }
+    static WF_HD bool is_valid(T x) { return x < P; }
+};
+
+// ------------------------------------------------------------------------------------------------ F128
+struct U128 {
+    uint64_t lo, hi;
+};
+
+struct F128 {
+    typedef U128 T;
+    static constexpr uint32_t TWO_ADICITY = 40;
+    static constexpr int BYTES = 16;
+    static constexpr int FIELD_ID = 2;
+    // p = 2^128 - C, C = 45*2^40 - 1
+    static constexpr uint64_t P_LO = 0xFFFFD30000000001ull, P_HI = 0xFFFFFFFFFFFFFFFFull;
+    static constexpr uint64_t C_LO = 0x00002CFFFFFFFFFFull;  // 45*2^40 - 1 (46 bits)
+
+    static WF_HD u128 P() { return ((u128)P_HI << 64) | (u128)P_LO; }
+    static WF_HD u128 w(T a) { return ((u128)a.hi << 64) | (u128)a.lo; }
+    static WF_HD T n(u128 v) { return T{(uint64_t)v, (uint64_t)(v >> 64)}; }
+
+    static WF_HD T zero() { return T{0, 0}; }
+    static WF_HD T one() { return T{1, 0}; }
+    static WF_HD T add(T a, T b) {
+        u128 x = w(a), z = P() - w(b);
+        return n(x < z ? x + w(b) : x - z);
+    }
+    static WF_HD T sub(T a, T b) {
+        u128 x = w(a), y = w(b);
+        return n(x < y ? P() - y + x : x - y);
+    }
+    // 64x64 -> 128
+    static WF_HD void mul64(uint64_t a, uint64_t b, uint64_t &lo, uint64_t &hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        lo = a * b;
+        hi = __umul64hi(a, b);
+#else
+        u128 x = (u128)a * (u128)b;
+        lo = (uint64_t)x;
+        hi = (uint64_t)(x >> 64);
+#endif
+    }
+    // (a * b) mod p : 256-bit schoolbook product folded twice with 2^128 = C (mod p)
+    static WF_HD T mul(T a, T b) {
+        uint64_t p0l, p0h, p1l, p1h, p2l, p2h, p3l, p3h;
+        mul64(a.lo, b.lo, p0l, p0h);
+        mul64(a.lo, b.hi, p1l, p1h);
+        mul64(a.hi, b.lo, p2l, p2h);
+        mul64(a.hi, b.hi, p3l, p3h);
+        // r0..r3 : 64-bit limbs of the product
+        uint64_t r0 = p0l;
+        u128 acc = (u128)p0h + p1l + p2l;
+        uint64_t r1 = (uint64_t)acc;
+        acc = (acc >> 64) + p1h + p2h + p3l;
+        uint64_t r2 = (uint64_t)acc;
+        uint64_t r3 = (uint64_t)(acc >> 64) + p3h;
+        // fold: H = r3:r2 (128 bits), L = r1:r0 ; x = L + H*C, H*C < 2^174
+        uint64_t h0l, h0h, h1l, h1h;
+        mul64(r2, C_LO, h0l, h0h);
+        mul64(r3, C_LO, h1l, h1h);
+        u128 t = (u128)r0 + h0l;
+        uint64_t s0 = (uint64_t)t;
+        t = (t >> 64) + r1 + h0h + h1l;
+        uint64_t s1 = (uint64_t)t;
+        uint64_t s2 = (uint64_t)(t >> 64) + h1h;  // < 2^47
+        // second fold: s2 * C < 2^93
+        uint64_t g_l, g_h;
+        mul64(s2, C_LO, g_l, g_h);
+        u128 low = ((u128)s1 << 64) | s0;
+        u128 g = ((u128)g_h << 64) | g_l;
+        u128 z = low + g;
+        bool carry = z < low;  // value = z + carry*2^128 = z + carry*C (mod p)
+        if (carry) z += (u128)C_LO;  // cannot carry again: z < 2^93 here
+        if (z >= P()) z -= P();
+        return n(z);
+    }
+    static WF_HD T from_u128_canonical(u128 v) { return n(v % P()); }
+    static WF_HD bool is_valid(T x) { return w(x) < P(); }
+};
+
+// ------------------------------------------------------------------------------------------------ generic helpers
+template <class F>
+WF_HD typename F::T f_pow(typename F::T b, u128 e) {
+    typename F::T r = F::one();
+    while (e) {
+        if (e & 1) r = F::mul(r, b);
+        b = F::mul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+
+template <class F>
+struct FieldInfo;
+template <>
+struct FieldInfo<F64> {
+    static u128 modulus() { return (u128)F64::P; }
+    static F64::T two_adic_root() { return F64::from_canonical(F64::TWO_ADIC_ROOT); }
+};
+template <>
+struct FieldInfo<F128> {
+    static u128 modulus() { return F128::P(); }
+    // 23953097886125630542083529559205016746 (order 2^40), math/src/field/f128/mod.rs:38
+    static F128::T two_adic_root() { return F128::T{0x86B8723E1920F4AAull, 0x120532E7B364080Aull}; }
+};
+
+template <class F>
+inline typename F::T f_inv(typename F::T x) {
+    return f_pow<F>(x, FieldInfo<F>::modulus() - 2);
+}
+// root of unity of order 2^n (math/src/field/traits.rs:254-263)
+template <class F>
+inline typename F::T f_root_of_unity(uint32_t n) {
+    return f_pow<F>(FieldInfo<F>::two_adic_root(), (u128)1 << (F::TWO_ADICITY - n));
+}
+
+}  // namespace wf

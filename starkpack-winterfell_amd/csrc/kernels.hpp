@@ -1,0 +1,466 @@
+// HIP kernels of the LDE + commitment path (gfx950).  See DESIGN.md for the pass structure and data layout.
+//
+// NTT of size N = 2^L is split into 1..4 "digit" passes (digits of <= 11 bits).  Input index
+// n = (n1, n2, .., nP) (n1 most significant), output index k = k1 + N1*k2 + N1*N2*k3 + ..  Pass i transforms digit
+// n_i -> k_i in place, inside LDS, for a tile of adjacent inner positions, then multiplies by the inter-pass
+// twiddle w_{Ni*..*NP}^(k_i * inner).  The last pass has inner = 1 (contiguous rows) and scatters its outputs to
+// natural order: column-major polynomials (interpolation) or the row-major LDE matrix (evaluation on a coset).
+// Nothing is ever bit-reverse permuted in memory (the reference's permute passes, math/src/fft/fft_inputs.rs:56-64
+// and prover/src/matrix/segments.rs:276-298, disappear into the index arithmetic).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "blake3_dev.hpp"
+#include "field.hpp"
+
+namespace wf {
+
+// Two-level table of powers of one base g: g^e = lo[e & mask] * hi[e >> s].
+template <class F>
+struct Pow2L {
+    const typename F::T *lo;
+    const typename F::T *hi;
+    uint32_t s;
+    uint32_t mask;
+    __device__ __forceinline__ typename F::T get(uint64_t e) const {
+        typename F::T a = lo[e & mask];
+        uint64_t h = e >> s;
+        if (h) a = F::mul(a, hi[h]);
+        return a;
+    }
+};
+
+enum : uint32_t { SCALE_NONE = 0, SCALE_CONST = 1, SCALE_SERIES = 2 };
+enum : uint32_t { OUT_COLS = 0, OUT_ROWS = 1 };
+
+template <class F>
+struct NttArgs {
+    typedef typename F::T T;
+    const T *src;
+    T *dst;
+    // transform
+    uint32_t logN;     // full transform size
+    uint32_t logD;     // this pass's digit
+    uint32_t W;        // coordinates per element (extension degree)
+    uint32_t Tl;       // tile: adjacent inner positions (strided pass) or adjacent k1 rows (last pass)
+    uint32_t GC;       // last pass, OUT_ROWS: columns per work-group
+    uint32_t V;        // values per LDS row = Tl*GC*W
+    uint64_t I;        // strided pass: inner count (product of later digits)
+    uint64_t O;        // outer count (product of earlier digits)
+    uint32_t n_prev;   // last pass: number of earlier digits and their sizes (most significant first)
+    uint32_t prev_log[3];
+    // batch
+    uint32_t TC;        // columns (all traces)
+    uint32_t n_cosets;  // 1 for interpolation
+    uint32_t src_by_tc; // strided pass: source column = tc (shared by all cosets) instead of the batch slot
+    uint64_t col_elems; // elements per column (= N)
+    // twiddles: powers of the N-th root used by this transform (forward or inverse)
+    Pow2L<F> tw;
+    // coset pre-scale h_c^n (first pass of an evaluation); tables for coset c at lo + c*pre_lo_stride
+    uint32_t pre_on;
+    Pow2L<F> pre;
+    uint64_t pre_lo_stride, pre_hi_stride;
+    // output scaling of the last pass
+    uint32_t scale_mode;
+    T scale;            // SCALE_CONST
+    Pow2L<F> out_pow;   // SCALE_SERIES: multiply output k by out_pow^k (lo table pre-multiplied by 1/n)
+    // OUT_ROWS
+    uint32_t out_mode;
+    uint32_t n_cols;     // columns per trace
+    uint32_t log_blowup;
+    uint64_t row_width;  // base elements per output row
+    uint64_t trace_lde_elems;  // elements per trace matrix
+};
+
+__device__ __forceinline__ uint32_t digit_reverse(uint32_t pos, uint32_t logD) {
+    // LDS position -> output index of the in-LDS transform (radix-4 digits, a trailing radix-2 digit if logD is odd)
+    uint32_t k = 0, cur = logD, sh = 0;
+    while (cur >= 2) {
+        k |= ((pos >> (cur - 2)) & 3u) << sh;
+        sh += 2;
+        cur -= 2;
+    }
+    if (cur == 1) k |= (pos & 1u) << sh;
+    return k;
+}
+
+// In-place NTT of D = 2^logD rows of V values each, held in LDS as x[row*V + v]; twd[e] = w_D^e.
+// Natural order in, digit-reversed order out (see digit_reverse).
+template <class F>
+__device__ __forceinline__ void lds_ntt(typename F::T *x, const typename F::T *twd, uint32_t logD, uint32_t V) {
+    typedef typename F::T T;
+    const uint32_t D = 1u << logD;
+    const bool vpow2 = (V & (V - 1)) == 0;
+    const uint32_t vshift = 31 - __builtin_clz(V);
+    uint32_t cur = logD;
+    T w4 = F::one();
+    if (logD >= 2) w4 = twd[D >> 2];
+    while (cur > 0) {
+        __syncthreads();
+        if (cur >= 2) {
+            const uint32_t mlog = cur - 2, m = 1u << mlog;
+            const uint32_t nwork = (D >> 2) * V;
+            const uint32_t tstep = 1u << (logD - cur);
+            const uint32_t st = m * V;
+            for (uint32_t wk = threadIdx.x; wk < nwork; wk += blockDim.x) {
+                uint32_t u, v;
+                if (vpow2) {
+                    u = wk >> vshift;
+                    v = wk & (V - 1);
+                } else {
+                    u = wk / V;
+                    v = wk - u * V;
+                }
+                const uint32_t jp = u & (m - 1), p = u >> mlog;
+                const uint32_t base = ((p << cur) + jp) * V + v;
+                T x0 = x[base], x1 = x[base + st], x2 = x[base + 2 * st], x3 = x[base + 3 * st];
+                T a = F::add(x0, x2), b = F::sub(x0, x2), c = F::add(x1, x3), d = F::mul(F::sub(x1, x3), w4);
+                T y0 = F::add(a, c), y2 = F::sub(a, c), y1 = F::add(b, d), y3 = F::sub(b, d);
+                if (jp != 0) {
+                    const uint32_t e = jp * tstep;
+                    y1 = F::mul(y1, twd[e]);
+                    y2 = F::mul(y2, twd[2 * e]);
+                    y3 = F::mul(y3, twd[3 * e]);
+                }
+                x[base] = y0;
+                x[base + st] = y1;
+                x[base + 2 * st] = y2;
+                x[base + 3 * st] = y3;
+            }
+            cur -= 2;
+        } else {
+            const uint32_t nwork = (D >> 1) * V;
+            for (uint32_t wk = threadIdx.x; wk < nwork; wk += blockDim.x) {
+                uint32_t u, v;
+                if (vpow2) {
+                    u = wk >> vshift;
+                    v = wk & (V - 1);
+                } else {
+                    u = wk / V;
+                    v = wk - u * V;
+                }
+                const uint32_t base = (u << 1) * V + v;
+                T x0 = x[base], x1 = x[base + V];
+                x[base] = F::add(x0, x1);
+                x[base + V] = F::sub(x0, x1);
+            }
+            cur = 0;
+        }
+    }
+    __syncthreads();
+}
+
+template <class F>
+__device__ __forceinline__ void build_digit_twiddles(typename F::T *twd, const Pow2L<F> &tw, uint32_t logN,
+                                                     uint32_t logD) {
+    const uint32_t D = 1u << logD;
+    for (uint32_t e = threadIdx.x; e < D; e += blockDim.x) twd[e] = tw.get((uint64_t)e << (logN - logD));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Strided pass: view [O][D][I] of every column (I contiguous), transform the D axis for a tile of Tl inner positions.
+// grid.x = batch * O * (I / Tl)
+template <class F>
+__global__ void __launch_bounds__(1024) k_ntt_strided(NttArgs<F> a) {
+    typedef typename F::T T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const uint32_t D = 1u << a.logD, V = a.V;
+    T *x = reinterpret_cast<T *>(smem_raw);
+    T *twd = x + (size_t)D * V;
+
+    const uint64_t tiles = a.I / a.Tl;
+    uint64_t bid = blockIdx.x;
+    const uint64_t tile = bid % tiles;
+    bid /= tiles;
+    const uint64_t o = bid % a.O;
+    const uint64_t b = bid / a.O;
+    const uint32_t c = (uint32_t)(b / a.TC);
+    const uint32_t tc = (uint32_t)(b - (uint64_t)c * a.TC);
+    const uint64_t i0 = tile * a.Tl;
+    const T *src = a.src + (a.src_by_tc ? (uint64_t)tc : b) * a.col_elems * a.W;
+    T *dst = a.dst + b * a.col_elems * a.W;
+
+    build_digit_twiddles<F>(twd, a.tw, a.logN, a.logD);
+
+    Pow2L<F> pre = a.pre;
+    if (a.pre_on) {
+        pre.lo += (uint64_t)c * a.pre_lo_stride;
+        pre.hi += (uint64_t)c * a.pre_hi_stride;
+    }
+    const uint32_t total = D * V;
+    for (uint32_t wk = threadIdx.x; wk < total; wk += blockDim.x) {
+        const uint32_t d = wk / V, v = wk - d * V;
+        const uint64_t g = ((o * D + d) * a.I + i0) * a.W + v;
+        T val = src[g];
+        if (a.pre_on) {
+            const uint64_t n = (uint64_t)d * a.I + i0 + v / a.W;  // coefficient index (O == 1 on this pass)
+            val = F::mul(val, pre.get(n));
+        }
+        x[wk] = val;
+    }
+    lds_ntt<F>(x, twd, a.logD, V);
+    // inter-pass twiddle w_{D*I}^(k*i) = w_N^(k*i*N/(D*I)), store with digit d -> k
+    const uint32_t tw_shift = a.logN - a.logD - (63 - __builtin_clzll(a.I));
+    for (uint32_t wk = threadIdx.x; wk < total; wk += blockDim.x) {
+        const uint32_t pos = wk / V, v = wk - pos * V;
+        const uint32_t k = digit_reverse(pos, a.logD);
+        const uint64_t i = i0 + v / a.W;
+        const uint64_t e = ((uint64_t)k * i) << tw_shift;
+        T val = x[wk];
+        if (e) val = F::mul(val, a.tw.get(e));
+        dst[((o * D + k) * a.I + i0) * a.W + v] = val;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Last pass: view [O][D] (D contiguous).  OUT_COLS: one column, Tl adjacent k1 rows -> natural-order column.
+// OUT_ROWS: GC columns of one coset, one row tile -> row-major LDE matrix rows k*blowup + c.
+// grid.x = batch * (O / Tl)   with batch = n_cosets * (TC or traces*groups)
+template <class F>
+__global__ void __launch_bounds__(1024) k_ntt_last(NttArgs<F> a) {
+    typedef typename F::T T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const uint32_t D = 1u << a.logD, V = a.V, W = a.W;
+    T *x = reinterpret_cast<T *>(smem_raw);
+    T *twd = x + (size_t)D * V;
+
+    // tiles over the most significant earlier digit k1
+    const uint32_t log1 = a.n_prev ? a.prev_log[0] : 0;
+    const uint64_t O_lo = a.O >> log1;              // combinations of the remaining earlier digits
+    const uint64_t k1_tiles = ((uint64_t)1 << log1) / a.Tl;
+    const uint64_t tiles = k1_tiles * O_lo;
+    uint64_t bid = blockIdx.x;
+    const uint64_t tile = bid % tiles;
+    const uint64_t b = bid / tiles;
+    const uint64_t k1_0 = (tile % k1_tiles) * a.Tl;
+    const uint64_t o_rest = tile / k1_tiles;
+    // natural output index contributed by the earlier digits other than k1
+    uint64_t rev_rest = 0;
+    {
+        uint64_t r = o_rest;
+        uint32_t sh_out = log1;
+        // o_rest = (k2, k3, ..) with k2 most significant
+        uint32_t bits_rest = 0;
+        for (uint32_t i = 1; i < a.n_prev; i++) bits_rest += a.prev_log[i];
+        uint32_t hi = bits_rest;
+        for (uint32_t i = 1; i < a.n_prev; i++) {
+            hi -= a.prev_log[i];
+            const uint64_t dig = (r >> hi) & (((uint64_t)1 << a.prev_log[i]) - 1);
+            rev_rest |= dig << sh_out;
+            sh_out += a.prev_log[i];
+        }
+    }
+
+    // batch decode
+    uint32_t c, col0, trace = 0, ncol_here;
+    const T *src_base;
+    if (a.out_mode == OUT_ROWS) {
+        const uint32_t groups = (a.n_cols + a.GC - 1) / a.GC;
+        const uint32_t n_traces = a.TC / a.n_cols;
+        const uint32_t g = (uint32_t)(b % groups);
+        const uint64_t r2 = b / groups;
+        trace = (uint32_t)(r2 % n_traces);
+        c = (uint32_t)(r2 / n_traces);
+        col0 = g * a.GC;
+        ncol_here = min(a.GC, a.n_cols - col0);
+        const uint64_t slot0 = a.src_by_tc ? (uint64_t)trace * a.n_cols + col0
+                                           : ((uint64_t)c * a.TC + (uint64_t)trace * a.n_cols + col0);
+        src_base = a.src + slot0 * a.col_elems * W;
+    } else {
+        c = 0;
+        col0 = 0;
+        ncol_here = 1;
+        src_base = a.src + b * a.col_elems * W;
+    }
+
+    build_digit_twiddles<F>(twd, a.tw, a.logN, a.logD);
+    Pow2L<F> pre = a.pre;
+    if (a.pre_on) {
+        pre.lo += (uint64_t)c * a.pre_lo_stride;
+        pre.hi += (uint64_t)c * a.pre_hi_stride;
+    }
+
+    // load: line = (t_in, cg); a line is D*W contiguous values; read in 8-value chunks per line
+    const uint32_t lines = a.Tl * a.GC;
+    const uint32_t line_vals = D * W;
+    const uint32_t CH = (line_vals % 8 == 0) ? 8 : 1;
+    const uint32_t total = D * V;
+    for (uint32_t wk = threadIdx.x; wk < total; wk += blockDim.x) {
+        const uint32_t gg = wk % CH;
+        const uint32_t r = wk / CH;
+        const uint32_t line = r % lines;
+        const uint32_t g = (r / lines) * CH + gg;  // value index inside the line
+        const uint32_t t_in = line / a.GC, cg = line - t_in * a.GC;
+        const uint32_t d = g / W, w = g - d * W;
+        T val = F::zero();
+        if (cg < ncol_here) {
+            const uint64_t o_t = ((k1_0 + t_in) * O_lo) + o_rest;
+            val = src_base[((uint64_t)cg * a.col_elems + o_t * D) * W + g];
+            if (a.pre_on) val = F::mul(val, pre.get(d));  // single-pass evaluation: coefficient index = d
+        }
+        x[d * V + line * W + w] = val;
+    }
+    lds_ntt<F>(x, twd, a.logD, V);
+
+    if (a.out_mode == OUT_COLS) {
+        T *dst = a.dst + b * a.col_elems * W;
+        for (uint32_t wk = threadIdx.x; wk < total; wk += blockDim.x) {
+            const uint32_t pos = wk / V, v = wk - pos * V;
+            const uint32_t t_in = v / W, w = v - t_in * W;
+            const uint64_t k = (k1_0 + t_in) + rev_rest + ((uint64_t)digit_reverse(pos, a.logD) << (a.logN - a.logD));
+            T val = x[wk];
+            if (a.scale_mode == SCALE_CONST)
+                val = F::mul(val, a.scale);
+            else if (a.scale_mode == SCALE_SERIES)
+                val = F::mul(val, a.out_pow.get(k));
+            dst[k * W + w] = val;
+        }
+    } else {
+        T *dst = a.dst + (uint64_t)trace * a.trace_lde_elems + (uint64_t)col0 * W;
+        const uint32_t vw = a.GC * W;  // values per (t_in) chunk
+        for (uint32_t wk = threadIdx.x; wk < total; wk += blockDim.x) {
+            const uint32_t pos = wk / V, v = wk - pos * V;
+            const uint32_t t_in = v / vw, cv = v - t_in * vw;
+            if (cv >= ncol_here * W) continue;
+            const uint64_t k = (k1_0 + t_in) + rev_rest + ((uint64_t)digit_reverse(pos, a.logD) << (a.logN - a.logD));
+            const uint64_t row = (k << a.log_blowup) + c;
+            dst[row * a.row_width + cv] = x[wk];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Leaf hashing: leaf j = BLAKE3(canonical LE bytes of row j of trace 0 || row j of trace 1 || ..)
+// (RowMatrix::commit_to_comb_rows, prover/src/matrix/row_matrix.rs:204-238; Blake3_256::hash_elements,
+// crypto/src/hash/blake/mod.rs:46-59).  One lane per row.
+template <class F>
+struct HashArgs {
+    const typename F::T *lde;   // [n_traces] matrices
+    uint64_t trace_elems;       // elements per matrix
+    uint64_t n_rows;
+    uint32_t row_width;         // elements per stored row
+    uint32_t epr;               // elements of a row that are hashed (elements_per_row)
+    uint32_t n_traces;
+    uint32_t *leaves;           // n_rows * 8 words
+};
+
+template <class F>
+__device__ __forceinline__ void elem_words(typename F::T v, uint32_t *w);
+template <>
+__device__ __forceinline__ void elem_words<F64>(uint64_t v, uint32_t *w) {
+    const uint64_t c = F64::to_canonical(v);  // f64/mod.rs:605-610: canonical as_int(), little endian
+    w[0] = (uint32_t)c;
+    w[1] = (uint32_t)(c >> 32);
+}
+template <>
+__device__ __forceinline__ void elem_words<F128>(U128 v, uint32_t *w) {
+    w[0] = (uint32_t)v.lo;
+    w[1] = (uint32_t)(v.lo >> 32);
+    w[2] = (uint32_t)v.hi;
+    w[3] = (uint32_t)(v.hi >> 32);
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) k_hash_rows(HashArgs<F> a) {
+    typedef typename F::T T;
+    constexpr uint32_t EPB = 64 / F::BYTES;  // elements per 64-byte block
+    constexpr uint32_t WPE = F::BYTES / 4;   // words per element
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.n_rows) return;
+    const uint64_t total_elems = (uint64_t)a.n_traces * a.epr;
+    const uint64_t len = total_elems * F::BYTES;
+    uint32_t out[8];
+    if (a.n_traces == 1) {
+        const T *row = a.lde + j * a.row_width;
+        const uint32_t epr = a.epr;
+        auto load = [&](uint64_t bi, uint32_t(&m)[16]) {
+            const uint32_t e0 = (uint32_t)bi * EPB;
+#pragma unroll
+            for (uint32_t i = 0; i < EPB; i++) {
+                if (e0 + i < epr) {
+                    elem_words<F>(row[e0 + i], &m[i * WPE]);
+                } else {
+#pragma unroll
+                    for (uint32_t q = 0; q < WPE; q++) m[i * WPE + q] = 0;
+                }
+            }
+        };
+        b3::hash_stream(len, load, out);
+    } else {
+        auto load = [&](uint64_t bi, uint32_t(&m)[16]) {
+            const uint64_t e0 = bi * EPB;
+#pragma unroll
+            for (uint32_t i = 0; i < EPB; i++) {
+                const uint64_t e = e0 + i;
+                if (e < total_elems) {
+                    const uint64_t t = e / a.epr;
+                    const uint32_t col = (uint32_t)(e - t * a.epr);
+                    elem_words<F>(a.lde[t * a.trace_elems + j * a.row_width + col], &m[i * WPE]);
+                } else {
+#pragma unroll
+                    for (uint32_t q = 0; q < WPE; q++) m[i * WPE + q] = 0;
+                }
+            }
+        };
+        b3::hash_stream(len, load, out);
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(a.leaves + j * 8);
+    dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
+    dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Merkle levels (build_merkle_nodes, crypto/src/merkle/mod.rs:350-374): each work-group folds 2*blockDim children
+// through up to `levels` levels, keeping the intermediate digests in LDS and writing every level to `nodes`.
+// children: digests of the level below (n_children of them); the parents level has n_children/2 nodes stored at
+// nodes[n_children/2 .. n_children).
+__global__ void __launch_bounds__(256) k_merkle_subtree(const uint32_t *__restrict__ children,
+                                                        uint32_t *__restrict__ nodes, uint64_t n_children,
+                                                        uint32_t levels) {
+    __shared__ uint32_t sh[256 * 8];
+    const uint32_t tid = threadIdx.x;
+    uint64_t n_par = n_children >> 1;                        // nodes in the first produced level
+    uint64_t first = (uint64_t)blockIdx.x * blockDim.x;      // this group's slice of that level
+    uint32_t width = (uint32_t)min((uint64_t)blockDim.x, n_par - first);
+    uint32_t m[16], cv[8];
+    if (tid < width) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(children + (first + tid) * 16);
+        uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+        m[0] = q0.x; m[1] = q0.y; m[2] = q0.z; m[3] = q0.w;
+        m[4] = q1.x; m[5] = q1.y; m[6] = q1.z; m[7] = q1.w;
+        m[8] = q2.x; m[9] = q2.y; m[10] = q2.z; m[11] = q2.w;
+        m[12] = q3.x; m[13] = q3.y; m[14] = q3.z; m[15] = q3.w;
+        b3::merge(m, cv);
+        uint4 *dst = reinterpret_cast<uint4 *>(nodes + (n_par + first + tid) * 8);
+        dst[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+        dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) sh[tid * 8 + i] = cv[i];
+    }
+    for (uint32_t lv = 1; lv < levels; lv++) {
+        __syncthreads();
+        n_par >>= 1;
+        first >>= 1;
+        width >>= 1;
+        const bool act = tid < width;
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) m[i] = sh[tid * 16 + i];
+            b3::merge(m, cv);
+        }
+        __syncthreads();
+        if (act) {
+            uint4 *dst = reinterpret_cast<uint4 *>(nodes + (n_par + first + tid) * 8);
+            dst[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+            dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+#pragma unroll
+            for (int i = 0; i < 8; i++) sh[tid * 8 + i] = cv[i];
+        }
+    }
+}
+
+// Hash contiguous rows of `row_elems` elements (wf_hash_rows building block) is k_hash_rows with n_traces = 1.
+
+}  // namespace wf

@@ -1,0 +1,831 @@
+// libwf_lde.so -- host side of the C ABI declared in include/wf_lde.h: context, twiddle tables, pass planner and
+// kernel launches.  Replaces Prover::build_trace_commitment / build_constraint_commitment
+// (/root/reference/prover/src/lib.rs:615-715) and the math::fft / crypto building blocks they call.
+// There is deliberately no CPU fallback: every compute entry point needs a HIP device.
+#include "../../include/wf_lde.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace wf;
+
+// ------------------------------------------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return fail(WF_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------- context
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct TableSet {  // device-resident Pow2L tables
+    void *lo = nullptr, *hi = nullptr;
+    uint32_t s = 0, mask = 0;
+    uint64_t lo_stride = 0, hi_stride = 0;  // per-coset strides (elements)
+};
+
+struct wf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // key: (field, logN, kind, aux, offset lo, offset hi); kind 0 = forward root, 1 = inverse root,
+    // 2 = coset bases (aux = log blowup), 3 = output series for interpolate_with_offset
+    std::map<std::tuple<int, int, int, int, uint64_t, uint64_t>, TableSet> tables;
+    DevBuf scratch;   // evaluation intermediate [cosets][columns][R]
+    DevBuf io[5];     // staging for the host-buffer API: trace, polys, lde, leaves, nodes
+};
+
+static int ensure(DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return 0;
+    if (b.p) {
+        HIP_TRY(hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    HIP_TRY(hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------- tables (host)
+template <class F>
+static int upload_pow2l(wf_ctx *ctx, const std::vector<typename F::T> &bases, uint32_t logN, TableSet &ts) {
+    // for each base g: lo[e] = g^e (e < 2^s), hi[h] = g^(h * 2^s) (h < 2^(logN - s))
+    typedef typename F::T T;
+    const uint32_t s = (logN + 1) / 2;
+    const size_t nlo = (size_t)1 << s, nhi = (size_t)1 << (logN - s);
+    std::vector<T> lo(nlo * bases.size()), hi(nhi * bases.size());
+    for (size_t bi = 0; bi < bases.size(); bi++) {
+        T g = bases[bi], acc = F::one();
+        for (size_t e = 0; e < nlo; e++) {
+            lo[bi * nlo + e] = acc;
+            acc = F::mul(acc, g);
+        }
+        T gs = acc;  // g^(2^s)
+        acc = F::one();
+        for (size_t h = 0; h < nhi; h++) {
+            hi[bi * nhi + h] = acc;
+            acc = F::mul(acc, gs);
+        }
+    }
+    HIP_TRY(hipMalloc(&ts.lo, lo.size() * sizeof(T)));
+    HIP_TRY(hipMalloc(&ts.hi, hi.size() * sizeof(T)));
+    HIP_TRY(hipMemcpyAsync(ts.lo, lo.data(), lo.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ts.hi, hi.data(), hi.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // host vectors die at return
+    ts.s = s;
+    ts.mask = (uint32_t)(nlo - 1);
+    ts.lo_stride = nlo;
+    ts.hi_stride = nhi;
+    return 0;
+}
+
+template <class F>
+static Pow2L<F> as_pow2l(const TableSet &ts) {
+    Pow2L<F> p;
+    p.lo = (const typename F::T *)ts.lo;
+    p.hi = (const typename F::T *)ts.hi;
+    p.s = ts.s;
+    p.mask = ts.mask;
+    return p;
+}
+
+// powers of the 2^logN-th root of unity (or its inverse): get_twiddles / get_inv_twiddles of the reference
+// (math/src/fft/mod.rs:466-522) without the bit-reversal, in two-level form
+template <class F>
+static int root_tables(wf_ctx *ctx, uint32_t logN, bool inverse, TableSet **out) {
+    auto key = std::make_tuple((int)F::FIELD_ID, (int)logN, inverse ? 1 : 0, 0, (uint64_t)0, (uint64_t)0);
+    auto it = ctx->tables.find(key);
+    if (it == ctx->tables.end()) {
+        typename F::T w = f_root_of_unity<F>(logN);
+        if (inverse) w = f_inv<F>(w);
+        TableSet ts;
+        int rc = upload_pow2l<F>(ctx, {w}, logN, ts);
+        if (rc) return rc;
+        it = ctx->tables.emplace(key, ts).first;
+    }
+    *out = &it->second;
+    return 0;
+}
+
+// coset bases h_c = offset * g^c, c < blowup, g = root of unity of order R*blowup
+// (get_evaluation_offsets, prover/src/matrix/row_matrix.rs:248-287, with natural coset numbering)
+template <class F>
+static int coset_tables(wf_ctx *ctx, uint32_t logR, uint32_t logB, typename F::T offset, uint64_t off_lo,
+                        uint64_t off_hi, TableSet **out) {
+    auto key = std::make_tuple((int)F::FIELD_ID, (int)logR, 2, (int)logB, off_lo, off_hi);
+    auto it = ctx->tables.find(key);
+    if (it == ctx->tables.end()) {
+        typename F::T g = f_root_of_unity<F>(logR + logB);
+        std::vector<typename F::T> bases((size_t)1 << logB);
+        typename F::T h = offset;
+        for (size_t c = 0; c < bases.size(); c++) {
+            bases[c] = h;
+            h = F::mul(h, g);
+        }
+        TableSet ts;
+        int rc = upload_pow2l<F>(ctx, bases, logR, ts);
+        if (rc) return rc;
+        it = ctx->tables.emplace(key, ts).first;
+    }
+    *out = &it->second;
+    return 0;
+}
+
+// output series for interpolate_poly_with_offset: coefficient k is multiplied by (1/n) * offset^-k
+// (math/src/fft/serial.rs:78-93); 1/n is folded into the lo table
+template <class F>
+static int series_tables(wf_ctx *ctx, uint32_t logN, typename F::T offset, uint64_t off_lo, uint64_t off_hi,
+                         TableSet **out) {
+    auto key = std::make_tuple((int)F::FIELD_ID, (int)logN, 3, 0, off_lo, off_hi);
+    auto it = ctx->tables.find(key);
+    if (it == ctx->tables.end()) {
+        typedef typename F::T T;
+        T inv_off = f_inv<F>(offset);
+        T inv_n = f_inv<F>(F::from_u128_canonical((u128)1 << logN));
+        const uint32_t s = (logN + 1) / 2;
+        const size_t nlo = (size_t)1 << s, nhi = (size_t)1 << (logN - s);
+        std::vector<T> lo(nlo), hi(nhi);
+        T acc = F::one();
+        for (size_t e = 0; e < nlo; e++) {
+            lo[e] = F::mul(acc, inv_n);
+            acc = F::mul(acc, inv_off);
+        }
+        T gs = acc;
+        acc = F::one();
+        for (size_t h = 0; h < nhi; h++) {
+            hi[h] = acc;
+            acc = F::mul(acc, gs);
+        }
+        TableSet ts;
+        HIP_TRY(hipMalloc(&ts.lo, nlo * sizeof(T)));
+        HIP_TRY(hipMalloc(&ts.hi, nhi * sizeof(T)));
+        HIP_TRY(hipMemcpy(ts.lo, lo.data(), nlo * sizeof(T), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ts.hi, hi.data(), nhi * sizeof(T), hipMemcpyHostToDevice));
+        ts.s = s;
+        ts.mask = (uint32_t)(nlo - 1);
+        it = ctx->tables.emplace(key, ts).first;
+    }
+    *out = &it->second;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------- planner
+struct Plan {
+    int n_pass;
+    uint32_t dig[4];
+};
+
+static Plan make_plan(uint32_t L) {
+    Plan p;
+    p.n_pass = L <= 10 ? 1 : (L <= 22 ? 2 : (L <= 33 ? 3 : 4));
+    uint32_t base = L / p.n_pass, rem = L % p.n_pass;
+    for (int i = 0; i < p.n_pass; i++) p.dig[i] = base + (i < (int)rem ? 1 : 0);
+    return p;
+}
+
+template <class F>
+static uint32_t tile_target(uint32_t W) {  // adjacent elements so that a global chunk is ~64 bytes
+    uint32_t t = 64 / (W * F::BYTES);
+    return t < 1 ? 1 : t;
+}
+
+static uint32_t pow2_floor(uint32_t v) {
+    uint32_t r = 1;
+    while (r * 2 <= v) r *= 2;
+    return r;
+}
+
+template <class F>
+static int launch_dims(uint32_t logD, uint32_t V, uint32_t &threads, size_t &lds) {
+    const size_t vals = ((size_t)1 << logD) * V;
+    lds = (vals + ((size_t)1 << logD)) * sizeof(typename F::T);
+    if (lds > 160 * 1024) return fail(WF_ERR_ARG, "internal: pass needs %zu bytes of LDS", lds);
+    threads = vals >= 16384 ? 1024 : (vals >= 8192 ? 512 : 256);
+    if (lds > 64 * 1024) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k_ntt_strided<F>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_ntt_last<F>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024));
+    }
+    return 0;
+}
+
+// One transform of every column of a batch.
+//   inverse        : use the inverse root
+//   src            : [TC] columns (N elements of W coordinates)
+//   OUT_COLS       : dst = [TC] columns, natural order, scaled per scale_mode
+//   OUT_ROWS       : dst = [n_traces] row-major matrices; n_cosets = blowup, coset c of trace t, column col lands in
+//                    rows k*blowup + c; `pre` holds the coset bases
+template <class F>
+struct XformDesc {
+    typedef typename F::T T;
+    const T *src;
+    T *dst;
+    uint32_t logN, W, TC, n_cols, n_cosets, log_blowup;
+    bool inverse;
+    uint32_t out_mode, scale_mode;
+    T scale;
+    const TableSet *out_series;
+    const TableSet *pre;
+    uint64_t row_width, trace_lde_elems;
+};
+
+template <class F>
+static int run_transform(wf_ctx *ctx, hipStream_t st, const XformDesc<F> &d) {
+    typedef typename F::T T;
+    TableSet *tw;
+    int rc = root_tables<F>(ctx, d.logN, d.inverse, &tw);
+    if (rc) return rc;
+    const Plan plan = make_plan(d.logN);
+    const uint64_t N = (uint64_t)1 << d.logN;
+
+    NttArgs<F> a;
+    memset(&a, 0, sizeof(a));
+    a.logN = d.logN;
+    a.W = d.W;
+    a.TC = d.TC;
+    a.n_cosets = d.n_cosets;
+    a.col_elems = N;
+    a.tw = as_pow2l<F>(*tw);
+    a.n_cols = d.n_cols;
+    a.log_blowup = d.log_blowup;
+    a.row_width = d.row_width;
+    a.trace_lde_elems = d.trace_lde_elems;
+    a.out_mode = d.out_mode;
+    if (d.pre) {
+        a.pre = as_pow2l<F>(*d.pre);
+        a.pre_lo_stride = d.pre->lo_stride;
+        a.pre_hi_stride = d.pre->hi_stride;
+    }
+    const uint64_t batch = (uint64_t)d.TC * d.n_cosets;
+    // multi-pass transforms go  src -> scratch (first pass), scratch in place (middle), scratch -> dst (last pass):
+    // the last pass scatters to natural order and therefore cannot run in place
+    T *scratch = nullptr;
+    if (plan.n_pass > 1) {
+        rc = ensure(ctx->scratch, (size_t)batch * N * d.W * sizeof(T));
+        if (rc) return rc;
+        scratch = (T *)ctx->scratch.p;
+    }
+
+    // strided passes
+    uint32_t done_bits = 0;
+    for (int pi = 0; pi + 1 < plan.n_pass; pi++) {
+        a.logD = plan.dig[pi];
+        a.O = (uint64_t)1 << done_bits;
+        a.I = N >> (done_bits + a.logD);
+        a.Tl = (uint32_t)std::min<uint64_t>(tile_target<F>(d.W), a.I);
+        a.GC = 1;
+        a.V = a.Tl * d.W;
+        const bool first = pi == 0;
+        a.src = first ? d.src : scratch;
+        a.dst = scratch;
+        a.src_by_tc = (first && d.out_mode == OUT_ROWS) ? 1 : 0;
+        a.pre_on = (first && d.pre) ? 1 : 0;
+        uint32_t threads;
+        size_t lds;
+        rc = launch_dims<F>(a.logD, a.V, threads, lds);
+        if (rc) return rc;
+        const uint64_t grid = batch * a.O * (a.I / a.Tl);
+        if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
+        hipLaunchKernelGGL(k_ntt_strided<F>, dim3((uint32_t)grid), dim3(threads), lds, st, a);
+        HIP_TRY(hipGetLastError());
+        done_bits += a.logD;
+    }
+    // last pass
+    {
+        const int pi = plan.n_pass - 1;
+        a.logD = plan.dig[pi];
+        a.O = (uint64_t)1 << done_bits;
+        a.I = 1;
+        a.n_prev = plan.n_pass - 1;
+        for (int i = 0; i < pi; i++) a.prev_log[i] = plan.dig[i];
+        const bool single = plan.n_pass == 1;
+        a.scale_mode = d.scale_mode;
+        a.scale = d.scale;
+        if (d.out_series) a.out_pow = as_pow2l<F>(*d.out_series);
+        uint64_t groups_per_coset;
+        if (d.out_mode == OUT_COLS) {
+            a.GC = 1;
+            uint32_t t = single ? 1 : std::min<uint32_t>(tile_target<F>(d.W), 1u << plan.dig[0]);
+            a.Tl = t;
+            a.src = single ? d.src : scratch;
+            a.dst = d.dst;
+            a.src_by_tc = 0;
+            groups_per_coset = d.TC;
+        } else {
+            uint32_t gc = std::max<uint32_t>(1, (F::BYTES == 8 ? 8u : 4u) / d.W);
+            a.GC = std::min<uint32_t>(gc, d.n_cols);
+            a.Tl = 1;
+            a.src = single ? d.src : scratch;
+            a.dst = d.dst;
+            a.src_by_tc = single ? 1 : 0;
+            const uint32_t groups = (d.n_cols + a.GC - 1) / a.GC;
+            groups_per_coset = (uint64_t)(d.TC / d.n_cols) * groups;
+        }
+        a.pre_on = (single && d.pre) ? 1 : 0;
+        a.V = a.Tl * a.GC * d.W;
+        uint32_t threads;
+        size_t lds;
+        rc = launch_dims<F>(a.logD, a.V, threads, lds);
+        if (rc) return rc;
+        const uint64_t tiles = a.O / a.Tl;
+        const uint64_t grid = groups_per_coset * d.n_cosets * tiles;
+        if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
+        hipLaunchKernelGGL(k_ntt_last<F>, dim3((uint32_t)grid), dim3(threads), lds, st, a);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------- hashing + tree
+template <class F>
+static int run_hash_rows(hipStream_t st, const void *lde, uint64_t trace_elems, uint64_t n_rows, uint32_t row_width,
+                         uint32_t epr, uint32_t n_traces, void *leaves) {
+    HashArgs<F> h;
+    h.lde = (const typename F::T *)lde;
+    h.trace_elems = trace_elems;
+    h.n_rows = n_rows;
+    h.row_width = row_width;
+    h.epr = epr;
+    h.n_traces = n_traces;
+    h.leaves = (uint32_t *)leaves;
+    const uint32_t threads = 256;
+    const uint64_t grid = (n_rows + threads - 1) / threads;
+    hipLaunchKernelGGL(k_hash_rows<F>, dim3((uint32_t)grid), dim3(threads), 0, st, h);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int run_merkle(hipStream_t st, const void *leaves, uint64_t n_leaves, void *nodes) {
+    HIP_TRY(hipMemsetAsync(nodes, 0, 32, st));  // nodes[0] = Digest::default() (merkle/mod.rs:355)
+    const uint32_t *children = (const uint32_t *)leaves;
+    uint64_t n_children = n_leaves;
+    while (n_children > 1) {
+        uint32_t total_levels = 0;
+        for (uint64_t t = n_children; t > 1; t >>= 1) total_levels++;
+        const uint32_t levels = std::min<uint32_t>(9, total_levels);
+        const uint64_t n_par = n_children >> 1;
+        const uint32_t threads = 256;
+        const uint64_t grid = (n_par + threads - 1) / threads;
+        hipLaunchKernelGGL(k_merkle_subtree, dim3((uint32_t)grid), dim3(threads), 0, st, children,
+                           (uint32_t *)nodes, n_children, levels);
+        HIP_TRY(hipGetLastError());
+        n_children >>= levels;
+        children = (const uint32_t *)nodes + n_children * 8;  // that level lives at nodes[n .. 2n)
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------- validation
+static int check_params(const wf_params *p, bool constraint) {
+    if (!p) return fail(WF_ERR_ARG, "params is null");
+    if (p->field != WF_FIELD_F64 && p->field != WF_FIELD_F128) return fail(WF_ERR_FIELD, "unknown field id %u", p->field);
+    if (p->ext_degree < 1 || p->ext_degree > 3 || (p->field == WF_FIELD_F128 && p->ext_degree == 3))
+        return fail(WF_ERR_EXTENSION, "unsupported extension degree %u for field %u", p->ext_degree, p->field);
+    if (p->log2_trace_len < 3) return fail(WF_ERR_TRACE_LENGTH, "trace length must be at least 8");
+    if (p->log2_blowup < 1 || p->log2_blowup > 7) return fail(WF_ERR_BLOWUP, "blowup must be a power of two in [2,128]");
+    const uint32_t adicity = p->field == WF_FIELD_F64 ? F64::TWO_ADICITY : F128::TWO_ADICITY;
+    if (p->log2_trace_len + p->log2_blowup > adicity)
+        return fail(WF_ERR_DOMAIN, "no multiplicative subgroup of size 2^%u in this field", p->log2_trace_len + p->log2_blowup);
+    if (p->n_cols < 1 || p->n_cols > 255) return fail(WF_ERR_WIDTH, "number of columns must be in [1,255]");
+    if (p->n_traces < 1 || (constraint && p->n_traces != 1)) return fail(WF_ERR_TRACES, "invalid number of traces %u", p->n_traces);
+    if (p->digest_bytes != 32) return fail(WF_ERR_DIGEST, "only 32-byte digests (Blake3_256) are supported");
+    if (p->reserved != 0) return fail(WF_ERR_ARG, "reserved field must be zero");
+    u128 off;
+    memcpy(&off, p->domain_offset, 16);
+    const u128 mod = p->field == WF_FIELD_F64 ? (u128)F64::P : F128::P();
+    if (off == 0 || off >= mod) return fail(WF_ERR_OFFSET, "domain offset must be a non-zero field element");
+    return 0;
+}
+
+template <class F>
+static typename F::T offset_elem(const wf_params *p, uint64_t &lo, uint64_t &hi) {
+    u128 off;
+    memcpy(&off, p->domain_offset, 16);
+    lo = (uint64_t)off;
+    hi = (uint64_t)(off >> 64);
+    return F::from_u128_canonical(off);
+}
+
+// ------------------------------------------------------------------------------------------------- the path (device)
+template <class F>
+static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, const void *d_polys, void *d_lde,
+                               void *d_leaves, void *d_nodes) {
+    typedef typename F::T T;
+    const uint32_t W = p->ext_degree, logR = p->log2_trace_len, logB = p->log2_blowup;
+    const uint64_t R = (uint64_t)1 << logR, Nrows = R << logB;
+    const uint32_t TC = p->n_cols * p->n_traces;
+    const uint64_t row_width = wf_row_width(p);
+    const uint32_t base_cols = p->n_cols * W;
+
+    uint64_t olo, ohi;
+    T off = offset_elem<F>(p, olo, ohi);
+    TableSet *cos;
+    int rc = coset_tables<F>(ctx, logR, logB, off, olo, ohi, &cos);
+    if (rc) return rc;
+
+    if (make_plan(logR).n_pass > 1) {  // size the scratch once for the larger (evaluation) use
+        rc = ensure(ctx->scratch, (size_t)TC * (R << logB) * W * sizeof(T));
+        if (rc) return rc;
+    }
+    if (row_width != base_cols)  // zero the padding lanes (segments.rs:65-72)
+        HIP_TRY(hipMemsetAsync(d_lde, 0, (size_t)p->n_traces * Nrows * row_width * sizeof(T), st));
+
+    XformDesc<F> d;
+    memset(&d, 0, sizeof(d));
+    d.src = (const T *)d_polys;
+    d.dst = (T *)d_lde;
+    d.logN = logR;
+    d.W = W;
+    d.TC = TC;
+    d.n_cols = p->n_cols;
+    d.n_cosets = 1u << logB;
+    d.log_blowup = logB;
+    d.inverse = false;
+    d.out_mode = OUT_ROWS;
+    d.scale_mode = SCALE_NONE;
+    d.pre = cos;
+    d.row_width = row_width;
+    d.trace_lde_elems = Nrows * row_width;
+    rc = run_transform<F>(ctx, st, d);
+    if (rc) return rc;
+
+    if (d_leaves) {
+        rc = run_hash_rows<F>(st, d_lde, Nrows * row_width, Nrows, (uint32_t)row_width, base_cols, p->n_traces, d_leaves);
+        if (rc) return rc;
+        if (d_nodes) {
+            rc = run_merkle(st, d_leaves, Nrows, d_nodes);
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}
+
+template <class F>
+static int interpolate_columns(wf_ctx *ctx, hipStream_t st, const wf_params *p, const void *d_trace, void *d_polys) {
+    typedef typename F::T T;
+    XformDesc<F> d;
+    memset(&d, 0, sizeof(d));
+    d.src = (const T *)d_trace;
+    d.dst = (T *)d_polys;
+    d.logN = p->log2_trace_len;
+    d.W = p->ext_degree;
+    d.TC = p->n_cols * p->n_traces;
+    d.n_cols = p->n_cols;
+    d.n_cosets = 1;
+    d.inverse = true;
+    d.out_mode = OUT_COLS;
+    d.scale_mode = SCALE_CONST;
+    d.scale = f_inv<F>(F::from_u128_canonical((u128)1 << p->log2_trace_len));  // 1/n, fft/serial.rs:70
+    return run_transform<F>(ctx, st, d);
+}
+
+template <class F>
+static int trace_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_trace, void *d_polys, void *d_lde,
+                            void *d_leaves, void *d_nodes, hipStream_t st) {
+    int rc;
+    if (make_plan(p->log2_trace_len).n_pass > 1) {  // one allocation covers interpolation and evaluation
+        const size_t vals = ((size_t)p->n_cols * p->n_traces * p->ext_degree) << (p->log2_trace_len + p->log2_blowup);
+        if ((rc = ensure(ctx->scratch, vals * sizeof(typename F::T)))) return rc;
+    }
+    rc = interpolate_columns<F>(ctx, st, p, d_trace, d_polys);
+    if (rc) return rc;
+    return evaluate_and_commit<F>(ctx, st, p, d_polys, d_lde, d_leaves, d_nodes);
+}
+
+// ------------------------------------------------------------------------------------------------- C ABI
+extern "C" {
+
+const char *wf_last_error(void) { return g_err; }
+
+int wf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int wf_ctx_create(int device, wf_ctx **out) {
+    if (!out) return fail(WF_ERR_ARG, "out is null");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(WF_ERR_HIP, "HIP device %d not available (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    wf_ctx *c = new wf_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(WF_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return 0;
+}
+
+void wf_ctx_destroy(wf_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->tables) {
+        if (kv.second.lo) (void)hipFree(kv.second.lo);
+        if (kv.second.hi) (void)hipFree(kv.second.hi);
+    }
+    if (ctx->scratch.p) (void)hipFree(ctx->scratch.p);
+    for (auto &b : ctx->io)
+        if (b.p) (void)hipFree(b.p);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int wf_ctx_synchronize(wf_ctx *ctx) {
+    if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+void *wf_ctx_stream(wf_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int wf_params_check(const wf_params *p, int is_constraint) { return check_params(p, is_constraint != 0); }
+
+size_t wf_elem_bytes(uint32_t field) { return field == WF_FIELD_F64 ? 8 : (field == WF_FIELD_F128 ? 16 : 0); }
+size_t wf_row_width(const wf_params *p) { return 8 * (((size_t)p->n_cols * p->ext_degree + 7) / 8); }
+size_t wf_column_bytes(const wf_params *p) {
+    return ((size_t)1 << p->log2_trace_len) * p->ext_degree * wf_elem_bytes(p->field);
+}
+size_t wf_lde_bytes(const wf_params *p) {
+    return ((size_t)1 << (p->log2_trace_len + p->log2_blowup)) * wf_row_width(p) * wf_elem_bytes(p->field);
+}
+size_t wf_digests_bytes(const wf_params *p) { return ((size_t)1 << (p->log2_trace_len + p->log2_blowup)) * 32; }
+
+int wf_trace_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_trace, void *d_polys, void *d_lde,
+                        void *d_leaves, void *d_nodes, void *stream) {
+    if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
+    int rc = check_params(p, false);
+    if (rc) return rc;
+    if (!d_trace || !d_polys || !d_lde) return fail(WF_ERR_ARG, "null device buffer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (p->field == WF_FIELD_F64) return trace_commit_dev<F64>(ctx, p, d_trace, d_polys, d_lde, d_leaves, d_nodes, st);
+    return trace_commit_dev<F128>(ctx, p, d_trace, d_polys, d_lde, d_leaves, d_nodes, st);
+}
+
+int wf_constraint_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_polys, void *d_lde, void *d_leaves,
+                             void *d_nodes, void *stream) {
+    if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
+    int rc = check_params(p, true);
+    if (rc) return rc;
+    if (!d_polys || !d_lde) return fail(WF_ERR_ARG, "null device buffer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (p->field == WF_FIELD_F64) return evaluate_and_commit<F64>(ctx, st, p, d_polys, d_lde, d_leaves, d_nodes);
+    return evaluate_and_commit<F128>(ctx, st, p, d_polys, d_lde, d_leaves, d_nodes);
+}
+
+// host-buffer form -------------------------------------------------------------------------------------------------
+static int commit_host(wf_ctx *ctx, const wf_params *p, bool constraint, const void *const *cols_in,
+                       void *const *polys_out, void *const *lde_out, uint8_t *leaves_out, uint8_t *nodes_out,
+                       uint8_t *root_out) {
+    if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
+    int rc = check_params(p, constraint);
+    if (rc) return rc;
+    if (!cols_in) return fail(WF_ERR_ARG, "column pointer array is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t colb = wf_column_bytes(p), ldeb = wf_lde_bytes(p), digb = wf_digests_bytes(p);
+    const size_t TC = (size_t)p->n_cols * p->n_traces;
+    for (size_t i = 0; i < TC; i++)
+        if (!cols_in[i]) return fail(WF_ERR_ARG, "column %zu is null", i);
+    if ((rc = ensure(ctx->io[0], TC * colb))) return rc;
+    if (!constraint && (rc = ensure(ctx->io[1], TC * colb))) return rc;
+    if ((rc = ensure(ctx->io[2], ldeb * p->n_traces))) return rc;
+    if ((rc = ensure(ctx->io[3], digb))) return rc;
+    if ((rc = ensure(ctx->io[4], digb))) return rc;
+    hipStream_t st = ctx->stream;
+    for (size_t i = 0; i < TC; i++)
+        HIP_TRY(hipMemcpyAsync((char *)ctx->io[0].p + i * colb, cols_in[i], colb, hipMemcpyHostToDevice, st));
+    void *d_polys = constraint ? ctx->io[0].p : ctx->io[1].p;
+    if (constraint)
+        rc = wf_constraint_commit_dev(ctx, p, ctx->io[0].p, ctx->io[2].p, ctx->io[3].p, ctx->io[4].p, st);
+    else
+        rc = wf_trace_commit_dev(ctx, p, ctx->io[0].p, ctx->io[1].p, ctx->io[2].p, ctx->io[3].p, ctx->io[4].p, st);
+    if (rc) return rc;
+    if (polys_out)
+        for (size_t i = 0; i < TC; i++)
+            if (polys_out[i])
+                HIP_TRY(hipMemcpyAsync(polys_out[i], (char *)d_polys + i * colb, colb, hipMemcpyDeviceToHost, st));
+    if (lde_out)
+        for (size_t t = 0; t < p->n_traces; t++)
+            if (lde_out[t])
+                HIP_TRY(hipMemcpyAsync(lde_out[t], (char *)ctx->io[2].p + t * ldeb, ldeb, hipMemcpyDeviceToHost, st));
+    if (leaves_out) HIP_TRY(hipMemcpyAsync(leaves_out, ctx->io[3].p, digb, hipMemcpyDeviceToHost, st));
+    if (nodes_out) HIP_TRY(hipMemcpyAsync(nodes_out, ctx->io[4].p, digb, hipMemcpyDeviceToHost, st));
+    if (root_out) HIP_TRY(hipMemcpyAsync(root_out, (char *)ctx->io[4].p + 32, 32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int wf_trace_commit(wf_ctx *ctx, const wf_params *p, const void *const *trace_cols, void *const *polys_out,
+                    void *const *lde_out, uint8_t *leaves_out, uint8_t *nodes_out, uint8_t *root_out) {
+    return commit_host(ctx, p, false, trace_cols, polys_out, lde_out, leaves_out, nodes_out, root_out);
+}
+
+int wf_constraint_commit(wf_ctx *ctx, const wf_params *p, const void *const *poly_cols, void *lde_out,
+                         uint8_t *leaves_out, uint8_t *nodes_out, uint8_t *root_out) {
+    void *lde_arr[1] = {lde_out};
+    return commit_host(ctx, p, true, poly_cols, nullptr, lde_out ? lde_arr : nullptr, leaves_out, nodes_out, root_out);
+}
+
+int wf_evaluate_polys_over(wf_ctx *ctx, const wf_params *p, const void *const *poly_cols, void *lde_out) {
+    return wf_constraint_commit(ctx, p, poly_cols, lde_out, nullptr, nullptr, nullptr);
+}
+
+// math::fft building blocks -------------------------------------------------------------------------------------------
+static int check_fft_args(wf_ctx *ctx, uint32_t field, uint32_t ext, const void *buf, size_t n, uint32_t *logn) {
+    if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
+    if (field != WF_FIELD_F64 && field != WF_FIELD_F128) return fail(WF_ERR_FIELD, "unknown field id %u", field);
+    if (ext < 1 || ext > 3 || (field == WF_FIELD_F128 && ext == 3)) return fail(WF_ERR_EXTENSION, "unsupported extension degree %u", ext);
+    if (!buf) return fail(WF_ERR_ARG, "buffer is null");
+    if (n < 2 || (n & (n - 1))) return fail(WF_ERR_TRACE_LENGTH, "size must be a power of two >= 2");  // fft/mod.rs:89-93
+    uint32_t l = 0;
+    while (((size_t)1 << l) < n) l++;
+    const uint32_t adicity = field == WF_FIELD_F64 ? F64::TWO_ADICITY : F128::TWO_ADICITY;
+    if (l > adicity) return fail(WF_ERR_DOMAIN, "no multiplicative subgroup of size 2^%u in this field", l);
+    *logn = l;
+    return 0;
+}
+
+}  // extern "C"
+
+template <class F>
+static int fft_host(wf_ctx *ctx, uint32_t ext, void *buf, uint32_t logn, bool inverse, const uint8_t *offset16) {
+    typedef typename F::T T;
+    const size_t bytes = ((size_t)1 << logn) * ext * sizeof(T);
+    int rc;
+    if ((rc = ensure(ctx->io[0], bytes))) return rc;
+    if ((rc = ensure(ctx->io[1], bytes))) return rc;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->io[0].p, buf, bytes, hipMemcpyHostToDevice, st));
+    XformDesc<F> d;
+    memset(&d, 0, sizeof(d));
+    d.src = (const T *)ctx->io[0].p;
+    d.dst = (T *)ctx->io[1].p;
+    d.logN = logn;
+    d.W = ext;
+    d.TC = 1;
+    d.n_cols = 1;
+    d.n_cosets = 1;
+    d.inverse = inverse;
+    d.out_mode = OUT_COLS;
+    if (inverse) {
+        if (offset16) {
+            u128 off;
+            memcpy(&off, offset16, 16);
+            if (off == 0 || off >= FieldInfo<F>::modulus()) return fail(WF_ERR_OFFSET, "domain offset must be a non-zero field element");
+            TableSet *ser;
+            rc = series_tables<F>(ctx, logn, F::from_u128_canonical(off), (uint64_t)off, (uint64_t)(off >> 64), &ser);
+            if (rc) return rc;
+            d.scale_mode = SCALE_SERIES;
+            d.out_series = ser;
+        } else {
+            d.scale_mode = SCALE_CONST;
+            d.scale = f_inv<F>(F::from_u128_canonical((u128)1 << logn));
+        }
+    }
+    rc = run_transform<F>(ctx, st, d);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(buf, ctx->io[1].p, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" {
+
+int wf_fft_evaluate_poly(wf_ctx *ctx, uint32_t field, uint32_t ext, void *poly, size_t n) {
+    uint32_t l;
+    int rc = check_fft_args(ctx, field, ext, poly, n, &l);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return field == WF_FIELD_F64 ? fft_host<F64>(ctx, ext, poly, l, false, nullptr) : fft_host<F128>(ctx, ext, poly, l, false, nullptr);
+}
+
+int wf_fft_interpolate_poly(wf_ctx *ctx, uint32_t field, uint32_t ext, void *evals, size_t n) {
+    uint32_t l;
+    int rc = check_fft_args(ctx, field, ext, evals, n, &l);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return field == WF_FIELD_F64 ? fft_host<F64>(ctx, ext, evals, l, true, nullptr) : fft_host<F128>(ctx, ext, evals, l, true, nullptr);
+}
+
+int wf_fft_interpolate_poly_with_offset(wf_ctx *ctx, uint32_t field, uint32_t ext, void *evals, size_t n,
+                                        const uint8_t domain_offset[16]) {
+    uint32_t l;
+    int rc = check_fft_args(ctx, field, ext, evals, n, &l);
+    if (rc) return rc;
+    if (!domain_offset) return fail(WF_ERR_ARG, "domain offset is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return field == WF_FIELD_F64 ? fft_host<F64>(ctx, ext, evals, l, true, domain_offset)
+                                 : fft_host<F128>(ctx, ext, evals, l, true, domain_offset);
+}
+
+// evaluate_poly_with_offset: one column of E evaluated over the coset LDE domain -> natural-order vector.
+// Implemented as the row-major evaluation with a single column (row_width 8) followed by a strided copy-out.
+int wf_fft_evaluate_poly_with_offset(wf_ctx *ctx, uint32_t field, uint32_t ext, const void *poly, size_t n,
+                                     const uint8_t domain_offset[16], size_t blowup, void *result) {
+    uint32_t l;
+    int rc = check_fft_args(ctx, field, ext, poly, n, &l);
+    if (rc) return rc;
+    if (!result || !domain_offset) return fail(WF_ERR_ARG, "null argument");
+    if (blowup < 2 || (blowup & (blowup - 1))) return fail(WF_ERR_BLOWUP, "blowup must be a power of two >= 2");
+    uint32_t lb = 0;
+    while (((size_t)1 << lb) < blowup) lb++;
+    if (l < 3) return fail(WF_ERR_TRACE_LENGTH, "polynomial size must be at least 8");
+    wf_params p;
+    memset(&p, 0, sizeof(p));
+    p.field = field;
+    p.ext_degree = ext;
+    p.log2_trace_len = l;
+    p.log2_blowup = lb;
+    p.n_cols = 1;
+    p.n_traces = 1;
+    p.digest_bytes = 32;
+    memcpy(p.domain_offset, domain_offset, 16);
+    if (lb > 7) return fail(WF_ERR_BLOWUP, "blowup must be at most 128");
+    rc = check_params(&p, true);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t eb = wf_elem_bytes(field), ldeb = wf_lde_bytes(&p), colb = wf_column_bytes(&p);
+    if ((rc = ensure(ctx->io[0], colb))) return rc;
+    if ((rc = ensure(ctx->io[2], ldeb))) return rc;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->io[0].p, poly, colb, hipMemcpyHostToDevice, st));
+    rc = wf_constraint_commit_dev(ctx, &p, ctx->io[0].p, ctx->io[2].p, nullptr, nullptr, st);
+    if (rc) return rc;
+    const size_t rows = n * blowup, rw = wf_row_width(&p);
+    HIP_TRY(hipMemcpy2DAsync(result, ext * eb, ctx->io[2].p, rw * eb, ext * eb, rows, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int wf_hash_rows(wf_ctx *ctx, uint32_t field, const void *rows, size_t n_rows, size_t row_elems, uint8_t *digests_out) {
+    if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
+    if (field != WF_FIELD_F64 && field != WF_FIELD_F128) return fail(WF_ERR_FIELD, "unknown field id %u", field);
+    if (!digests_out || (!rows && n_rows * row_elems)) return fail(WF_ERR_ARG, "null argument");
+    if (n_rows == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t bytes = n_rows * row_elems * wf_elem_bytes(field);
+    int rc;
+    if ((rc = ensure(ctx->io[2], bytes ? bytes : 16))) return rc;
+    if ((rc = ensure(ctx->io[3], n_rows * 32))) return rc;
+    hipStream_t st = ctx->stream;
+    if (bytes) HIP_TRY(hipMemcpyAsync(ctx->io[2].p, rows, bytes, hipMemcpyHostToDevice, st));
+    if (field == WF_FIELD_F64)
+        rc = run_hash_rows<F64>(st, ctx->io[2].p, 0, n_rows, (uint32_t)row_elems, (uint32_t)row_elems, 1, ctx->io[3].p);
+    else
+        rc = run_hash_rows<F128>(st, ctx->io[2].p, 0, n_rows, (uint32_t)row_elems, (uint32_t)row_elems, 1, ctx->io[3].p);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(digests_out, ctx->io[3].p, n_rows * 32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int wf_merkle_build(wf_ctx *ctx, const uint8_t *leaves, size_t n_leaves, uint8_t *nodes_out) {
+    if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
+    if (!leaves || !nodes_out) return fail(WF_ERR_ARG, "null argument");
+    if (n_leaves < 2) return fail(WF_ERR_LEAVES, "a tree must have at least 2 leaves");           // merkle/mod.rs:118-120
+    if (n_leaves & (n_leaves - 1)) return fail(WF_ERR_LEAVES, "number of leaves must be a power of two");  // :121-123
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx->io[3], n_leaves * 32))) return rc;
+    if ((rc = ensure(ctx->io[4], n_leaves * 32))) return rc;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->io[3].p, leaves, n_leaves * 32, hipMemcpyHostToDevice, st));
+    rc = run_merkle(st, ctx->io[3].p, n_leaves, ctx->io[4].p);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(nodes_out, ctx->io[4].p, n_leaves * 32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+}  // extern "C"
