@@ -81,6 +81,14 @@ int wf_ctx_synchronize(wf_ctx *ctx);
 /* The context's hipStream_t (as void*), for callers that interleave their own work. */
 void *wf_ctx_stream(wf_ctx *ctx);
 
+/* Per-launch timing of the *_commit_dev calls: with profiling enabled an event is recorded on the call's stream in
+ * front of every kernel launch and at the end of the call; events accumulate over calls.  wf_ctx_profile_read waits
+ * for the last recorded event, returns the number of (name, milliseconds) pairs written (at most max_entries) and
+ * clears the log; names are static strings such as "evaluate.strided_pass" ("between_calls" = gap to the next
+ * call).  Used by bench.py for the roofline figures; off by default. */
+int wf_ctx_profile_enable(wf_ctx *ctx, int on);
+int wf_ctx_profile_read(wf_ctx *ctx, int max_entries, const char **names, float *ms);
+
 /* Validates a parameter block without touching the device (is_constraint != 0: n_traces must be 1).
  * The preconditions are the reference's assert!s: SURVEY.md §8b "Error convention". */
 int wf_params_check(const wf_params *p, int is_constraint);

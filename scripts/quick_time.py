@@ -23,7 +23,11 @@ def main():
     lde = torch.empty(N * rw, dtype=torch.int64, device="cuda")
     leaves = torch.empty(N * 32, dtype=torch.uint8, device="cuda")
     nodes = torch.empty(N * 32, dtype=torch.uint8, device="cuda")
-    st = torch.cuda.current_stream().cuda_stream
+    ts = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(ts)
+    st = ts.cuda_stream
+    assert st != 0
     for it in range(3):
         ctx.trace_commit_dev(p, trace.data_ptr(), polys.data_ptr(), lde.data_ptr(), leaves.data_ptr(), nodes.data_ptr(), st)
     torch.cuda.synchronize()

@@ -18,7 +18,7 @@ ELEM_WORDS = {F64: 1, F128: 2}
 
 SYMBOLS = [
     "wf_ctx_create", "wf_ctx_destroy", "wf_last_error", "wf_device_count", "wf_ctx_synchronize", "wf_ctx_stream",
-    "wf_params_check", "wf_elem_bytes", "wf_row_width", "wf_column_bytes", "wf_lde_bytes", "wf_digests_bytes",
+    "wf_ctx_profile_enable", "wf_ctx_profile_read", "wf_params_check", "wf_elem_bytes", "wf_row_width", "wf_column_bytes", "wf_lde_bytes", "wf_digests_bytes",
     "wf_trace_commit", "wf_constraint_commit", "wf_trace_commit_dev", "wf_constraint_commit_dev",
     "wf_fft_evaluate_poly", "wf_fft_evaluate_poly_with_offset", "wf_fft_interpolate_poly",
     "wf_fft_interpolate_poly_with_offset", "wf_evaluate_polys_over", "wf_hash_rows", "wf_merkle_build",
@@ -67,6 +67,8 @@ def load():
         L.wf_ctx_synchronize.argtypes = [vp]
         L.wf_ctx_stream.argtypes = [vp]
         L.wf_ctx_stream.restype = vp
+        L.wf_ctx_profile_enable.argtypes = [vp, i32]
+        L.wf_ctx_profile_read.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]
         L.wf_params_check.argtypes = [PP, i32]
         L.wf_elem_bytes.argtypes = [u32]
         L.wf_elem_bytes.restype = sz
@@ -130,6 +132,19 @@ class Context:
 
     def synchronize(self):
         _check(load().wf_ctx_synchronize(self._h))
+
+    def profile_enable(self, on: bool = True):
+        _check(load().wf_ctx_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        """[(launch name, milliseconds)] of the *_commit_dev calls since the last read (waits for them)."""
+        cap = 16384
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        n = load().wf_ctx_profile_read(self._h, cap, names, ms)
+        if n < 0:
+            _check(n)
+        return [(names[i].decode(), float(ms[i])) for i in range(n)]
 
     @property
     def stream(self) -> int:

@@ -34,6 +34,9 @@ struct Pow2L {
 
 enum : uint32_t { SCALE_NONE = 0, SCALE_CONST = 1, SCALE_SERIES = 2 };
 enum : uint32_t { OUT_COLS = 0, OUT_ROWS = 1 };
+// kernel flavour (also keeps the two uses apart in profiler output): interpolation of columns (inverse transform,
+// column-major natural-order output) or evaluation over the cosets of the LDE domain (row-major output)
+enum : int { K_INTERP = 0, K_EVAL = 1 };
 
 template <class F>
 struct NttArgs {
@@ -95,10 +98,11 @@ __device__ __forceinline__ void lds_ntt(typename F::T *x, const typename F::T *t
     const bool vpow2 = (V & (V - 1)) == 0;
     const uint32_t vshift = 31 - __builtin_clz(V);
     uint32_t cur = logD;
+    __syncthreads();  // x and twd were just written by other lanes
     T w4 = F::one();
     if (logD >= 2) w4 = twd[D >> 2];
     while (cur > 0) {
-        __syncthreads();
+        if (cur != logD) __syncthreads();
         if (cur >= 2) {
             const uint32_t mlog = cur - 2, m = 1u << mlog;
             const uint32_t nwork = (D >> 2) * V;
@@ -162,7 +166,7 @@ __device__ __forceinline__ void build_digit_twiddles(typename F::T *twd, const P
 // ---------------------------------------------------------------------------------------------------------------
 // Strided pass: view [O][D][I] of every column (I contiguous), transform the D axis for a tile of Tl inner positions.
 // grid.x = batch * O * (I / Tl)
-template <class F>
+template <class F, int KIND>
 __global__ void __launch_bounds__(1024) k_ntt_strided(NttArgs<F> a) {
     typedef typename F::T T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -185,7 +189,8 @@ __global__ void __launch_bounds__(1024) k_ntt_strided(NttArgs<F> a) {
     build_digit_twiddles<F>(twd, a.tw, a.logN, a.logD);
 
     Pow2L<F> pre = a.pre;
-    if (a.pre_on) {
+    const bool pre_on = KIND == K_EVAL && a.pre_on;
+    if (pre_on) {
         pre.lo += (uint64_t)c * a.pre_lo_stride;
         pre.hi += (uint64_t)c * a.pre_hi_stride;
     }
@@ -194,7 +199,7 @@ __global__ void __launch_bounds__(1024) k_ntt_strided(NttArgs<F> a) {
         const uint32_t d = wk / V, v = wk - d * V;
         const uint64_t g = ((o * D + d) * a.I + i0) * a.W + v;
         T val = src[g];
-        if (a.pre_on) {
+        if (pre_on) {
             const uint64_t n = (uint64_t)d * a.I + i0 + v / a.W;  // coefficient index (O == 1 on this pass)
             val = F::mul(val, pre.get(n));
         }
@@ -218,7 +223,7 @@ __global__ void __launch_bounds__(1024) k_ntt_strided(NttArgs<F> a) {
 // Last pass: view [O][D] (D contiguous).  OUT_COLS: one column, Tl adjacent k1 rows -> natural-order column.
 // OUT_ROWS: GC columns of one coset, one row tile -> row-major LDE matrix rows k*blowup + c.
 // grid.x = batch * (O / Tl)   with batch = n_cosets * (TC or traces*groups)
-template <class F>
+template <class F, int KIND>
 __global__ void __launch_bounds__(1024) k_ntt_last(NttArgs<F> a) {
     typedef typename F::T T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -256,7 +261,7 @@ __global__ void __launch_bounds__(1024) k_ntt_last(NttArgs<F> a) {
     // batch decode
     uint32_t c, col0, trace = 0, ncol_here;
     const T *src_base;
-    if (a.out_mode == OUT_ROWS) {
+    if (KIND == K_EVAL) {
         const uint32_t groups = (a.n_cols + a.GC - 1) / a.GC;
         const uint32_t n_traces = a.TC / a.n_cols;
         const uint32_t g = (uint32_t)(b % groups);
@@ -277,7 +282,8 @@ __global__ void __launch_bounds__(1024) k_ntt_last(NttArgs<F> a) {
 
     build_digit_twiddles<F>(twd, a.tw, a.logN, a.logD);
     Pow2L<F> pre = a.pre;
-    if (a.pre_on) {
+    const bool pre_on = KIND == K_EVAL && a.pre_on;
+    if (pre_on) {
         pre.lo += (uint64_t)c * a.pre_lo_stride;
         pre.hi += (uint64_t)c * a.pre_hi_stride;
     }
@@ -298,13 +304,13 @@ __global__ void __launch_bounds__(1024) k_ntt_last(NttArgs<F> a) {
         if (cg < ncol_here) {
             const uint64_t o_t = ((k1_0 + t_in) * O_lo) + o_rest;
             val = src_base[((uint64_t)cg * a.col_elems + o_t * D) * W + g];
-            if (a.pre_on) val = F::mul(val, pre.get(d));  // single-pass evaluation: coefficient index = d
+            if (pre_on) val = F::mul(val, pre.get(d));  // single-pass evaluation: coefficient index = d
         }
         x[d * V + line * W + w] = val;
     }
     lds_ntt<F>(x, twd, a.logD, V);
 
-    if (a.out_mode == OUT_COLS) {
+    if (KIND == K_INTERP) {
         T *dst = a.dst + b * a.col_elems * W;
         for (uint32_t wk = threadIdx.x; wk < total; wk += blockDim.x) {
             const uint32_t pos = wk / V, v = wk - pos * V;

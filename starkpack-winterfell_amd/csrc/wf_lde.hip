@@ -54,9 +54,27 @@ struct wf_ctx {
     // key: (field, logN, kind, aux, offset lo, offset hi); kind 0 = forward root, 1 = inverse root,
     // 2 = coset bases (aux = log blowup), 3 = output series for interpolate_with_offset
     std::map<std::tuple<int, int, int, int, uint64_t, uint64_t>, TableSet> tables;
+    // optional per-launch timing (wf_ctx_profile_*): an event is recorded in front of every kernel launch
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;
+    std::vector<const char *> prof_name;
+    size_t prof_n = 0;
     DevBuf scratch;   // evaluation intermediate [cosets][columns][R]
     DevBuf io[5];     // staging for the host-buffer API: trace, polys, lde, leaves, nodes
 };
+
+static void prof_mark(wf_ctx *ctx, hipStream_t st, const char *name) {
+    if (!ctx->prof_on) return;
+    if (ctx->prof_n == ctx->prof_ev.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        ctx->prof_ev.push_back(e);
+        ctx->prof_name.push_back(name);
+    }
+    ctx->prof_name[ctx->prof_n] = name;
+    (void)hipEventRecord(ctx->prof_ev[ctx->prof_n], st);
+    ctx->prof_n++;
+}
 
 static int ensure(DevBuf &b, size_t bytes) {
     if (bytes <= b.cap) return 0;
@@ -219,16 +237,16 @@ static uint32_t pow2_floor(uint32_t v) {
     return r;
 }
 
-template <class F>
+template <class F, int KIND>
 static int launch_dims(uint32_t logD, uint32_t V, uint32_t &threads, size_t &lds) {
     const size_t vals = ((size_t)1 << logD) * V;
     lds = (vals + ((size_t)1 << logD)) * sizeof(typename F::T);
     if (lds > 160 * 1024) return fail(WF_ERR_ARG, "internal: pass needs %zu bytes of LDS", lds);
     threads = vals >= 16384 ? 1024 : (vals >= 8192 ? 512 : 256);
     if (lds > 64 * 1024) {
-        HIP_TRY(hipFuncSetAttribute((const void *)k_ntt_strided<F>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_ntt_last<F>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        HIP_TRY(hipFuncSetAttribute((const void *)k_ntt_strided<F, KIND>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_ntt_last<F, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
     }
     return 0;
@@ -254,7 +272,7 @@ struct XformDesc {
     uint64_t row_width, trace_lde_elems;
 };
 
-template <class F>
+template <class F, int KIND>
 static int run_transform(wf_ctx *ctx, hipStream_t st, const XformDesc<F> &d) {
     typedef typename F::T T;
     TableSet *tw;
@@ -307,11 +325,12 @@ static int run_transform(wf_ctx *ctx, hipStream_t st, const XformDesc<F> &d) {
         a.pre_on = (first && d.pre) ? 1 : 0;
         uint32_t threads;
         size_t lds;
-        rc = launch_dims<F>(a.logD, a.V, threads, lds);
+        rc = launch_dims<F, KIND>(a.logD, a.V, threads, lds);
         if (rc) return rc;
         const uint64_t grid = batch * a.O * (a.I / a.Tl);
         if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
-        hipLaunchKernelGGL(k_ntt_strided<F>, dim3((uint32_t)grid), dim3(threads), lds, st, a);
+        prof_mark(ctx, st, KIND == K_EVAL ? "evaluate.strided_pass" : "interpolate.strided_pass");
+        hipLaunchKernelGGL((k_ntt_strided<F, KIND>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
         HIP_TRY(hipGetLastError());
         done_bits += a.logD;
     }
@@ -350,12 +369,13 @@ static int run_transform(wf_ctx *ctx, hipStream_t st, const XformDesc<F> &d) {
         a.V = a.Tl * a.GC * d.W;
         uint32_t threads;
         size_t lds;
-        rc = launch_dims<F>(a.logD, a.V, threads, lds);
+        rc = launch_dims<F, KIND>(a.logD, a.V, threads, lds);
         if (rc) return rc;
         const uint64_t tiles = a.O / a.Tl;
         const uint64_t grid = groups_per_coset * d.n_cosets * tiles;
         if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
-        hipLaunchKernelGGL(k_ntt_last<F>, dim3((uint32_t)grid), dim3(threads), lds, st, a);
+        prof_mark(ctx, st, KIND == K_EVAL ? "evaluate.last_pass" : "interpolate.last_pass");
+        hipLaunchKernelGGL((k_ntt_last<F, KIND>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
         HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -471,17 +491,20 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
     d.pre = cos;
     d.row_width = row_width;
     d.trace_lde_elems = Nrows * row_width;
-    rc = run_transform<F>(ctx, st, d);
+    rc = run_transform<F, K_EVAL>(ctx, st, d);
     if (rc) return rc;
 
     if (d_leaves) {
+        prof_mark(ctx, st, "hash_rows");
         rc = run_hash_rows<F>(st, d_lde, Nrows * row_width, Nrows, (uint32_t)row_width, base_cols, p->n_traces, d_leaves);
         if (rc) return rc;
         if (d_nodes) {
+            prof_mark(ctx, st, "merkle");
             rc = run_merkle(st, d_leaves, Nrows, d_nodes);
             if (rc) return rc;
         }
     }
+    prof_mark(ctx, st, "between_calls");
     return 0;
 }
 
@@ -501,7 +524,7 @@ static int interpolate_columns(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
     d.out_mode = OUT_COLS;
     d.scale_mode = SCALE_CONST;
     d.scale = f_inv<F>(F::from_u128_canonical((u128)1 << p->log2_trace_len));  // 1/n, fft/serial.rs:70
-    return run_transform<F>(ctx, st, d);
+    return run_transform<F, K_INTERP>(ctx, st, d);
 }
 
 template <class F>
@@ -556,6 +579,7 @@ void wf_ctx_destroy(wf_ctx *ctx) {
     if (ctx->scratch.p) (void)hipFree(ctx->scratch.p);
     for (auto &b : ctx->io)
         if (b.p) (void)hipFree(b.p);
+    for (auto e : ctx->prof_ev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -567,6 +591,26 @@ int wf_ctx_synchronize(wf_ctx *ctx) {
 }
 
 void *wf_ctx_stream(wf_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int wf_ctx_profile_enable(wf_ctx *ctx, int on) {
+    if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
+    ctx->prof_on = on != 0;
+    ctx->prof_n = 0;
+    return 0;
+}
+
+int wf_ctx_profile_read(wf_ctx *ctx, int max_entries, const char **names, float *ms) {
+    if (!ctx || !names || !ms) return fail(WF_ERR_ARG, "null argument");
+    if (ctx->prof_n < 2) return 0;
+    HIP_TRY(hipEventSynchronize(ctx->prof_ev[ctx->prof_n - 1]));
+    int n = 0;
+    for (size_t i = 0; i + 1 < ctx->prof_n && n < max_entries; i++, n++) {
+        names[n] = ctx->prof_name[i];
+        HIP_TRY(hipEventElapsedTime(&ms[n], ctx->prof_ev[i], ctx->prof_ev[i + 1]));
+    }
+    ctx->prof_n = 0;
+    return n;
+}
 
 int wf_params_check(const wf_params *p, int is_constraint) { return check_params(p, is_constraint != 0); }
 
@@ -713,7 +757,7 @@ static int fft_host(wf_ctx *ctx, uint32_t ext, void *buf, uint32_t logn, bool in
             d.scale = f_inv<F>(F::from_u128_canonical((u128)1 << logn));
         }
     }
-    rc = run_transform<F>(ctx, st, d);
+    rc = run_transform<F, K_INTERP>(ctx, st, d);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(buf, ctx->io[1].p, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

@@ -1,0 +1,34 @@
+"""Multi-GPU layout of the path: independent proofs, one commitment per GPU, roots assembled by ONE all-gather.
+
+The reference has no distributed code ("Distributed communication backend: none").  BASELINE.json
+configs[3] shards independent 2^20-row proofs one per GPU and assembles their Merkle roots with a single
+all-gather (RCCL over xGMI; `gloo` in the CPU tests).  There is no data-path collective: a commitment never
+needs another rank's rows.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def proofs_of_rank(n_proofs: int, rank: int, world: int):
+    """Contiguous block partition of proof ids over ranks (first ranks take the remainder)."""
+    base, rem = divmod(n_proofs, world)
+    lo = rank * base + min(rank, rem)
+    return list(range(lo, lo + base + (1 if rank < rem else 0)))
+
+
+def seed_of_proof(base_seed: int, proof_id: int) -> int:
+    """Synthetic-input seed of one proof (seeds offset by proof / rank)."""
+    return (base_seed + 0x9E3779B97F4A7C15 * (proof_id + 1)) & 0x7FFFFFFFFFFFFFFF
+
+
+def all_gather_roots(local_roots: torch.Tensor, group=None) -> torch.Tensor:
+    """local_roots: uint8 [k, 32] on this rank's device (k equal on all ranks).  Returns [world*k, 32], rank-major:
+    the one collective of the path."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local_roots.clone()
+    world = dist.get_world_size(group)
+    out = torch.empty((world * local_roots.shape[0], 32), dtype=torch.uint8, device=local_roots.device)
+    dist.all_gather_into_tensor(out, local_roots.contiguous(), group=group)
+    return out

@@ -1,0 +1,106 @@
+"""GPU: BASELINE.json configurations at (or near) full size.
+
+cfg 1  Fibonacci-style f64 trace, 2 columns, 2^16 rows (substitute for the absent examples/fib; recurrence of
+       prover/src/tests/mod.rs:17-29)                         -> full bit-exact comparison with the oracle
+cfg 2  2^20 x 8 f64, blowup 8 (the metric)                    -> full root comparison with the threaded oracle +
+                                                                 size-independent properties on samples
+cfg 5' do_work trace (examples/src/do_work/prover.rs:62-80), f128, 10 columns, 2^14 rows -> full comparison
+"""
+import numpy as np
+import pytest
+
+from conftest import rand_f64
+
+pytestmark = pytest.mark.gpu
+F64, F128 = 1, 2
+P64 = 2**64 - 2**32 + 1
+P128 = 2**128 - 45 * 2**40 + 1
+
+
+def test_cfg1_fib_2_16(ctx, orc, capi):
+    n = 1 << 16
+    r1, r2 = [1], [1]
+    for i in range(n - 1):
+        a, b = r1[i], r2[i]
+        r1.append((a + b) % P64)
+        r2.append((a + 2 * b) % P64)
+    cols = [np.array([(v << 64) % P64 for v in r], dtype=np.uint64) for r in (r1, r2)]
+    want = orc.build_trace_commitment(F64, [cols], 1, 16, 3, 7, threads=8)
+    got = ctx.trace_commit(capi.make_params(F64, 1, 16, 3, 2, 1), cols)
+    assert np.array_equal(got["lde"][0], want["lde"][0])
+    assert np.array_equal(got["polys"][0], want["polys"][0][0]) and np.array_equal(got["polys"][1], want["polys"][0][1])
+    assert np.array_equal(got["nodes"], want["nodes"])
+    assert got["root"] == want["root"]
+
+
+def test_do_work_f128(ctx, orc, capi):
+    logR = 14
+    R = 1 << logR
+    traces = []
+    for start in (0, 1):  # two packed traces, as winterfell/src/main.rs packs several
+        col0, x = [], start
+        for _ in range(R):
+            col0.append(x)
+            x = (pow(x, 3, P128) + 42) % P128
+        cols = [orc.f128_from_ints(col0)] + [orc.f128_from_ints([start] * R) for _ in range(9)]
+        traces.append(cols)
+    want = orc.build_trace_commitment(F128, traces, 1, logR, 3, 3, threads=8)
+    got = ctx.trace_commit(capi.make_params(F128, 1, logR, 3, 10, 2), [c for t in traces for c in t])
+    for t in range(2):
+        assert np.array_equal(got["lde"][t], want["lde"][t])
+    assert np.array_equal(got["leaves"], want["leaves"])
+    assert got["root"] == want["root"]
+
+
+def test_cfg2_2_20_x8(ctx, orc, capi):
+    logR, logB, C = 20, 3, 8
+    R, N = 1 << logR, 1 << (logR + logB)
+    rng = np.random.default_rng(0x57415446)
+    cols = [rand_f64(rng, R) for _ in range(C)]
+    got = ctx.trace_commit(capi.make_params(F64, 1, logR, logB, C, 1), cols)
+    lde, polys, leaves, nodes = got["lde"][0], got["polys"], got["leaves"], got["nodes"]
+    L = orc.lib()
+
+    # (a) polys interpolate the trace: P_c(w_R^i) == trace[i, c] on sampled i (definition of interpolate_columns)
+    w = L.orc_f64_get_root_of_unity(logR)
+    samp = [0, 1, R - 1, 12345, 777777]
+    xs = np.array([L.orc_f64_exp(w, i) for i in samp], dtype=np.uint64)
+    for c in (0, 3, 7):
+        assert np.array_equal(orc.eval_many(F64, polys[c], xs), cols[c][samp])
+
+    # (b) LDE rows are evaluations on the coset: lde[j, c] == P_c(7 * g^j)
+    g = L.orc_f64_get_root_of_unity(logR + logB)
+    off = L.orc_f64_new(7)
+    js = [0, 1, 7, 8, N - 1, 4242421, 5000000]
+    xs = np.array([L.orc_f64_mul(off, L.orc_f64_exp(g, j)) for j in js], dtype=np.uint64)
+    for c in (0, 5, 7):
+        assert np.array_equal(orc.eval_many(F64, polys[c], xs), lde[js, c])
+
+    # (c) leaves are hashes of rows; nodes are merges of children; node 0 is the zero digest
+    for j in js + list(range(1000, 1016)):
+        assert bytes(leaves[j]) == orc.hash_elements(F64, lde[j])
+    half = N // 2
+    for i in [1, 2, 3, 255, 256, 511, 512, 4095, 70000, half - 1]:
+        assert bytes(nodes[i]) == orc.merge(bytes(nodes[2 * i]), bytes(nodes[2 * i + 1]))
+    for i in [half, half + 1, N - 1, half + 123457]:
+        k = i - half
+        assert bytes(nodes[i]) == orc.merge(bytes(leaves[2 * k]), bytes(leaves[2 * k + 1]))
+    assert not nodes[0].any()
+    assert got["root"] == bytes(nodes[1])
+
+    # (d) the whole tree again from the GPU leaves with the oracle, and the full path with the threaded oracle
+    assert np.array_equal(orc.build_merkle_nodes(leaves, threads=16), nodes)
+    want = orc.build_trace_commitment(F64, [cols], 1, logR, logB, 7, threads=16)
+    assert want["root"] == got["root"]
+    assert np.array_equal(want["lde"][0], lde)
+
+    # (e) linearity of the LDE: LDE(a + b) == LDE(a) + LDE(b) column-wise (sampled rows)
+    cols2 = [rand_f64(rng, R) for _ in range(C)]
+    both = [np.array([L.orc_f64_add(int(a), int(b)) for a, b in zip(x[:4096], y[:4096])], dtype=np.uint64)
+            for x, y in zip(cols, cols2)]
+    p12 = capi.make_params(F64, 1, 12, logB, C, 1)
+    la = ctx.trace_commit(p12, [c[:4096] for c in cols])["lde"][0]
+    lb = ctx.trace_commit(p12, [c[:4096] for c in cols2])["lde"][0]
+    lab = ctx.trace_commit(p12, both)["lde"][0]
+    for j in (0, 5, 4097, 32767):
+        assert [L.orc_f64_add(int(a), int(b)) for a, b in zip(la[j], lb[j])] == [int(v) for v in lab[j]]

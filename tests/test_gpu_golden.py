@@ -1,0 +1,51 @@
+"""GPU: the HIP path against the committed golden vectors (tests/golden, made by oracle/gen_golden.py without the
+C oracle and without the HIP code)."""
+import numpy as np
+import pytest
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", G.load("lde_commit_small.json"), ids=lambda c: c["name"])
+def test_commit_golden(ctx, capi, case):
+    field, fid, ext = case["field"], G.field_id(case["field"]), case["ext"]
+    traces = [[G.to_mem(field, col) for col in tr] for tr in case["traces"]]
+    n_cols = len(traces[0])
+    params = capi.make_params(fid, ext, case["log2_trace_len"], case["log2_blowup"], n_cols, len(traces),
+                              int(case["offset"]))
+    got = ctx.trace_commit(params, [c for t in traces for c in t])
+    rw = 8 * ((n_cols * ext + 7) // 8)
+    for t in range(len(traces)):
+        for c in range(n_cols):
+            assert np.array_equal(got["polys"][t * n_cols + c], G.to_mem(field, case["polys"][t][c]))
+        assert np.array_equal(got["lde"][t], G.lde_to_mem(field, case["lde"][t], rw))
+    assert G.hexrows(got["leaves"]) == case["leaves"]
+    assert G.hexrows(got["nodes"]) == case["nodes"]
+    assert got["root"].hex() == case["root"]
+    if len(traces) == 1:
+        polys = [G.to_mem(field, col) for col in case["polys"][0]]
+        p1 = capi.make_params(fid, ext, case["log2_trace_len"], case["log2_blowup"], n_cols, 1, int(case["offset"]))
+        assert ctx.constraint_commit(p1, polys)["root"].hex() == case["root"]
+
+
+def test_blake3_golden_through_hash_rows(ctx, capi):
+    """Official-implementation digests: a byte string whose 16-byte words are valid f128 elements is hashed raw by
+    hash_elements (blake/mod.rs:47-51), so wf_hash_rows(F128) must reproduce the BLAKE3 KATs."""
+    g = G.load("blake3_kat.json")
+    n = 0
+    for k in g["kat"]:
+        if k["len"] == 0 or k["len"] % 16:
+            continue
+        data = np.frombuffer(bytes(i % 251 for i in range(k["len"])), dtype=np.uint64)
+        got = ctx.hash_rows(capi.F128, data, 1, k["len"] // 16)
+        assert bytes(got[0]).hex() == k["digest"], k["len"]
+        n += 1
+    assert n >= 10
+    for t in g["trees"]:
+        leaves = np.frombuffer(b"".join(bytes.fromhex(x) for x in t["leaves"]), dtype=np.uint8).reshape(-1, 32)
+        assert G.hexrows(ctx.merkle_build(leaves)) == t["nodes"]
+    m = g["merge"]
+    two = np.frombuffer(bytes.fromhex(m["left"]) + bytes.fromhex(m["right"]), dtype=np.uint8).reshape(2, 32)
+    assert bytes(ctx.merkle_build(two)[1]).hex() == m["digest"]

@@ -1,0 +1,263 @@
+"""Pins the CPU oracle (runs without a GPU).
+
+1. Golden vectors produced independently of the oracle (oracle/gen_golden.py: Python big integers + the official
+   BLAKE3 C implementation).
+2. The definitional / known-answer checks the reference's own tests make for this path, re-run on the oracle:
+     math/src/field/f64/tests.rs:17-161, f128/tests.rs:19-117   field identities and edge cases
+     math/src/fft/tests.rs:19-72                                  fft == polynom::eval_many, twiddles == permuted powers
+     prover/src/matrix/tests.rs:13-40                             row-matrix LDE == per-column evaluation on the coset
+     crypto/src/merkle/tests.rs:67-92                             tree == nested merges
+     crypto/src/hash/blake/tests.rs:11-30                         hash is sensitive to zero padding
+"""
+import numpy as np
+import pytest
+
+import golden_util as G
+from conftest import rand_f64, rand_f128
+
+F64, F128 = 1, 2
+P64 = 2**64 - 2**32 + 1
+P128 = 2**128 - 45 * 2**40 + 1
+
+
+# ------------------------------------------------------------------------------------------------ golden: BLAKE3
+def test_blake3_golden(orc):
+    g = G.load("blake3_kat.json")
+    for k in g["kat"]:
+        data = bytes(i % 251 for i in range(k["len"]))
+        assert orc.blake3(data).hex() == k["digest"], k["len"]
+    m = g["merge"]
+    assert orc.merge(bytes.fromhex(m["left"]), bytes.fromhex(m["right"])).hex() == m["digest"]
+    w = g["merge_with_int"]
+    assert orc.merge_with_int(bytes.fromhex(w["seed"]), w["value"]).hex() == w["digest"]
+    for t in g["trees"]:
+        leaves = np.frombuffer(b"".join(bytes.fromhex(x) for x in t["leaves"]), dtype=np.uint8).reshape(-1, 32)
+        assert G.hexrows(orc.build_merkle_nodes(leaves)) == t["nodes"]
+        assert G.hexrows(orc.build_merkle_nodes(leaves, threads=4)) == t["nodes"]
+
+
+def test_blake3_pyref_agrees(orc):
+    from oracle import pyref
+    g = G.load("blake3_kat.json")
+    for k in g["kat"]:
+        if k["len"] <= 8193:
+            assert pyref.blake3_py(bytes(i % 251 for i in range(k["len"]))).hex() == k["digest"]
+
+
+# ------------------------------------------------------------------------------------------------ golden: fields
+def test_field_golden(orc):
+    g = G.load("field_kat.json")
+    L = orc.lib()
+    f = g["f64"]
+    for o in f["ops"]:
+        a, b = int(o["a"]), int(o["b"])
+        am, bm = L.orc_f64_new(a), L.orc_f64_new(b)
+        assert am == int(o["mem_a"])
+        assert am < P64
+        assert L.orc_f64_as_int(am) == a
+        assert L.orc_f64_as_int(L.orc_f64_add(am, bm)) == int(o["add"])
+        assert L.orc_f64_as_int(L.orc_f64_sub(am, bm)) == int(o["sub"])
+        assert L.orc_f64_as_int(L.orc_f64_mul(am, bm)) == int(o["mul"])
+        assert L.orc_f64_as_int(L.orc_f64_inv(am)) == int(o["inv"])
+    for n, r in f["roots_of_unity"].items():
+        assert L.orc_f64_as_int(L.orc_f64_get_root_of_unity(int(n))) == int(r)
+    f = g["f128"]
+    for o in f["ops"]:
+        a, b = int(o["a"]), int(o["b"])
+        assert orc.f128_op("add", a, b) == int(o["add"])
+        assert orc.f128_op("sub", a, b) == int(o["sub"])
+        assert orc.f128_op("mul", a, b) == int(o["mul"])
+        assert orc.f128_op("inv", a) == int(o["inv"])
+    for n, r in f["roots_of_unity"].items():
+        assert orc.f128_root_of_unity(int(n)) == int(r)
+
+
+def test_f64_reference_known_answers(orc):
+    """math/src/field/f64/tests.rs:17-161 (the assertions with literal operands)."""
+    L = orc.lib()
+    new, val = L.orc_f64_new, L.orc_f64_as_int
+    add, sub, mul = L.orc_f64_add, L.orc_f64_sub, L.orc_f64_mul
+    M = P64
+    assert add(new(2), new(3)) == new(5)
+    t = new(M - 1)
+    assert add(t, new(1)) == new(0) and add(t, new(2)) == new(1)          # tests.rs:28-31
+    assert sub(new(5), new(3)) == new(2) and sub(new(3), new(5)) == new(M - 2)  # :41-48
+    assert mul(new(5), new(3)) == new(15)
+    assert mul(t, t) == new(1) and mul(t, new(2)) == new(M - 2) and mul(t, new(4)) == new(M - 4)  # :74-78
+    assert mul(new((M + 1) // 2), new(2)) == new(1)                        # :80-84
+    assert val(new(2**64 - 1)) == (2**64 - 1) % M                           # :124-127
+    assert val(new(0)) == val(new(M)) == 0                                  # :129-132
+    assert L.orc_f64_inv(new(1)) == new(1) and L.orc_f64_inv(new(0)) == new(0)  # :117-120
+    r32 = L.orc_f64_get_root_of_unity(32)
+    assert val(r32) == 7277203076849721926 and L.orc_f64_exp(r32, 1 << 32) == new(1)  # :150-154
+    assert L.orc_f64_get_root_of_unity(31) == L.orc_f64_exp(r32, 2)        # :156-159
+    assert val(L.orc_f64_get_root_of_unity(6)) == 8  # omega_64 = 2^3
+
+
+def test_f128_reference_known_answers(orc):
+    """math/src/field/f128/tests.rs:19-117 (literal operands)."""
+    M = P128
+    op = orc.f128_op
+    assert op("add", 2, 3) == 5 and op("add", M - 1, 1) == 0 and op("add", M - 1, 2) == 1
+    assert op("sub", 5, 3) == 2 and op("sub", 3, 5) == M - 2
+    assert op("mul", 5, 3) == 15 and op("mul", M - 1, M - 1) == 1
+    assert op("mul", M - 1, 2) == M - 2 and op("mul", M - 1, 4) == M - 4
+    assert op("mul", (M + 1) // 2, 2) == 1
+    assert op("inv", 1) == 1 and op("inv", 0) == 0
+    rng = np.random.default_rng(3)
+    for v in orc.f128_to_ints(rand_f128(rng, 200)):
+        assert op("mul", v, op("inv", v)) == (1 if v else 0)
+    r40 = orc.f128_root_of_unity(40)
+    assert r40 == 23953097886125630542083529559205016746 and pow(r40, 1 << 40, M) == 1
+
+
+# ------------------------------------------------------------------------------------------------ golden: the path
+@pytest.mark.parametrize("case", G.load("lde_commit_small.json"), ids=lambda c: c["name"])
+def test_commit_golden(orc, case):
+    field, fid, ext = case["field"], G.field_id(case["field"]), case["ext"]
+    traces = [[G.to_mem(field, col) for col in tr] for tr in case["traces"]]
+    for threads in (1, 3):
+        got = orc.build_trace_commitment(fid, traces, ext, case["log2_trace_len"], case["log2_blowup"],
+                                         int(case["offset"]), threads=threads)
+        rw = orc.row_width(len(traces[0]), ext)
+        for t in range(len(traces)):
+            for c in range(len(traces[t])):
+                assert np.array_equal(got["polys"][t][c], G.to_mem(field, case["polys"][t][c]))
+            assert np.array_equal(got["lde"][t], G.lde_to_mem(field, case["lde"][t], rw))
+        assert G.hexrows(got["leaves"]) == case["leaves"]
+        assert G.hexrows(got["nodes"]) == case["nodes"]
+        assert got["root"].hex() == case["root"]
+    if len(traces) == 1:  # the constraint-commitment entry takes coefficient columns
+        polys = [G.to_mem(field, col) for col in case["polys"][0]]
+        got = orc.build_constraint_commitment(fid, polys, ext, case["log2_trace_len"], case["log2_blowup"],
+                                              int(case["offset"]))
+        assert got["root"].hex() == case["root"]
+
+
+# ------------------------------------------------------------------------------------------------ reference-shaped checks
+@pytest.mark.parametrize("field", [F64, F128])
+@pytest.mark.parametrize("n", [4, 8, 16, 1024])
+def test_fft_equals_naive_evaluation(orc, field, n):
+    """math/src/fft/tests.rs:19-60: fft_in_place + permute == polynom::eval_many over the domain."""
+    rng = np.random.default_rng(n)
+    p = rand_f64(rng, n) if field == F64 else rand_f128(rng, n)
+    tw = orc.get_twiddles(field, n)
+    lg = n.bit_length() - 1
+    if field == F64:
+        g = orc.lib().orc_f64_get_root_of_unity(lg)
+        one = orc.lib().orc_f64_new(1)
+        dom = np.empty(n, dtype=np.uint64)
+        acc = one
+        for i in range(n):
+            dom[i] = acc
+            acc = orc.lib().orc_f64_mul(acc, g)
+    else:
+        g = orc.f128_root_of_unity(lg)
+        dom = orc.f128_from_ints([pow(g, i, P128) for i in range(n)])
+    want = orc.eval_many(field, p, dom)
+    got = p.copy()
+    orc.fft_in_place(field, got, n, 1, tw)
+    orc.permute(field, got, n)
+    assert np.array_equal(got, want)
+    got2 = p.copy()
+    orc.evaluate_poly(field, got2, n, 1, tw)
+    assert np.array_equal(got2, want)
+    # interpolate back (doctest fft/mod.rs:253-273)
+    orc.interpolate_poly(field, got2, n, 1, orc.get_twiddles(field, n, inverse=True))
+    assert np.array_equal(got2, p)
+
+
+def test_twiddles_are_permuted_powers(orc):
+    """math/src/fft/tests.rs:62-72."""
+    n = 2048
+    tw = orc.get_twiddles(F128, n)
+    g = orc.f128_root_of_unity(11)
+    want = orc.f128_from_ints([pow(g, i, P128) for i in range(n // 2)])
+    orc.permute(F128, want, n // 2)
+    assert np.array_equal(tw, want)
+    assert tw.shape[0] == n // 2
+
+
+def test_row_matrix_lde_equals_column_evaluation(orc):
+    """prover/src/matrix/tests.rs:13-40: 64 polys of size 256, blowup 8, offset GENERATOR; every column of the
+    row-major LDE equals evaluate_poly_with_offset of that column (and the naive evaluation on the coset)."""
+    rng = np.random.default_rng(64)
+    n, blowup, ncols = 256, 8, 64
+    polys = [rand_f64(rng, n) for _ in range(ncols)]
+    lde = orc.evaluate_polys_over(F64, polys, 1, 8, 3, 7)
+    tw = orc.get_twiddles(F64, n)
+    L = orc.lib()
+    off = L.orc_f64_new(7)
+    for c in range(ncols):
+        col = orc.evaluate_poly_with_offset(F64, polys[c], n, 1, tw, off, blowup)
+        assert np.array_equal(lde[:, c], col)
+    # naive: P(offset * g^j) for a few columns
+    g = L.orc_f64_get_root_of_unity(11)
+    xs = np.empty(n * blowup, dtype=np.uint64)
+    acc = off
+    for j in range(n * blowup):
+        xs[j] = acc
+        acc = L.orc_f64_mul(acc, g)
+    for c in (0, 17, 63):
+        assert np.array_equal(orc.eval_many(F64, polys[c], xs), lde[:, c])
+    # multi-threaded build is identical
+    assert np.array_equal(orc.evaluate_polys_over(F64, polys, 1, 8, 3, 7, threads=4), lde)
+
+
+def test_interpolate_with_offset_roundtrip(orc):
+    """math/src/fft/mod.rs:339-361 doctest shape: evaluate on a coset (blowup 1 equivalent) and interpolate back."""
+    rng = np.random.default_rng(5)
+    n = 512
+    for field, off in ((F64, 7), (F128, 3)):
+        p = rand_f64(rng, n) if field == F64 else rand_f128(rng, n)
+        tw = orc.get_twiddles(field, n)
+        off_mem = orc.lib().orc_f64_new(off) if field == F64 else off
+        ev = orc.evaluate_poly_with_offset(field, p, n, 1, tw, off_mem, 2)
+        # even-indexed LDE points form the coset of size n with the same offset
+        sub = np.ascontiguousarray(ev[0::2])
+        orc.interpolate_poly_with_offset(field, sub, n, 1, orc.get_twiddles(field, n, inverse=True), off_mem)
+        assert np.array_equal(sub, p)
+
+
+def test_merkle_is_nested_merges(orc):
+    """crypto/src/merkle/tests.rs:67-92."""
+    rng = np.random.default_rng(8)
+    leaves = rng.integers(0, 256, size=(8, 32), dtype=np.uint8)
+    lv = [bytes(x) for x in leaves]
+    m = orc.merge
+    n4 = [m(lv[0], lv[1]), m(lv[2], lv[3]), m(lv[4], lv[5]), m(lv[6], lv[7])]
+    n2 = [m(n4[0], n4[1]), m(n4[2], n4[3])]
+    root = m(n2[0], n2[1])
+    nodes = orc.build_merkle_nodes(leaves)
+    assert [bytes(x) for x in nodes] == [bytes(32), root, n2[0], n2[1], n4[0], n4[1], n4[2], n4[3]]
+    with pytest.raises(ValueError):
+        orc.build_merkle_nodes(leaves[:1])   # merkle/mod.rs:118-120
+    with pytest.raises(ValueError):
+        orc.build_merkle_nodes(leaves[:6])   # :121-123
+    big = rng.integers(0, 256, size=(4096, 32), dtype=np.uint8)
+    assert np.array_equal(orc.build_merkle_nodes(big), orc.build_merkle_nodes(big, threads=8))  # concurrent.rs:84-90
+
+
+def test_hash_padding_sensitivity(orc):
+    """crypto/src/hash/blake/tests.rs:11-30."""
+    assert orc.blake3(bytes([1, 2, 3])) != orc.blake3(bytes([1, 2, 3, 0]))
+    e = np.array([orc.lib().orc_f64_new(v) for v in (1, 2, 3)], dtype=np.uint64)
+    e0 = np.array([orc.lib().orc_f64_new(v) for v in (1, 2, 3, 0)], dtype=np.uint64)
+    assert orc.hash_elements(F64, e) != orc.hash_elements(F64, e0)
+    # hash_elements of f64 hashes canonical little-endian bytes (f64/mod.rs:605-610)
+    assert orc.hash_elements(F64, e) == orc.blake3(b"".join(int(v).to_bytes(8, "little") for v in (1, 2, 3)))
+    # f128 hashes the raw element bytes (blake/mod.rs:47-51)
+    x = orc.f128_from_ints([5, 2**100 + 3])
+    assert orc.hash_elements(F128, x) == orc.blake3((5).to_bytes(16, "little") + (2**100 + 3).to_bytes(16, "little"))
+
+
+def test_oracle_rejects_bad_parameters(orc):
+    col = [np.zeros(8, dtype=np.uint64)]
+    with pytest.raises(ValueError):
+        orc.build_trace_commitment(F64, [col], 1, 2, 1, 7)     # trace too short
+    with pytest.raises(ValueError):
+        orc.build_trace_commitment(F64, [col], 1, 3, 0, 7)     # blowup 1
+    with pytest.raises(ValueError):
+        orc.build_trace_commitment(F64, [col], 1, 3, 1, 0)     # zero offset
+    with pytest.raises(ValueError):
+        orc.build_trace_commitment(F128, [col], 3, 3, 1, 3)    # no cubic extension over f128
