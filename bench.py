@@ -55,9 +55,9 @@ def rand_f64_dev(torch, n, seed, device):
     return torch.where(bad, v & 0x7FFFFFFFFFFFFFFF, v)
 
 
-def cpu_baseline(model):
-    """One full commitment of the bench workload with the threaded CPU oracle (test infrastructure used as the
-    reported CPU baseline only)."""
+def cpu_baseline(model, trace_host=None, gpu_root=None):
+    """One full commitment of the bench workload (the very trace rank 0 committed on the GPU) with the threaded CPU
+    oracle -- test infrastructure, used here only as the reported CPU baseline and as a last parity gate."""
     import numpy as np
     from oracle import oracle as O
     O.build()
@@ -78,14 +78,15 @@ def cpu_baseline(model):
         return out
 
     O.build_trace_commitment(O.F64, [cols(14)], 1, 14, LOG_B, 7, threads=threads)  # warm-up (threads, page cache)
-    data = cols(LOG_R)
+    data = cols(LOG_R) if trace_host is None else [np.ascontiguousarray(c) for c in trace_host]
     t0 = time.perf_counter()
     res = O.build_trace_commitment(O.F64, [data], 1, LOG_R, LOG_B, 7, threads=threads)
     dt = time.perf_counter() - t0
     return dict(value=model["field_ops"] / dt, unit="field-ops/s", cores=threads, kind="port",
                 sample=f"1 full commitment (2^{LOG_R} x {N_COLS} f64, blowup {1 << LOG_B}) after a 2^14-row warm-up; "
                        f"{dt * 1e3:.0f} ms wall incl. output allocation",
-                ms=dt * 1e3, root=res["root"].hex())
+                ms=dt * 1e3, root=res["root"].hex(),
+                root_matches_gpu=(None if gpu_root is None else res["root"].hex() == gpu_root))
 
 
 def main():
@@ -208,7 +209,10 @@ def main():
             "root": root_hex,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model)
+            th = trace.cpu().numpy().view("uint64").reshape(N_COLS, R)
+            out["cpu_baseline"] = cpu_baseline(model, th, root_hex)
+            if out["cpu_baseline"]["root_matches_gpu"] is False:
+                raise SystemExit("PARITY FAILURE: CPU oracle root != GPU root on the bench workload")
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if world > 1:
