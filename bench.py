@@ -167,7 +167,7 @@ def main():
         value = commits * model["field_ops"] / elapsed
         avg = {k: sum(v) / len(v) for k, v in per_launch.items()}
         logical = {
-            "interpolate": sum(v for k, v in avg.items() if k.startswith("interpolate")),
+            "interpolate": sum(v for k, v in avg.items() if k.startswith(("interpolate", "layout"))),
             "evaluate": sum(v for k, v in avg.items() if k.startswith("evaluate")),
             "hash_rows": avg.get("hash_rows", 0.0),
             "merkle": avg.get("merkle", 0.0),

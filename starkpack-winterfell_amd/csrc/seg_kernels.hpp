@@ -1,0 +1,357 @@
+// "Segment" NTT kernels: the commitment path's transforms on a lane-interleaved layout.
+//
+// A segment is S = 64 / sizeof(element) base columns (8 for f64, 4 for f128) stored row by row:
+//     seg[g][n][l]   g = segment, n = row (coefficient / evaluation index), l = lane
+// i.e. one 64-byte row per index -- the device-side analogue of the reference's `Segment<B, 8>`
+// (prover/src/matrix/segments.rs:35-41), chosen because the S lanes of a row share every twiddle, coset factor and
+// index computation, and because every global access is a whole 64-byte row.  Base columns of all traces are packed
+// back to back into segments (base column index B = trace * base_cols + column), only the last segment is padded.
+//
+// Transform structure (same as kernels.hpp): N = 2^L split into digit passes; a strided pass handles the rows
+// (o, d, i), d = 0..D-1, of one inner position i; the last pass handles D contiguous rows and scatters to natural
+// order.  Inside LDS: radix-4 rounds on x[D][S], two lanes per thread (16-byte LDS accesses for f64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "field.hpp"
+#include "kernels.hpp"
+
+namespace wf {
+
+template <class F>
+struct SegCfg {
+    static constexpr uint32_t S = 64 / F::BYTES;  // lanes per segment row
+    static constexpr uint32_t HP = S / 2;         // lane pairs per row
+};
+
+template <class T>
+struct alignas(16) Pair {
+    T a, b;
+};
+
+enum : int { SEG_OUT_SEG = 0, SEG_OUT_ROWS = 1 };
+
+template <class F>
+struct SegArgs {
+    typedef typename F::T T;
+    const T *src;
+    T *dst;
+    uint32_t logN, logD;
+    uint64_t I, O;          // inner / outer row counts of the [O][D][I] view (last pass: I = 1)
+    uint32_t n_seg;         // segments per coset
+    uint32_t n_cosets;
+    uint32_t src_shared;    // source indexed by segment only (first pass of an evaluation reads the polys)
+    Pow2L<F> tw;            // powers of the N-th root of this transform
+    const T *digit_tw;      // [D] powers of the D-th root
+    uint32_t pre_on;        // multiply input row n by h_c^n (first pass of a coset evaluation)
+    Pow2L<F> pre;
+    uint64_t pre_lo_stride, pre_hi_stride;
+    uint32_t scale_on;      // multiply by `scale` (strided pass: folded into the twiddle table; last pass: at store)
+    T scale;
+    // last pass
+    uint32_t n_prev;
+    uint32_t prev_log[3];
+    // SEG_OUT_ROWS
+    uint32_t base_cols;        // base columns per trace
+    uint32_t total_base_cols;  // over all traces
+    uint32_t log_blowup;
+    uint64_t row_width;
+    uint64_t trace_lde_elems;
+};
+
+// radix-4 / radix-2 rounds on x[D][S] with two lanes per work item; twd[e] = w_D^e
+template <class F>
+__device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::T *twd, uint32_t logD) {
+    typedef typename F::T T;
+    typedef Pair<T> P2;
+    constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;
+    constexpr uint32_t hp_shift = HP == 4 ? 2 : 1;
+    const uint32_t D = 1u << logD;
+    uint32_t cur = logD;
+    T w4 = F::one();
+    if (logD >= 2) w4 = twd[D >> 2];
+    while (cur > 0) {
+        if (cur >= 2) {
+            const uint32_t mlog = cur - 2, m = 1u << mlog;
+            const uint32_t nwork = (D >> 2) * HP;
+            const uint32_t tshift = logD - cur;
+            const uint32_t st = m * S;
+            for (uint32_t wk = threadIdx.x; wk < nwork; wk += blockDim.x) {
+                const uint32_t lp = wk & (HP - 1), u = wk >> hp_shift;
+                const uint32_t jp = u & (m - 1), p = u >> mlog;
+                const uint32_t base = (((p << cur) + jp) * S) + 2 * lp;
+                P2 x0 = *reinterpret_cast<P2 *>(x + base);
+                P2 x1 = *reinterpret_cast<P2 *>(x + base + st);
+                P2 x2 = *reinterpret_cast<P2 *>(x + base + 2 * st);
+                P2 x3 = *reinterpret_cast<P2 *>(x + base + 3 * st);
+                P2 y0, y1, y2, y3;
+                {
+                    T a = F::add(x0.a, x2.a), b = F::sub(x0.a, x2.a), c = F::add(x1.a, x3.a);
+                    T d = F::mul(F::sub(x1.a, x3.a), w4);
+                    y0.a = F::add(a, c);
+                    y2.a = F::sub(a, c);
+                    y1.a = F::add(b, d);
+                    y3.a = F::sub(b, d);
+                }
+                {
+                    T a = F::add(x0.b, x2.b), b = F::sub(x0.b, x2.b), c = F::add(x1.b, x3.b);
+                    T d = F::mul(F::sub(x1.b, x3.b), w4);
+                    y0.b = F::add(a, c);
+                    y2.b = F::sub(a, c);
+                    y1.b = F::add(b, d);
+                    y3.b = F::sub(b, d);
+                }
+                if (jp != 0) {
+                    const uint32_t e = jp << tshift;
+                    const T t1 = twd[e], t2 = twd[2 * e], t3 = twd[3 * e];
+                    y1.a = F::mul(y1.a, t1);
+                    y1.b = F::mul(y1.b, t1);
+                    y2.a = F::mul(y2.a, t2);
+                    y2.b = F::mul(y2.b, t2);
+                    y3.a = F::mul(y3.a, t3);
+                    y3.b = F::mul(y3.b, t3);
+                }
+                *reinterpret_cast<P2 *>(x + base) = y0;
+                *reinterpret_cast<P2 *>(x + base + st) = y1;
+                *reinterpret_cast<P2 *>(x + base + 2 * st) = y2;
+                *reinterpret_cast<P2 *>(x + base + 3 * st) = y3;
+            }
+            cur -= 2;
+        } else {
+            const uint32_t nwork = (D >> 1) * HP;
+            for (uint32_t wk = threadIdx.x; wk < nwork; wk += blockDim.x) {
+                const uint32_t lp = wk & (HP - 1), u = wk >> hp_shift;
+                const uint32_t base = (u << 1) * S + 2 * lp;
+                P2 x0 = *reinterpret_cast<P2 *>(x + base);
+                P2 x1 = *reinterpret_cast<P2 *>(x + base + S);
+                P2 y0, y1;
+                y0.a = F::add(x0.a, x1.a);
+                y1.a = F::sub(x0.a, x1.a);
+                y0.b = F::add(x0.b, x1.b);
+                y1.b = F::sub(x0.b, x1.b);
+                *reinterpret_cast<P2 *>(x + base) = y0;
+                *reinterpret_cast<P2 *>(x + base + S) = y1;
+            }
+            cur = 0;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Strided pass.  grid.x = n_cosets * n_seg * O * I ; work-group = (coset c, segment g, outer o, inner i)
+template <class F>
+__global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
+    typedef typename F::T T;
+    typedef Pair<T> P2;
+    constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;
+    constexpr uint32_t hp_shift = HP == 4 ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const uint32_t D = 1u << a.logD;
+    T *x = reinterpret_cast<T *>(smem_raw);
+    T *twd = x + (size_t)D * S;
+    T *aux = twd + D;  // coset factors of the input rows, later the inter-pass twiddles of the output rows
+
+    uint64_t bid = blockIdx.x;
+    const uint64_t i = bid % a.I;
+    bid /= a.I;
+    const uint64_t o = bid % a.O;
+    bid /= a.O;
+    const uint32_t g = (uint32_t)(bid % a.n_seg);
+    const uint32_t c = (uint32_t)(bid / a.n_seg);
+    const uint64_t seg_elems = ((uint64_t)1 << a.logN) * S;
+    const T *src = a.src + (a.src_shared ? (uint64_t)g : (uint64_t)c * a.n_seg + g) * seg_elems;
+    T *dst = a.dst + ((uint64_t)c * a.n_seg + g) * seg_elems;
+
+    Pow2L<F> pre = a.pre;
+    if (a.pre_on) {
+        pre.lo += (uint64_t)c * a.pre_lo_stride;
+        pre.hi += (uint64_t)c * a.pre_hi_stride;
+    }
+    for (uint32_t e = threadIdx.x; e < D; e += blockDim.x) {
+        twd[e] = a.digit_tw[e];
+        if (a.pre_on) aux[e] = pre.get((uint64_t)e * a.I);  // h_c^(d*I); the h_c^i part goes into the output table
+    }
+    __syncthreads();
+
+    const uint32_t nitems = D * HP;
+    const uint64_t row0 = o * D * a.I + i;  // row index of d = 0; rows of this group are I apart
+    for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
+        const uint32_t lp = wk & (HP - 1), d = wk >> hp_shift;
+        P2 v = *reinterpret_cast<const P2 *>(src + (row0 + (uint64_t)d * a.I) * S + 2 * lp);
+        if (a.pre_on) {
+            const T f = aux[d];
+            v.a = F::mul(v.a, f);
+            v.b = F::mul(v.b, f);
+        }
+        *reinterpret_cast<P2 *>(x + d * S + 2 * lp) = v;
+    }
+    __syncthreads();
+    seg_lds_ntt<F>(x, twd, a.logD);
+
+    // output factors: start * (w_N^(i * N/(D*I)))^k, start = h_c^i (evaluation) or the 1/n scale (interpolation)
+    {
+        const uint32_t tw_shift = a.logN - a.logD - (63 - __builtin_clzll(a.I));
+        T start = a.scale_on ? a.scale : F::one();
+        if (a.pre_on) start = pre.get(i);
+        const bool trivial = !a.scale_on && !a.pre_on;
+        for (uint32_t k = threadIdx.x; k < D; k += blockDim.x) {
+            const uint64_t e = ((uint64_t)k * i) << tw_shift;
+            T f = a.tw.get(e);
+            if (!trivial) f = F::mul(f, start);
+            aux[k] = f;
+        }
+    }
+    __syncthreads();
+    for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
+        const uint32_t lp = wk & (HP - 1), pos = wk >> hp_shift;
+        const uint32_t k = digit_reverse(pos, a.logD);
+        P2 v = *reinterpret_cast<P2 *>(x + pos * S + 2 * lp);
+        const T f = aux[k];
+        v.a = F::mul(v.a, f);
+        v.b = F::mul(v.b, f);
+        *reinterpret_cast<P2 *>(dst + (row0 + (uint64_t)k * a.I) * S + 2 * lp) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Last pass.  grid.x = n_cosets * n_seg * O ; work-group = (coset c, segment g, row block o) of D contiguous rows.
+template <class F, int OUT>
+__global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
+    typedef typename F::T T;
+    typedef Pair<T> P2;
+    constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;
+    constexpr uint32_t hp_shift = HP == 4 ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const uint32_t D = 1u << a.logD;
+    T *x = reinterpret_cast<T *>(smem_raw);
+    T *twd = x + (size_t)D * S;
+    T *aux = twd + D;
+
+    uint64_t bid = blockIdx.x;
+    const uint64_t o = bid % a.O;
+    bid /= a.O;
+    const uint32_t g = (uint32_t)(bid % a.n_seg);
+    const uint32_t c = (uint32_t)(bid / a.n_seg);
+    const uint64_t seg_elems = ((uint64_t)1 << a.logN) * S;
+    const T *src = a.src + (a.src_shared ? (uint64_t)g : (uint64_t)c * a.n_seg + g) * seg_elems + o * D * S;
+
+    // natural-order contribution of the earlier digits: o = (k1, k2, ..), k1 most significant -> k1 + N1*k2 + ..
+    uint64_t rev_o = 0;
+    {
+        uint32_t bits = 0;
+        for (uint32_t q = 0; q < a.n_prev; q++) bits += a.prev_log[q];
+        uint32_t hi = bits, sh = 0;
+        for (uint32_t q = 0; q < a.n_prev; q++) {
+            hi -= a.prev_log[q];
+            rev_o |= ((o >> hi) & (((uint64_t)1 << a.prev_log[q]) - 1)) << sh;
+            sh += a.prev_log[q];
+        }
+    }
+
+    Pow2L<F> pre = a.pre;
+    if (a.pre_on) {
+        pre.lo += (uint64_t)c * a.pre_lo_stride;
+        pre.hi += (uint64_t)c * a.pre_hi_stride;
+    }
+    for (uint32_t e = threadIdx.x; e < D; e += blockDim.x) {
+        twd[e] = a.digit_tw[e];
+        if (a.pre_on) aux[e] = pre.get(e);  // single-pass evaluation: row index = coefficient index
+    }
+    __syncthreads();
+    const uint32_t nitems = D * HP;
+    for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
+        P2 v = *reinterpret_cast<const P2 *>(src + 2 * (uint64_t)wk);
+        if (a.pre_on) {
+            const T f = aux[wk >> hp_shift];
+            v.a = F::mul(v.a, f);
+            v.b = F::mul(v.b, f);
+        }
+        *reinterpret_cast<P2 *>(x + 2 * wk) = v;
+    }
+    __syncthreads();
+    seg_lds_ntt<F>(x, twd, a.logD);
+
+    const uint32_t out_shift = a.logN - a.logD;
+    if (OUT == SEG_OUT_SEG) {
+        T *dst = a.dst + ((uint64_t)c * a.n_seg + g) * seg_elems;
+        for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
+            const uint32_t lp = wk & (HP - 1), pos = wk >> hp_shift;
+            const uint64_t k = rev_o + ((uint64_t)digit_reverse(pos, a.logD) << out_shift);
+            P2 v = *reinterpret_cast<P2 *>(x + pos * S + 2 * lp);
+            if (a.scale_on) {
+                v.a = F::mul(v.a, a.scale);
+                v.b = F::mul(v.b, a.scale);
+            }
+            *reinterpret_cast<P2 *>(dst + k * S + 2 * lp) = v;
+        }
+    } else {
+        for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
+            const uint32_t lp = wk & (HP - 1), pos = wk >> hp_shift;
+            const uint64_t k = rev_o + ((uint64_t)digit_reverse(pos, a.logD) << out_shift);
+            const uint64_t row = (k << a.log_blowup) + c;
+            P2 v = *reinterpret_cast<P2 *>(x + pos * S + 2 * lp);
+            const uint32_t B = g * S + 2 * lp;  // global base column of lane a
+            if (B >= a.total_base_cols) continue;
+            const uint32_t t0 = B / a.base_cols, c0 = B - t0 * a.base_cols;
+            T *p0 = a.dst + (uint64_t)t0 * a.trace_lde_elems + row * a.row_width + c0;
+            if (c0 + 1 < a.base_cols && (c0 & 1) == 0) {
+                *reinterpret_cast<P2 *>(p0) = v;  // both lanes in the same trace, 16-byte aligned
+            } else {
+                *p0 = v.a;
+                if (B + 1 < a.total_base_cols) {
+                    const uint32_t t1 = (B + 1) / a.base_cols, c1 = (B + 1) - t1 * a.base_cols;
+                    a.dst[(uint64_t)t1 * a.trace_lde_elems + row * a.row_width + c1] = v.b;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Layout changes between the caller's columns ([col][row][ext coordinate]) and segments.
+template <class F>
+struct XposeArgs {
+    typedef typename F::T T;
+    const T *src;
+    T *dst;
+    uint64_t R;               // rows
+    uint32_t W;               // coordinates per column element
+    uint32_t total_base_cols;
+};
+
+// grid.x = n_seg * ceil(R / (256 / S)); one thread per (row, lane)
+template <class F>
+__global__ void __launch_bounds__(256) k_cols_to_seg(XposeArgs<F> a) {
+    constexpr uint32_t S = SegCfg<F>::S, RPB = 256 / S;
+    const uint64_t blocks_per_seg = (a.R + RPB - 1) / RPB;
+    const uint32_t g = (uint32_t)(blockIdx.x / blocks_per_seg);
+    const uint64_t r = (blockIdx.x % blocks_per_seg) * RPB + threadIdx.x / S;
+    const uint32_t l = threadIdx.x % S;
+    if (r >= a.R) return;
+    const uint32_t B = g * S + l;
+    typename F::T v = F::zero();
+    if (B < a.total_base_cols) {
+        const uint32_t col = B / a.W, w = B - col * a.W;
+        v = a.src[((uint64_t)col * a.R + r) * a.W + w];
+    }
+    a.dst[((uint64_t)g * a.R + r) * S + l] = v;
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) k_seg_to_cols(XposeArgs<F> a) {
+    constexpr uint32_t S = SegCfg<F>::S, RPB = 256 / S;
+    const uint64_t blocks_per_seg = (a.R + RPB - 1) / RPB;
+    const uint32_t g = (uint32_t)(blockIdx.x / blocks_per_seg);
+    const uint64_t r = (blockIdx.x % blocks_per_seg) * RPB + threadIdx.x / S;
+    const uint32_t l = threadIdx.x % S;
+    if (r >= a.R) return;
+    const uint32_t B = g * S + l;
+    if (B >= a.total_base_cols) return;
+    const uint32_t col = B / a.W, w = B - col * a.W;
+    a.dst[((uint64_t)col * a.R + r) * a.W + w] = a.src[((uint64_t)g * a.R + r) * S + l];
+}
+
+}  // namespace wf

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "seg_kernels.hpp"
 
 using namespace wf;
 
@@ -381,6 +382,180 @@ static int run_transform(wf_ctx *ctx, hipStream_t st, const XformDesc<F> &d) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------- segment pipeline
+// powers of the 2^logD-th root (or its inverse), D entries, for the in-LDS transform of one digit
+template <class F>
+static int digit_table(wf_ctx *ctx, uint32_t logD, bool inverse, const typename F::T **out) {
+    auto key = std::make_tuple((int)F::FIELD_ID, (int)logD, inverse ? 5 : 4, 0, (uint64_t)0, (uint64_t)0);
+    auto it = ctx->tables.find(key);
+    if (it == ctx->tables.end()) {
+        typedef typename F::T T;
+        T w = f_root_of_unity<F>(logD ? logD : 1);
+        if (logD == 0) w = F::one();
+        if (inverse) w = f_inv<F>(w);
+        std::vector<T> tab((size_t)1 << logD);
+        T acc = F::one();
+        for (auto &v : tab) {
+            v = acc;
+            acc = F::mul(acc, w);
+        }
+        TableSet ts;
+        HIP_TRY(hipMalloc(&ts.lo, tab.size() * sizeof(T)));
+        HIP_TRY(hipMemcpy(ts.lo, tab.data(), tab.size() * sizeof(T), hipMemcpyHostToDevice));
+        it = ctx->tables.emplace(key, ts).first;
+    }
+    *out = (const typename F::T *)it->second.lo;
+    return 0;
+}
+
+template <class F>
+static int seg_launch_dims(uint32_t logD, uint32_t &threads, size_t &lds) {
+    const size_t D = (size_t)1 << logD;
+    lds = (D * SegCfg<F>::S + 2 * D) * sizeof(typename F::T);
+    if (lds > 160 * 1024) return fail(WF_ERR_ARG, "internal: pass needs %zu bytes of LDS", lds);
+    threads = logD >= 9 ? 512 : 256;
+    if (lds > 64 * 1024) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k_seg_strided<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_seg_last<F, SEG_OUT_SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_seg_last<F, SEG_OUT_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    return 0;
+}
+
+// One transform of n_seg segments (x n_cosets cosets).
+//   interpolation (rows_out == false): in  = [n_seg][N][S] evaluations (overwritten when N needs > 1 pass),
+//                                      out = [n_seg][N][S] coefficients, natural order, scaled by 1/N
+//   evaluation    (rows_out == true) : in  = [n_seg][N][S] coefficients (read only), work = [cosets][n_seg][N][S],
+//                                      out = row-major LDE matrices (see SegArgs)
+template <class F>
+struct SegDesc {
+    typedef typename F::T T;
+    const T *in;
+    T *work;
+    T *out;
+    uint32_t logN, n_seg, n_cosets;
+    bool rows_out;
+    const TableSet *pre;
+    uint32_t base_cols, total_base_cols, log_blowup;
+    uint64_t row_width, trace_lde_elems;
+};
+
+template <class F>
+static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
+    typedef typename F::T T;
+    const bool inverse = !d.rows_out;
+    TableSet *tw;
+    int rc = root_tables<F>(ctx, d.logN, inverse, &tw);
+    if (rc) return rc;
+    const Plan plan = make_plan(d.logN);
+    const uint64_t N = (uint64_t)1 << d.logN;
+
+    SegArgs<F> a;
+    memset(&a, 0, sizeof(a));
+    a.logN = d.logN;
+    a.n_seg = d.n_seg;
+    a.n_cosets = d.n_cosets;
+    a.tw = as_pow2l<F>(*tw);
+    if (d.pre) {
+        a.pre = as_pow2l<F>(*d.pre);
+        a.pre_lo_stride = d.pre->lo_stride;
+        a.pre_hi_stride = d.pre->hi_stride;
+    }
+    a.base_cols = d.base_cols;
+    a.total_base_cols = d.total_base_cols;
+    a.log_blowup = d.log_blowup;
+    a.row_width = d.row_width;
+    a.trace_lde_elems = d.trace_lde_elems;
+    const T inv_n = inverse ? f_inv<F>(F::from_u128_canonical((u128)1 << d.logN)) : F::one();
+    const char *tag_s = d.rows_out ? "evaluate.strided_pass" : "interpolate.strided_pass";
+    const char *tag_l = d.rows_out ? "evaluate.last_pass" : "interpolate.last_pass";
+
+    uint32_t done_bits = 0;
+    for (int pi = 0; pi + 1 < plan.n_pass; pi++) {
+        const bool first = pi == 0;
+        a.logD = plan.dig[pi];
+        a.O = (uint64_t)1 << done_bits;
+        a.I = N >> (done_bits + a.logD);
+        rc = digit_table<F>(ctx, a.logD, inverse, &a.digit_tw);
+        if (rc) return rc;
+        if (d.rows_out) {
+            a.src = first ? d.in : d.work;
+            a.dst = d.work;
+            a.src_shared = first ? 1 : 0;
+            a.pre_on = first ? 1 : 0;
+            a.scale_on = 0;
+        } else {
+            a.src = first ? d.in : d.work;  // interpolation: first pass in -> work, later passes in place
+            a.dst = d.work;
+            a.src_shared = 0;
+            a.pre_on = 0;
+            a.scale_on = first ? 1 : 0;     // 1/n rides on the first inter-pass twiddle table
+            a.scale = inv_n;
+        }
+        uint32_t threads;
+        size_t lds;
+        rc = seg_launch_dims<F>(a.logD, threads, lds);
+        if (rc) return rc;
+        const uint64_t grid = (uint64_t)d.n_cosets * d.n_seg * a.O * a.I;
+        if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
+        prof_mark(ctx, st, tag_s);
+        hipLaunchKernelGGL(k_seg_strided<F>, dim3((uint32_t)grid), dim3(threads), lds, st, a);
+        HIP_TRY(hipGetLastError());
+        done_bits += a.logD;
+    }
+    {
+        const int pi = plan.n_pass - 1;
+        const bool single = plan.n_pass == 1;
+        a.logD = plan.dig[pi];
+        a.O = (uint64_t)1 << done_bits;
+        a.I = 1;
+        a.n_prev = plan.n_pass - 1;
+        for (int i = 0; i < pi; i++) a.prev_log[i] = plan.dig[i];
+        rc = digit_table<F>(ctx, a.logD, inverse, &a.digit_tw);
+        if (rc) return rc;
+        a.src = single ? d.in : d.work;
+        a.dst = d.out;
+        a.src_shared = (single && d.rows_out) ? 1 : 0;
+        a.pre_on = (single && d.rows_out) ? 1 : 0;
+        a.scale_on = (single && !d.rows_out) ? 1 : 0;
+        a.scale = inv_n;
+        uint32_t threads;
+        size_t lds;
+        rc = seg_launch_dims<F>(a.logD, threads, lds);
+        if (rc) return rc;
+        const uint64_t grid = (uint64_t)d.n_cosets * d.n_seg * a.O;
+        if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
+        prof_mark(ctx, st, tag_l);
+        if (d.rows_out)
+            hipLaunchKernelGGL((k_seg_last<F, SEG_OUT_ROWS>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
+        else
+            hipLaunchKernelGGL((k_seg_last<F, SEG_OUT_SEG>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+template <class F>
+static int run_xpose(wf_ctx *ctx, hipStream_t st, bool to_seg, const void *src, void *dst, uint64_t R, uint32_t W,
+                     uint32_t total_base_cols, uint32_t n_seg) {
+    XposeArgs<F> x;
+    x.src = (const typename F::T *)src;
+    x.dst = (typename F::T *)dst;
+    x.R = R;
+    x.W = W;
+    x.total_base_cols = total_base_cols;
+    constexpr uint32_t RPB = 256 / SegCfg<F>::S;
+    const uint64_t grid = (uint64_t)n_seg * ((R + RPB - 1) / RPB);
+    if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch");
+    prof_mark(ctx, st, to_seg ? "layout.cols_to_segments" : "layout.segments_to_cols");
+    if (to_seg)
+        hipLaunchKernelGGL(k_cols_to_seg<F>, dim3((uint32_t)grid), dim3(256), 0, st, x);
+    else
+        hipLaunchKernelGGL(k_seg_to_cols<F>, dim3((uint32_t)grid), dim3(256), 0, st, x);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------- hashing + tree
 template <class F>
 static int run_hash_rows(hipStream_t st, const void *lde, uint64_t trace_elems, uint64_t n_rows, uint32_t row_width,
@@ -452,13 +627,39 @@ static typename F::T offset_elem(const wf_params *p, uint64_t &lo, uint64_t &hi)
 }
 
 // ------------------------------------------------------------------------------------------------- the path (device)
+// Scratch layout of the commitment path (context-owned, reused across calls):
+//   segA [n_seg][R][S]          transposed input / interpolation work
+//   segB [n_seg][R][S]          polynomial coefficients in segment layout (input of the evaluation)
+//   work [cosets][n_seg][R][S]  evaluation intermediate (only when R needs more than one pass)
 template <class F>
-static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, const void *d_polys, void *d_lde,
+struct PathBufs {
+    typename F::T *segA, *segB, *work;
+    uint32_t n_seg, total_base_cols;
+};
+
+template <class F>
+static int path_buffers(wf_ctx *ctx, const wf_params *p, PathBufs<F> &b) {
+    typedef typename F::T T;
+    constexpr uint32_t S = SegCfg<F>::S;
+    b.total_base_cols = p->n_cols * p->ext_degree * p->n_traces;
+    b.n_seg = (b.total_base_cols + S - 1) / S;
+    const size_t seg_vals = (size_t)b.n_seg * S << p->log2_trace_len;
+    const size_t work_vals = make_plan(p->log2_trace_len).n_pass > 1 ? seg_vals << p->log2_blowup : 0;
+    int rc = ensure(ctx->scratch, (2 * seg_vals + work_vals) * sizeof(T));
+    if (rc) return rc;
+    b.segA = (T *)ctx->scratch.p;
+    b.segB = b.segA + seg_vals;
+    b.work = b.segB + seg_vals;
+    return 0;
+}
+
+// coefficients in segB -> row-major LDE -> leaves -> tree
+template <class F>
+static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, const PathBufs<F> &b, void *d_lde,
                                void *d_leaves, void *d_nodes) {
     typedef typename F::T T;
     const uint32_t W = p->ext_degree, logR = p->log2_trace_len, logB = p->log2_blowup;
-    const uint64_t R = (uint64_t)1 << logR, Nrows = R << logB;
-    const uint32_t TC = p->n_cols * p->n_traces;
+    const uint64_t Nrows = (uint64_t)1 << (logR + logB);
     const uint64_t row_width = wf_row_width(p);
     const uint32_t base_cols = p->n_cols * W;
 
@@ -467,31 +668,25 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
     TableSet *cos;
     int rc = coset_tables<F>(ctx, logR, logB, off, olo, ohi, &cos);
     if (rc) return rc;
-
-    if (make_plan(logR).n_pass > 1) {  // size the scratch once for the larger (evaluation) use
-        rc = ensure(ctx->scratch, (size_t)TC * (R << logB) * W * sizeof(T));
-        if (rc) return rc;
-    }
     if (row_width != base_cols)  // zero the padding lanes (segments.rs:65-72)
         HIP_TRY(hipMemsetAsync(d_lde, 0, (size_t)p->n_traces * Nrows * row_width * sizeof(T), st));
 
-    XformDesc<F> d;
+    SegDesc<F> d;
     memset(&d, 0, sizeof(d));
-    d.src = (const T *)d_polys;
-    d.dst = (T *)d_lde;
+    d.in = b.segB;
+    d.work = b.work;
+    d.out = (T *)d_lde;
     d.logN = logR;
-    d.W = W;
-    d.TC = TC;
-    d.n_cols = p->n_cols;
+    d.n_seg = b.n_seg;
     d.n_cosets = 1u << logB;
-    d.log_blowup = logB;
-    d.inverse = false;
-    d.out_mode = OUT_ROWS;
-    d.scale_mode = SCALE_NONE;
+    d.rows_out = true;
     d.pre = cos;
+    d.base_cols = base_cols;
+    d.total_base_cols = b.total_base_cols;
+    d.log_blowup = logB;
     d.row_width = row_width;
     d.trace_lde_elems = Nrows * row_width;
-    rc = run_transform<F, K_EVAL>(ctx, st, d);
+    rc = run_seg_transform<F>(ctx, st, d);
     if (rc) return rc;
 
     if (d_leaves) {
@@ -508,36 +703,46 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
     return 0;
 }
 
-template <class F>
-static int interpolate_columns(wf_ctx *ctx, hipStream_t st, const wf_params *p, const void *d_trace, void *d_polys) {
-    typedef typename F::T T;
-    XformDesc<F> d;
-    memset(&d, 0, sizeof(d));
-    d.src = (const T *)d_trace;
-    d.dst = (T *)d_polys;
-    d.logN = p->log2_trace_len;
-    d.W = p->ext_degree;
-    d.TC = p->n_cols * p->n_traces;
-    d.n_cols = p->n_cols;
-    d.n_cosets = 1;
-    d.inverse = true;
-    d.out_mode = OUT_COLS;
-    d.scale_mode = SCALE_CONST;
-    d.scale = f_inv<F>(F::from_u128_canonical((u128)1 << p->log2_trace_len));  // 1/n, fft/serial.rs:70
-    return run_transform<F, K_INTERP>(ctx, st, d);
-}
-
+// Prover::build_trace_commitment on device buffers
 template <class F>
 static int trace_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_trace, void *d_polys, void *d_lde,
                             void *d_leaves, void *d_nodes, hipStream_t st) {
-    int rc;
-    if (make_plan(p->log2_trace_len).n_pass > 1) {  // one allocation covers interpolation and evaluation
-        const size_t vals = ((size_t)p->n_cols * p->n_traces * p->ext_degree) << (p->log2_trace_len + p->log2_blowup);
-        if ((rc = ensure(ctx->scratch, vals * sizeof(typename F::T)))) return rc;
-    }
-    rc = interpolate_columns<F>(ctx, st, p, d_trace, d_polys);
+    PathBufs<F> b;
+    int rc = path_buffers<F>(ctx, p, b);
     if (rc) return rc;
-    return evaluate_and_commit<F>(ctx, st, p, d_polys, d_lde, d_leaves, d_nodes);
+    const uint64_t R = (uint64_t)1 << p->log2_trace_len;
+    // columns -> segments
+    rc = run_xpose<F>(ctx, st, true, d_trace, b.segA, R, p->ext_degree, b.total_base_cols, b.n_seg);
+    if (rc) return rc;
+    // ColMatrix::interpolate_columns (col_matrix.rs:196-206)
+    SegDesc<F> d;
+    memset(&d, 0, sizeof(d));
+    d.in = b.segA;
+    d.work = b.segA;  // strided passes run in place
+    d.out = b.segB;
+    d.logN = p->log2_trace_len;
+    d.n_seg = b.n_seg;
+    d.n_cosets = 1;
+    d.rows_out = false;
+    rc = run_seg_transform<F>(ctx, st, d);
+    if (rc) return rc;
+    // the caller's copy of the polynomials, column layout
+    rc = run_xpose<F>(ctx, st, false, b.segB, d_polys, R, p->ext_degree, b.total_base_cols, b.n_seg);
+    if (rc) return rc;
+    return evaluate_and_commit<F>(ctx, st, p, b, d_lde, d_leaves, d_nodes);
+}
+
+// Prover::build_constraint_commitment on device buffers
+template <class F>
+static int constraint_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_polys, void *d_lde, void *d_leaves,
+                                 void *d_nodes, hipStream_t st) {
+    PathBufs<F> b;
+    int rc = path_buffers<F>(ctx, p, b);
+    if (rc) return rc;
+    rc = run_xpose<F>(ctx, st, true, d_polys, b.segB, (uint64_t)1 << p->log2_trace_len, p->ext_degree,
+                      b.total_base_cols, b.n_seg);
+    if (rc) return rc;
+    return evaluate_and_commit<F>(ctx, st, p, b, d_lde, d_leaves, d_nodes);
 }
 
 // ------------------------------------------------------------------------------------------------- C ABI
@@ -644,8 +849,8 @@ int wf_constraint_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_poly
     if (!d_polys || !d_lde) return fail(WF_ERR_ARG, "null device buffer");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    if (p->field == WF_FIELD_F64) return evaluate_and_commit<F64>(ctx, st, p, d_polys, d_lde, d_leaves, d_nodes);
-    return evaluate_and_commit<F128>(ctx, st, p, d_polys, d_lde, d_leaves, d_nodes);
+    if (p->field == WF_FIELD_F64) return constraint_commit_dev<F64>(ctx, p, d_polys, d_lde, d_leaves, d_nodes, st);
+    return constraint_commit_dev<F128>(ctx, p, d_polys, d_lde, d_leaves, d_nodes, st);
 }
 
 // host-buffer form -------------------------------------------------------------------------------------------------
