@@ -41,21 +41,41 @@ struct F64 {
     }
     static WF_HD T mul(T a, T b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        uint64_t lo = a * b, hi = __umul64hi(a, b);
+        // 32-bit schoolbook: four v_mad_u64_u32 share the partial products (gfx950 has no 64-bit multiplier)
+        const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+        const uint64_t p00 = (uint64_t)a0 * b0;
+        const uint64_t p01 = (uint64_t)a0 * b1 + (p00 >> 32);
+        const uint64_t p10 = (uint64_t)a1 * b0 + (uint32_t)p01;
+        const uint64_t hi = (uint64_t)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+        const uint64_t lo = (p10 << 32) | (uint32_t)p00;
 #else
         u128 x = (u128)a * (u128)b;
         uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
 #endif
         return mont_reduce(lo, hi);
     }
+    // a + b: the sum wraps at 2^64 or lands in [p, 2^64) -> add 2^32 - 1 (= -p mod 2^64); both cases end in [0, p)
     static WF_HD T add(T a, T b) {
-        uint64_t t = P - b;
-        uint64_t r = a - t;
-        return a < t ? r - 0xFFFFFFFFull : r;
+        uint64_t r = a + b;
+        const bool fix = (r < a) | (r >= P);
+        return r + (fix ? 0xFFFFFFFFull : 0ull);
     }
     static WF_HD T sub(T a, T b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // explicit 32-bit borrow chain (5 VALU): r = a - b, then r -= (2^32 - 1) if it borrowed
+        const uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
+        uint32_t rl, t, rh;
+        const uint32_t b1 = __builtin_sub_overflow(al, bl, &rl);
+        const uint32_t b2 = __builtin_sub_overflow(ah, bh, &t);
+        const uint32_t b3 = __builtin_sub_overflow(t, b1, &rh);
+        const uint32_t m = 0u - (b2 | b3);
+        uint32_t r2l;
+        const uint32_t c1 = __builtin_sub_overflow(rl, m, &r2l);
+        return ((uint64_t)(rh - c1) << 32) | r2l;
+#else
         uint64_t r = a - b;
         return a < b ? r - 0xFFFFFFFFull : r;
+#endif
     }
     static WF_HD T from_canonical(uint64_t v) { return mul(v % P, R2); }
     static WF_HD uint64_t to_canonical(T x) { return mont_reduce(x, 0); }

@@ -383,6 +383,16 @@ __global__ void __launch_bounds__(256) k_hash_rows(HashArgs<F> a) {
         const uint32_t epr = a.epr;
         auto load = [&](uint64_t bi, uint32_t(&m)[16]) {
             const uint32_t e0 = (uint32_t)bi * EPB;
+            if (e0 + EPB <= epr) {  // whole 64-byte block: rows are 64-byte aligned, four 16-byte loads
+                const uint4 *q = reinterpret_cast<const uint4 *>(row + e0);
+                T ev[EPB];
+                uint4 *dstv = reinterpret_cast<uint4 *>(ev);
+#pragma unroll
+                for (uint32_t i = 0; i < 4; i++) dstv[i] = q[i];
+#pragma unroll
+                for (uint32_t i = 0; i < EPB; i++) elem_words<F>(ev[i], &m[i * WPE]);
+                return;
+            }
 #pragma unroll
             for (uint32_t i = 0; i < EPB; i++) {
                 if (e0 + i < epr) {
@@ -465,6 +475,24 @@ __global__ void __launch_bounds__(256) k_merkle_subtree(const uint32_t *__restri
             for (int i = 0; i < 8; i++) sh[tid * 8 + i] = cv[i];
         }
     }
+}
+
+// One Merkle level per launch (used while a level still fills the chip): parents[i] = merge(children[2i], children[2i+1]).
+__global__ void __launch_bounds__(256) k_merkle_level(const uint32_t *__restrict__ children,
+                                                      uint32_t *__restrict__ parents, uint64_t n_parents) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_parents) return;
+    const uint4 *src = reinterpret_cast<const uint4 *>(children + i * 16);
+    uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+    uint32_t m[16], cv[8];
+    m[0] = q0.x; m[1] = q0.y; m[2] = q0.z; m[3] = q0.w;
+    m[4] = q1.x; m[5] = q1.y; m[6] = q1.z; m[7] = q1.w;
+    m[8] = q2.x; m[9] = q2.y; m[10] = q2.z; m[11] = q2.w;
+    m[12] = q3.x; m[13] = q3.y; m[14] = q3.z; m[15] = q3.w;
+    b3::merge(m, cv);
+    uint4 *dst = reinterpret_cast<uint4 *>(parents + i * 8);
+    dst[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+    dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
 }
 
 // Hash contiguous rows of `row_elems` elements (wf_hash_rows building block) is k_hash_rows with n_traces = 1.

@@ -580,16 +580,23 @@ static int run_merkle(hipStream_t st, const void *leaves, uint64_t n_leaves, voi
     const uint32_t *children = (const uint32_t *)leaves;
     uint64_t n_children = n_leaves;
     while (n_children > 1) {
-        uint32_t total_levels = 0;
-        for (uint64_t t = n_children; t > 1; t >>= 1) total_levels++;
-        const uint32_t levels = std::min<uint32_t>(9, total_levels);
         const uint64_t n_par = n_children >> 1;
         const uint32_t threads = 256;
         const uint64_t grid = (n_par + threads - 1) / threads;
-        hipLaunchKernelGGL(k_merkle_subtree, dim3((uint32_t)grid), dim3(threads), 0, st, children,
-                           (uint32_t *)nodes, n_children, levels);
-        HIP_TRY(hipGetLastError());
-        n_children >>= levels;
+        if (n_par >= (1u << 15)) {  // a level that still fills the chip: one lane per node, one level per launch
+            hipLaunchKernelGGL(k_merkle_level, dim3((uint32_t)grid), dim3(threads), 0, st, children,
+                               (uint32_t *)nodes + n_par * 8, n_par);
+            HIP_TRY(hipGetLastError());
+            n_children = n_par;
+        } else {                    // the top of the tree: up to 9 levels per launch through LDS
+            uint32_t total_levels = 0;
+            for (uint64_t t = n_children; t > 1; t >>= 1) total_levels++;
+            const uint32_t levels = std::min<uint32_t>(9, total_levels);
+            hipLaunchKernelGGL(k_merkle_subtree, dim3((uint32_t)grid), dim3(threads), 0, st, children,
+                               (uint32_t *)nodes, n_children, levels);
+            HIP_TRY(hipGetLastError());
+            n_children >>= levels;
+        }
         children = (const uint32_t *)nodes + n_children * 8;  // that level lives at nodes[n .. 2n)
     }
     return 0;
