@@ -1,0 +1,314 @@
+// winterfell_hip.hpp -- C++ host-side mirror of the reference's interface for the LDE + commitment path, layered on
+// the C ABI (wf_lde.h).  The reference is Rust; this image has no Rust toolchain, so the types a winter-prover user
+// touches on this path are restated here in C++ with the same names, argument meaning and error behaviour
+// (a violated precondition throws where the reference panics / asserts).
+//
+//   ColMatrix<E>            prover/src/matrix/col_matrix.rs:31-130
+//   RowMatrix<E>            prover/src/matrix/row_matrix.rs:31-170
+//   MerkleTree              crypto/src/merkle/mod.rs:87-181 (nodes/leaves layout, root, depth, prove, verify)
+//   StarkDomain             prover/src/domain.rs:13-155 (the parameters the path reads)
+//   CompositionPoly<E>      prover/src/constraints/composition_poly.rs:21-98
+//   ConstraintCommitment<E> prover/src/constraints/commitment.rs:21-69
+//   Prover                  prover/src/lib.rs:615-715 (build_trace_commitment, build_constraint_commitment)
+//
+// Header-only; link with -lwf_lde.  Elements are the reference's in-memory representations:
+//   F64Element  = Montgomery u64 (math/src/field/f64/mod.rs:48-53)   F128Element = canonical u128
+//   QuadExtension<B> / CubeExtension<B> = consecutive base elements (extensions/quadratic.rs:26-28)
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "wf_lde.h"
+
+namespace winterfell {
+
+struct F64Element {
+    uint64_t inner;  // Montgomery form, as BaseElement::inner()
+    static constexpr uint32_t FIELD = WF_FIELD_F64;
+    static constexpr uint32_t EXTENSION_DEGREE = 1;
+    typedef F64Element BaseField;
+    bool operator==(const F64Element &o) const { return inner == o.inner; }
+};
+struct F128Element {
+    uint64_t lo, hi;  // canonical u128, little endian
+    static constexpr uint32_t FIELD = WF_FIELD_F128;
+    static constexpr uint32_t EXTENSION_DEGREE = 1;
+    typedef F128Element BaseField;
+    bool operator==(const F128Element &o) const { return lo == o.lo && hi == o.hi; }
+};
+template <class B>
+struct QuadExtension {
+    B c[2];
+    static constexpr uint32_t FIELD = B::FIELD;
+    static constexpr uint32_t EXTENSION_DEGREE = 2;
+    typedef B BaseField;
+    bool operator==(const QuadExtension &o) const { return c[0] == o.c[0] && c[1] == o.c[1]; }
+};
+template <class B>
+struct CubeExtension {
+    B c[3];
+    static constexpr uint32_t FIELD = B::FIELD;
+    static constexpr uint32_t EXTENSION_DEGREE = 3;
+    typedef B BaseField;
+    bool operator==(const CubeExtension &o) const { return c[0] == o.c[0] && c[1] == o.c[1] && c[2] == o.c[2]; }
+};
+
+typedef std::array<uint8_t, 32> Digest;  // ByteDigest<32>, crypto/src/hash/mod.rs:84-85
+
+class WfError : public std::runtime_error {
+  public:
+    WfError(int code, const std::string &what) : std::runtime_error(what), code(code) {}
+    int code;
+};
+inline void wf_check(int rc) {
+    if (rc != 0) throw WfError(rc, std::string("wf_lde: ") + wf_last_error());
+}
+
+// ------------------------------------------------------------------------------------------------- ColMatrix
+template <class E>
+class ColMatrix {
+  public:
+    // ColMatrix::new (col_matrix.rs:46-60): at least one column, all of equal power-of-two length > 1
+    explicit ColMatrix(std::vector<std::vector<E>> columns) : columns_(std::move(columns)) {
+        if (columns_.empty()) throw std::invalid_argument("a matrix must contain at least one column");
+        const size_t n = columns_[0].size();
+        if (n < 2 || (n & (n - 1))) throw std::invalid_argument("number of rows must be a power of two greater than 1");
+        for (auto &c : columns_)
+            if (c.size() != n) throw std::invalid_argument("all columns must have the same length");
+    }
+    size_t num_cols() const { return columns_.size(); }
+    size_t num_base_cols() const { return columns_.size() * E::EXTENSION_DEGREE; }
+    size_t num_rows() const { return columns_[0].size(); }
+    const std::vector<E> &get_column(size_t i) const { return columns_.at(i); }
+    E get(size_t col, size_t row) const { return columns_.at(col).at(row); }
+    const std::vector<std::vector<E>> &columns() const { return columns_; }
+
+  private:
+    std::vector<std::vector<E>> columns_;
+};
+
+// ------------------------------------------------------------------------------------------------- RowMatrix
+template <class E>
+class RowMatrix {
+  public:
+    typedef typename E::BaseField B;
+    // the raw constructor the reference lacks
+    static RowMatrix from_raw_parts(std::vector<B> data, size_t row_width, size_t elements_per_row) {
+        if (row_width == 0 || elements_per_row > row_width || data.size() % row_width)
+            throw std::invalid_argument("invalid RowMatrix dimensions");
+        RowMatrix m;
+        m.data_ = std::move(data);
+        m.row_width_ = row_width;
+        m.elements_per_row_ = elements_per_row;
+        return m;
+    }
+    size_t num_cols() const { return elements_per_row_ / E::EXTENSION_DEGREE; }  // row_matrix.rs:139-141
+    size_t num_rows() const { return data_.size() / row_width_; }                // :144-146
+    // RowMatrix::row (row_matrix.rs:160-164)
+    const E *row(size_t i) const {
+        if (i >= num_rows()) throw std::out_of_range("row index out of bounds");
+        return reinterpret_cast<const E *>(data_.data() + i * row_width_);
+    }
+    E get(size_t col, size_t row_idx) const { return row(row_idx)[col]; }
+    const std::vector<B> &data() const { return data_; }
+    size_t row_width() const { return row_width_; }
+    size_t elements_per_row() const { return elements_per_row_; }
+
+  private:
+    std::vector<B> data_;
+    size_t row_width_ = 0, elements_per_row_ = 0;
+};
+
+// ------------------------------------------------------------------------------------------------- MerkleTree
+class MerkleTree {
+  public:
+    // MerkleTree::from_raw_parts (merkle/mod.rs:149-161)
+    static MerkleTree from_raw_parts(std::vector<Digest> nodes, std::vector<Digest> leaves) {
+        if (leaves.size() < 2) throw std::invalid_argument("a tree must have at least 2 leaves");
+        if (leaves.size() & (leaves.size() - 1)) throw std::invalid_argument("number of leaves must be a power of two");
+        if (nodes.size() != leaves.size()) throw std::invalid_argument("nodes and leaves must have the same length");
+        MerkleTree t;
+        t.nodes_ = std::move(nodes);
+        t.leaves_ = std::move(leaves);
+        return t;
+    }
+    // MerkleTree::new (merkle/mod.rs:117-136) on the GPU
+    static MerkleTree from_leaves(wf_ctx *ctx, std::vector<Digest> leaves) {
+        std::vector<Digest> nodes(leaves.size());
+        wf_check(wf_merkle_build(ctx, leaves.empty() ? nullptr : leaves[0].data(), leaves.size(),
+                                 nodes.empty() ? nullptr : nodes[0].data()));
+        return from_raw_parts(std::move(nodes), std::move(leaves));
+    }
+    const Digest &root() const { return nodes_[1]; }  // :167
+    size_t depth() const {                            // :174-176
+        size_t d = 0;
+        while (((size_t)1 << d) < leaves_.size()) d++;
+        return d;
+    }
+    const std::vector<Digest> &leaves() const { return leaves_; }
+    const std::vector<Digest> &nodes() const { return nodes_; }
+    // MerkleTree::prove (merkle/mod.rs:192-212): [leaf, sibling leaf, sibling nodes bottom-up]
+    std::vector<Digest> prove(size_t index) const {
+        if (index >= leaves_.size()) throw std::out_of_range("leaf index out of bounds");
+        std::vector<Digest> proof{leaves_[index], leaves_[index ^ 1]};
+        size_t i = (index + nodes_.size()) >> 1;
+        while (i > 1) {
+            proof.push_back(nodes_[i ^ 1]);
+            i >>= 1;
+        }
+        return proof;
+    }
+
+  private:
+    std::vector<Digest> nodes_, leaves_;
+};
+
+// ------------------------------------------------------------------------------------------------- StarkDomain
+class StarkDomain {
+  public:
+    // the parameters of StarkDomain::new(air) (domain.rs:38-52) that the path reads; offset is the canonical
+    // integer of ProofOptions::domain_offset() = B::GENERATOR (air/src/options.rs:199-201)
+    StarkDomain(size_t trace_length, size_t blowup, unsigned __int128 domain_offset)
+        : trace_length_(trace_length), blowup_(blowup), offset_(domain_offset) {}
+    size_t trace_length() const { return trace_length_; }
+    size_t trace_to_lde_blowup() const { return blowup_; }
+    size_t lde_domain_size() const { return trace_length_ * blowup_; }
+    unsigned __int128 offset() const { return offset_; }
+
+  private:
+    size_t trace_length_, blowup_;
+    unsigned __int128 offset_;
+};
+
+// ------------------------------------------------------------------------------------------------- composition poly
+template <class E>
+class CompositionPoly {
+  public:
+    // CompositionPoly::new (composition_poly.rs:21-41): split the coefficient vector into `num_columns` columns of
+    // `trace_length` coefficients each
+    CompositionPoly(const std::vector<E> &coefficients, size_t trace_length, size_t num_columns)
+        : data_(split(coefficients, trace_length, num_columns)) {}
+    const ColMatrix<E> &data() const { return data_; }
+    size_t num_columns() const { return data_.num_cols(); }
+    size_t column_len() const { return data_.num_rows(); }
+
+  private:
+    static ColMatrix<E> split(const std::vector<E> &c, size_t len, size_t cols) {
+        if (c.size() != len * cols) throw std::invalid_argument("coefficient vector length mismatch");
+        std::vector<std::vector<E>> out;
+        for (size_t i = 0; i < cols; i++) out.emplace_back(c.begin() + i * len, c.begin() + (i + 1) * len);
+        return ColMatrix<E>(std::move(out));
+    }
+    ColMatrix<E> data_;
+};
+
+template <class E>
+class ConstraintCommitment {
+  public:
+    // ConstraintCommitment::new (constraints/commitment.rs:29-39)
+    ConstraintCommitment(RowMatrix<E> evaluations, MerkleTree tree)
+        : evaluations_(std::move(evaluations)), tree_(std::move(tree)) {
+        if (evaluations_.num_rows() != tree_.leaves().size())
+            throw std::invalid_argument("number of rows in constraint evaluation matrix must be the same as number of leaves");
+    }
+    const Digest &root() const { return tree_.root(); }
+    size_t tree_depth() const { return tree_.depth(); }
+    const RowMatrix<E> &evaluations() const { return evaluations_; }
+    const MerkleTree &tree() const { return tree_; }
+
+  private:
+    RowMatrix<E> evaluations_;
+    MerkleTree tree_;
+};
+
+// ------------------------------------------------------------------------------------------------- Prover
+inline unsigned ilog2_exact(size_t v, const char *what) {
+    if (v == 0 || (v & (v - 1))) throw std::invalid_argument(std::string(what) + " must be a power of two");
+    unsigned l = 0;
+    while (((size_t)1 << l) < v) l++;
+    return l;
+}
+
+class Prover {
+  public:
+    explicit Prover(int device = 0) { wf_check(wf_ctx_create(device, &ctx_)); }
+    ~Prover() { wf_ctx_destroy(ctx_); }
+    Prover(const Prover &) = delete;
+    Prover &operator=(const Prover &) = delete;
+    wf_ctx *context() const { return ctx_; }
+
+    // Prover::build_trace_commitment (prover/src/lib.rs:615-670)
+    template <class E>
+    std::tuple<std::vector<RowMatrix<E>>, MerkleTree, std::vector<ColMatrix<E>>> build_trace_commitment(
+        const std::vector<const ColMatrix<E> *> &traces, const StarkDomain &domain) const {
+        if (traces.empty()) throw std::invalid_argument("at least one trace is required");
+        const size_t rows = traces[0]->num_rows(), cols = traces[0]->num_cols();
+        wf_params p = params<E>(rows, cols, traces.size(), domain);
+        wf_check(wf_params_check(&p, 0));
+        std::vector<const void *> in;
+        for (auto t : traces) {
+            if (t->num_rows() != rows || t->num_cols() != cols) throw std::invalid_argument("all traces must have the same shape");
+            for (size_t c = 0; c < cols; c++) in.push_back(t->get_column(c).data());
+        }
+        const size_t lde_rows = domain.lde_domain_size(), rw = wf_row_width(&p);
+        std::vector<std::vector<std::vector<E>>> polys(traces.size(), std::vector<std::vector<E>>(cols, std::vector<E>(rows)));
+        std::vector<std::vector<typename E::BaseField>> ldes(traces.size(), std::vector<typename E::BaseField>(lde_rows * rw));
+        std::vector<Digest> leaves(lde_rows), nodes(lde_rows);
+        std::vector<void *> polys_out, lde_out;
+        for (auto &t : polys)
+            for (auto &c : t) polys_out.push_back(c.data());
+        for (auto &l : ldes) lde_out.push_back(l.data());
+        wf_check(wf_trace_commit(ctx_, &p, in.data(), polys_out.data(), lde_out.data(), leaves[0].data(), nodes[0].data(),
+                                 nullptr));
+        std::vector<RowMatrix<E>> trace_ldes;
+        for (auto &l : ldes) trace_ldes.push_back(RowMatrix<E>::from_raw_parts(std::move(l), rw, cols * E::EXTENSION_DEGREE));
+        std::vector<ColMatrix<E>> trace_polys;
+        for (auto &t : polys) trace_polys.emplace_back(std::move(t));
+        return {std::move(trace_ldes), MerkleTree::from_raw_parts(std::move(nodes), std::move(leaves)), std::move(trace_polys)};
+    }
+
+    // Prover::build_constraint_commitment (prover/src/lib.rs:680-715)
+    template <class E>
+    ConstraintCommitment<E> build_constraint_commitment(const CompositionPoly<E> &composition_poly,
+                                                        const StarkDomain &domain) const {
+        const ColMatrix<E> &data = composition_poly.data();
+        wf_params p = params<E>(data.num_rows(), data.num_cols(), 1, domain);
+        wf_check(wf_params_check(&p, 1));
+        std::vector<const void *> in;
+        for (size_t c = 0; c < data.num_cols(); c++) in.push_back(data.get_column(c).data());
+        const size_t lde_rows = domain.lde_domain_size(), rw = wf_row_width(&p);
+        std::vector<typename E::BaseField> lde(lde_rows * rw);
+        std::vector<Digest> leaves(lde_rows), nodes(lde_rows);
+        wf_check(wf_constraint_commit(ctx_, &p, in.data(), lde.data(), leaves[0].data(), nodes[0].data(), nullptr));
+        return ConstraintCommitment<E>(RowMatrix<E>::from_raw_parts(std::move(lde), rw, data.num_base_cols()),
+                                       MerkleTree::from_raw_parts(std::move(nodes), std::move(leaves)));
+    }
+
+  private:
+    template <class E>
+    static wf_params params(size_t rows, size_t cols, size_t n_traces, const StarkDomain &domain) {
+        if (rows != domain.trace_length()) throw std::invalid_argument("matrix length does not match the domain");
+        wf_params p;
+        std::memset(&p, 0, sizeof(p));
+        p.field = E::FIELD;
+        p.ext_degree = E::EXTENSION_DEGREE;
+        p.log2_trace_len = ilog2_exact(rows, "trace length");
+        p.log2_blowup = ilog2_exact(domain.trace_to_lde_blowup(), "blowup factor");
+        p.n_cols = (uint32_t)cols;
+        p.n_traces = (uint32_t)n_traces;
+        p.digest_bytes = 32;
+        unsigned __int128 off = domain.offset();
+        std::memcpy(p.domain_offset, &off, 16);
+        return p;
+    }
+    wf_ctx *ctx_ = nullptr;
+};
+
+}  // namespace winterfell

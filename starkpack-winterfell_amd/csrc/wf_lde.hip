@@ -218,9 +218,10 @@ struct Plan {
     uint32_t dig[4];
 };
 
-static Plan make_plan(uint32_t L) {
+// digits of at most `max_digit` bits (what one work-group can hold in LDS: 11 for f64, 10 for f128), balanced
+static Plan make_plan(uint32_t L, uint32_t max_digit) {
     Plan p;
-    p.n_pass = L <= 10 ? 1 : (L <= 22 ? 2 : (L <= 33 ? 3 : 4));
+    p.n_pass = L <= 10 ? 1 : (int)((L + max_digit - 1) / max_digit);
     uint32_t base = L / p.n_pass, rem = L % p.n_pass;
     for (int i = 0; i < p.n_pass; i++) p.dig[i] = base + (i < (int)rem ? 1 : 0);
     return p;
@@ -279,7 +280,7 @@ static int run_transform(wf_ctx *ctx, hipStream_t st, const XformDesc<F> &d) {
     TableSet *tw;
     int rc = root_tables<F>(ctx, d.logN, d.inverse, &tw);
     if (rc) return rc;
-    const Plan plan = make_plan(d.logN);
+    const Plan plan = make_plan(d.logN, F::BYTES == 8 ? 11 : 10);
     const uint64_t N = (uint64_t)1 << d.logN;
 
     NttArgs<F> a;
@@ -447,7 +448,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
     TableSet *tw;
     int rc = root_tables<F>(ctx, d.logN, inverse, &tw);
     if (rc) return rc;
-    const Plan plan = make_plan(d.logN);
+    const Plan plan = make_plan(d.logN, F::BYTES == 8 ? 11 : 10);
     const uint64_t N = (uint64_t)1 << d.logN;
 
     SegArgs<F> a;
@@ -651,7 +652,7 @@ static int path_buffers(wf_ctx *ctx, const wf_params *p, PathBufs<F> &b) {
     b.total_base_cols = p->n_cols * p->ext_degree * p->n_traces;
     b.n_seg = (b.total_base_cols + S - 1) / S;
     const size_t seg_vals = (size_t)b.n_seg * S << p->log2_trace_len;
-    const size_t work_vals = make_plan(p->log2_trace_len).n_pass > 1 ? seg_vals << p->log2_blowup : 0;
+    const size_t work_vals = make_plan(p->log2_trace_len, F::BYTES == 8 ? 11 : 10).n_pass > 1 ? seg_vals << p->log2_blowup : 0;
     int rc = ensure(ctx->scratch, (2 * seg_vals + work_vals) * sizeof(T));
     if (rc) return rc;
     b.segA = (T *)ctx->scratch.p;

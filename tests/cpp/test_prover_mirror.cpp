@@ -1,0 +1,212 @@
+// C++ parity test of the host-side mirror (include/winterfell_hip.hpp) -- reads like the reference's own tests:
+//   extend_trace_table / commit_trace_table   prover/src/trace/tests.rs:42-128
+//   build_fib_trace                            prover/src/tests/mod.rs:17-29
+// The oracle (oracle/liboracle.so) is linked only as the checker (hash_elements, merkle, naive eval_many).
+// Build + run: tests/test_gpu_cpp_mirror.py (needs a GPU).
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../include/winterfell_hip.hpp"
+#include "../../oracle/oracle.h"
+
+using namespace winterfell;
+typedef unsigned __int128 u128;
+
+#define EXPECT(cond)                                                        \
+    do {                                                                    \
+        if (!(cond)) {                                                      \
+            std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);   \
+            std::exit(1);                                                   \
+        }                                                                   \
+    } while (0)
+
+static const u128 P128 = (((u128)0xFFFFFFFFFFFFFFFFull) << 64) + (u128)0xFFFFD30000000001ull;
+static F128Element f128(u128 v) { return F128Element{(uint64_t)v, (uint64_t)(v >> 64)}; }
+static u128 val(F128Element e) { return ((u128)e.hi << 64) | e.lo; }
+
+// prover/src/tests/mod.rs:17-29 (length = 2 * rows)
+static ColMatrix<F128Element> build_fib_trace(size_t length) {
+    std::vector<F128Element> r1{f128(1)}, r2{f128(1)};
+    for (size_t i = 0; i + 1 < length / 2; i++) {
+        u128 a = val(r1[i]), b = val(r2[i]);
+        r1.push_back(f128((a + b) % P128));
+        r2.push_back(f128((a + 2 * b) % P128));
+    }
+    return ColMatrix<F128Element>({r1, r2});
+}
+
+static void extend_and_commit_trace_table() {
+    const size_t trace_length = 8, blowup = 8;  // MockAir::with_trace_length(8): ProofOptions blowup 8
+    ColMatrix<F128Element> trace = build_fib_trace(trace_length * 2);
+    StarkDomain domain(trace_length, blowup, 3);  // f128 GENERATOR
+    Prover prover(0);
+    auto [ldes, tree, polys] = prover.build_trace_commitment<F128Element>({&trace}, domain);
+
+    EXPECT(trace.get_column(0)[7] == f128(610) && trace.get_column(1)[7] == f128(987));  // new_trace_table
+    EXPECT(ldes.size() == 1 && polys.size() == 1);
+    EXPECT(ldes[0].num_cols() == 2 && ldes[0].num_rows() == 64 && ldes[0].row_width() == 8);
+
+    // trace polynomials evaluate to the Fibonacci trace over the trace domain (tests.rs:62-80)
+    u128 root_b;
+    orc_f128_get_root_of_unity(3, &root_b);
+    std::vector<u128> dom(trace_length), out(trace_length);
+    u128 acc = 1, one = 1;
+    for (size_t i = 0; i < trace_length; i++) {
+        dom[i] = acc;
+        orc_f128_mul(&acc, &root_b, &acc);
+    }
+    (void)one;
+    for (size_t c = 0; c < 2; c++) {
+        orc_f128_eval_many(reinterpret_cast<const u128 *>(polys[0].get_column(c).data()), trace_length, dom.data(),
+                           trace_length, out.data());
+        for (size_t i = 0; i < trace_length; i++) EXPECT(out[i] == val(trace.get_column(c)[i]));
+    }
+    // LDE columns are the polynomials on the shifted domain (tests.rs:82-92, via direct evaluation)
+    u128 g, x = 3;
+    orc_f128_get_root_of_unity(6, &g);
+    for (size_t j = 0; j < 64; j++) {
+        for (size_t c = 0; c < 2; c++) {
+            u128 y;
+            orc_f128_eval_many(reinterpret_cast<const u128 *>(polys[0].get_column(c).data()), trace_length, &x, 1, &y);
+            EXPECT(y == val(ldes[0].get(c, j)));
+        }
+        for (size_t l = 2; l < 8; l++) EXPECT(val(ldes[0].row(j)[l]) == 0);  // padding lanes
+        orc_f128_mul(&x, &g, &x);
+    }
+    // commit_trace_table (tests.rs:95-128): tree over manually hashed rows
+    std::vector<Digest> hashed(64), nodes(64);
+    for (size_t i = 0; i < 64; i++) {
+        F128Element state[2] = {ldes[0].get(0, i), ldes[0].get(1, i)};
+        orc_hash_elements(ORC_FIELD_F128, state, 2, hashed[i].data());
+    }
+    EXPECT(orc_build_merkle_nodes(hashed[0].data(), 64, nodes[0].data(), 1) == 0);
+    EXPECT(nodes[1] == tree.root());
+    EXPECT(hashed == tree.leaves() && nodes == tree.nodes());
+    EXPECT(tree.depth() == 6);
+    // MerkleTree::prove / verify round trip (merkle/tests.rs:94-131 shape)
+    for (size_t idx : {0u, 1u, 37u, 63u}) {
+        auto proof = tree.prove(idx);
+        EXPECT(proof.size() == 7);
+        Digest v;
+        size_t r = idx & 1;
+        orc_merge(proof[r].data(), proof[1 - r].data(), v.data());
+        size_t index = (idx + 64) >> 1;
+        for (size_t k = 2; k < proof.size(); k++) {
+            if ((index & 1) == 0) orc_merge(v.data(), proof[k].data(), v.data());
+            else orc_merge(proof[k].data(), v.data(), v.data());
+            index >>= 1;
+        }
+        EXPECT(v == tree.root());
+    }
+    std::printf("extend_and_commit_trace_table ok\n");
+}
+
+static void starkpack_two_traces_f64() {
+    // two packed traces under one tree: leaf = hash(row of trace 0 || row of trace 1) (row_matrix.rs:204-238)
+    const size_t n = 32, blowup = 4, cols = 3;
+    std::vector<ColMatrix<F64Element>> traces;
+    uint64_t s = 12345;
+    for (int t = 0; t < 2; t++) {
+        std::vector<std::vector<F64Element>> c(cols, std::vector<F64Element>(n));
+        for (auto &col : c)
+            for (auto &e : col) {
+                s = s * 6364136223846793005ull + 1442695040888963407ull;
+                e.inner = orc_f64_new(s >> 3);
+            }
+        traces.emplace_back(c);
+    }
+    StarkDomain domain(n, blowup, 7);
+    Prover prover(0);
+    auto [ldes, tree, polys] = prover.build_trace_commitment<F64Element>({&traces[0], &traces[1]}, domain);
+    EXPECT(ldes.size() == 2 && polys.size() == 2);
+    std::vector<Digest> hashed(n * blowup), nodes(n * blowup);
+    for (size_t i = 0; i < n * blowup; i++) {
+        uint64_t comb[2 * cols];
+        for (int t = 0; t < 2; t++)
+            for (size_t c = 0; c < cols; c++) comb[t * cols + c] = ldes[t].get(c, i).inner;
+        orc_hash_elements(ORC_FIELD_F64, comb, 2 * cols, hashed[i].data());
+    }
+    orc_build_merkle_nodes(hashed[0].data(), hashed.size(), nodes[0].data(), 1);
+    EXPECT(nodes[1] == tree.root());
+    // the whole thing against the oracle's path
+    std::vector<const void *> in;
+    std::vector<std::vector<uint64_t>> po(2 * cols, std::vector<uint64_t>(n)), lo(2, std::vector<uint64_t>(n * blowup * 8));
+    std::vector<void *> pout, lout;
+    for (auto &t : traces)
+        for (size_t c = 0; c < cols; c++) in.push_back(t.get_column(c).data());
+    for (auto &v : po) pout.push_back(v.data());
+    for (auto &v : lo) lout.push_back(v.data());
+    std::vector<Digest> ol(n * blowup), on(n * blowup);
+    uint8_t off[16] = {7};
+    EXPECT(orc_build_trace_commitment(ORC_FIELD_F64, 1, 5, 2, cols, 2, off, in.data(), pout.data(), lout.data(),
+                                      ol[0].data(), on[0].data(), 1) == 0);
+    EXPECT(on[1] == tree.root());
+    for (int t = 0; t < 2; t++)
+        EXPECT(std::memcmp(lo[t].data(), ldes[t].data().data(), lo[t].size() * 8) == 0);
+    std::printf("starkpack_two_traces_f64 ok\n");
+}
+
+static void constraint_commitment_quadratic() {
+    typedef QuadExtension<F64Element> E;
+    const size_t n = 64, blowup = 8, cols = 2;
+    std::vector<E> coeffs(n * cols);
+    uint64_t s = 99;
+    for (auto &e : coeffs)
+        for (auto &c : e.c) {
+            s = s * 6364136223846793005ull + 1442695040888963407ull;
+            c.inner = orc_f64_new(s >> 2);
+        }
+    CompositionPoly<E> poly(coeffs, n, cols);
+    EXPECT(poly.num_columns() == cols && poly.column_len() == n);
+    StarkDomain domain(n, blowup, 7);
+    Prover prover(0);
+    ConstraintCommitment<E> cc = prover.build_constraint_commitment(poly, domain);
+    EXPECT(cc.tree_depth() == 9 && cc.evaluations().num_cols() == cols && cc.evaluations().row_width() == 8);
+    std::vector<const void *> in{poly.data().get_column(0).data(), poly.data().get_column(1).data()};
+    std::vector<uint64_t> lde(n * blowup * 8);
+    std::vector<Digest> ol(n * blowup), on(n * blowup);
+    uint8_t off[16] = {7};
+    EXPECT(orc_build_constraint_commitment(ORC_FIELD_F64, 2, 6, 3, cols, off, in.data(), lde.data(), ol[0].data(),
+                                           on[0].data(), 1) == 0);
+    EXPECT(on[1] == cc.root());
+    EXPECT(std::memcmp(lde.data(), cc.evaluations().data().data(), lde.size() * 8) == 0);
+    std::printf("constraint_commitment_quadratic ok\n");
+}
+
+static void errors_like_the_reference() {
+    Prover prover(0);
+    bool threw = false;
+    try {  // trace shorter than 8 rows (air/src/air/trace_info.rs:35)
+        ColMatrix<F64Element> t({std::vector<F64Element>(4)});
+        StarkDomain d(4, 8, 7);
+        prover.build_trace_commitment<F64Element>({&t}, d);
+    } catch (const WfError &e) {
+        threw = e.code == WF_ERR_TRACE_LENGTH;
+    }
+    EXPECT(threw);
+    threw = false;
+    try {
+        MerkleTree::from_leaves(prover.context(), std::vector<Digest>(1));  // merkle/mod.rs:118-120
+    } catch (const WfError &e) {
+        threw = e.code == WF_ERR_LEAVES;
+    }
+    EXPECT(threw);
+    threw = false;
+    try {
+        ColMatrix<F64Element> bad({std::vector<F64Element>(6)});  // not a power of two (col_matrix.rs:50-54)
+    } catch (const std::invalid_argument &) {
+        threw = true;
+    }
+    EXPECT(threw);
+    std::printf("errors_like_the_reference ok\n");
+}
+
+int main() {
+    extend_and_commit_trace_table();
+    starkpack_two_traces_f64();
+    constraint_commitment_quadratic();
+    errors_like_the_reference();
+    std::printf("ALL OK\n");
+    return 0;
+}

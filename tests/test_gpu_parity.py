@@ -178,3 +178,24 @@ def test_error_codes(ctx, capi):
     with pytest.raises(capi.WfError) as e:
         ctx.merkle_build(np.zeros((6, 32), dtype=np.uint8))
     assert e.value.code == -18
+
+
+@pytest.mark.parametrize("field,logR,logB,n_cols", [
+    (F64, 21, 1, 2),    # digits [11, 10]
+    (F64, 22, 1, 1),    # digits [11, 11]: a whole 160 KiB of LDS per work-group
+    (F64, 23, 1, 1),    # three passes [8, 8, 7]
+    (F128, 21, 1, 1),   # f128 digits are capped at 10 bits: three passes [7, 7, 7]
+])
+def test_large_transform_plans(ctx, orc, capi, field, logR, logB, n_cols):
+    rng = np.random.default_rng(logR)
+    cols = rand_cols(rng, field, n_cols, 1 << logR)
+    offset = 7 if field == F64 else 3
+    want = orc.build_trace_commitment(field, [cols], 1, logR, logB, offset, threads=16)
+    got = ctx.trace_commit(capi.make_params(field, 1, logR, logB, n_cols, 1), cols)
+    assert np.array_equal(got["lde"][0], want["lde"][0])
+    assert got["root"] == want["root"]
+    # the stand-alone transforms use the column-layout kernels: check their multi-pass plans too
+    tw_inv = orc.get_twiddles(field, 1 << logR, inverse=True)
+    want_i = cols[0].copy()
+    orc.interpolate_poly(field, want_i, 1 << logR, 1, tw_inv)
+    assert np.array_equal(ctx.fft_interpolate_poly(field, 1, cols[0]), want_i)
