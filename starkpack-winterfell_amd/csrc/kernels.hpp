@@ -1,10 +1,12 @@
-// HIP kernels of the LDE + commitment path (gfx950).  See DESIGN.md for the pass structure and data layout.
+// Column-layout NTT kernels (the stand-alone math::fft entry points: evaluate_poly, interpolate_poly,
+// interpolate_poly_with_offset on one column of E), leaf hashing and Merkle kernels (gfx950).
+// The commitment path itself runs the segment-layout kernels of seg_kernels.hpp.  See DESIGN.md.
 //
 // NTT of size N = 2^L is split into 1..4 "digit" passes (digits of <= 11 bits).  Input index
 // n = (n1, n2, .., nP) (n1 most significant), output index k = k1 + N1*k2 + N1*N2*k3 + ..  Pass i transforms digit
 // n_i -> k_i in place, inside LDS, for a tile of adjacent inner positions, then multiplies by the inter-pass
 // twiddle w_{Ni*..*NP}^(k_i * inner).  The last pass has inner = 1 (contiguous rows) and scatters its outputs to
-// natural order: column-major polynomials (interpolation) or the row-major LDE matrix (evaluation on a coset).
+// natural order.
 // Nothing is ever bit-reverse permuted in memory (the reference's permute passes, math/src/fft/fft_inputs.rs:56-64
 // and prover/src/matrix/segments.rs:276-298, disappear into the index arithmetic).
 #pragma once
@@ -33,10 +35,6 @@ struct Pow2L {
 };
 
 enum : uint32_t { SCALE_NONE = 0, SCALE_CONST = 1, SCALE_SERIES = 2 };
-enum : uint32_t { OUT_COLS = 0, OUT_ROWS = 1 };
-// kernel flavour (also keeps the two uses apart in profiler output): interpolation of columns (inverse transform,
-// column-major natural-order output) or evaluation over the cosets of the LDE domain (row-major output)
-enum : int { K_INTERP = 0, K_EVAL = 1 };
 
 template <class F>
 struct NttArgs {
@@ -48,33 +46,18 @@ struct NttArgs {
     uint32_t logD;     // this pass's digit
     uint32_t W;        // coordinates per element (extension degree)
     uint32_t Tl;       // tile: adjacent inner positions (strided pass) or adjacent k1 rows (last pass)
-    uint32_t GC;       // last pass, OUT_ROWS: columns per work-group
-    uint32_t V;        // values per LDS row = Tl*GC*W
+    uint32_t V;        // values per LDS row = Tl*W
     uint64_t I;        // strided pass: inner count (product of later digits)
     uint64_t O;        // outer count (product of earlier digits)
     uint32_t n_prev;   // last pass: number of earlier digits and their sizes (most significant first)
     uint32_t prev_log[3];
-    // batch
-    uint32_t TC;        // columns (all traces)
-    uint32_t n_cosets;  // 1 for interpolation
-    uint32_t src_by_tc; // strided pass: source column = tc (shared by all cosets) instead of the batch slot
-    uint64_t col_elems; // elements per column (= N)
+    uint64_t col_elems; // elements per column (= N); grid covers a batch of columns
     // twiddles: powers of the N-th root used by this transform (forward or inverse)
     Pow2L<F> tw;
-    // coset pre-scale h_c^n (first pass of an evaluation); tables for coset c at lo + c*pre_lo_stride
-    uint32_t pre_on;
-    Pow2L<F> pre;
-    uint64_t pre_lo_stride, pre_hi_stride;
     // output scaling of the last pass
     uint32_t scale_mode;
     T scale;            // SCALE_CONST
     Pow2L<F> out_pow;   // SCALE_SERIES: multiply output k by out_pow^k (lo table pre-multiplied by 1/n)
-    // OUT_ROWS
-    uint32_t out_mode;
-    uint32_t n_cols;     // columns per trace
-    uint32_t log_blowup;
-    uint64_t row_width;  // base elements per output row
-    uint64_t trace_lde_elems;  // elements per trace matrix
 };
 
 __device__ __forceinline__ uint32_t digit_reverse(uint32_t pos, uint32_t logD) {
@@ -166,7 +149,7 @@ __device__ __forceinline__ void build_digit_twiddles(typename F::T *twd, const P
 // ---------------------------------------------------------------------------------------------------------------
 // Strided pass: view [O][D][I] of every column (I contiguous), transform the D axis for a tile of Tl inner positions.
 // grid.x = batch * O * (I / Tl)
-template <class F, int KIND>
+template <class F>
 __global__ void __launch_bounds__(1024) k_ntt_strided(NttArgs<F> a) {
     typedef typename F::T T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -180,30 +163,15 @@ __global__ void __launch_bounds__(1024) k_ntt_strided(NttArgs<F> a) {
     bid /= tiles;
     const uint64_t o = bid % a.O;
     const uint64_t b = bid / a.O;
-    const uint32_t c = (uint32_t)(b / a.TC);
-    const uint32_t tc = (uint32_t)(b - (uint64_t)c * a.TC);
     const uint64_t i0 = tile * a.Tl;
-    const T *src = a.src + (a.src_by_tc ? (uint64_t)tc : b) * a.col_elems * a.W;
+    const T *src = a.src + b * a.col_elems * a.W;
     T *dst = a.dst + b * a.col_elems * a.W;
 
     build_digit_twiddles<F>(twd, a.tw, a.logN, a.logD);
-
-    Pow2L<F> pre = a.pre;
-    const bool pre_on = KIND == K_EVAL && a.pre_on;
-    if (pre_on) {
-        pre.lo += (uint64_t)c * a.pre_lo_stride;
-        pre.hi += (uint64_t)c * a.pre_hi_stride;
-    }
     const uint32_t total = D * V;
     for (uint32_t wk = threadIdx.x; wk < total; wk += blockDim.x) {
         const uint32_t d = wk / V, v = wk - d * V;
-        const uint64_t g = ((o * D + d) * a.I + i0) * a.W + v;
-        T val = src[g];
-        if (pre_on) {
-            const uint64_t n = (uint64_t)d * a.I + i0 + v / a.W;  // coefficient index (O == 1 on this pass)
-            val = F::mul(val, pre.get(n));
-        }
-        x[wk] = val;
+        x[wk] = src[((o * D + d) * a.I + i0) * a.W + v];
     }
     lds_ntt<F>(x, twd, a.logD, V);
     // inter-pass twiddle w_{D*I}^(k*i) = w_N^(k*i*N/(D*I)), store with digit d -> k
@@ -220,10 +188,9 @@ __global__ void __launch_bounds__(1024) k_ntt_strided(NttArgs<F> a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Last pass: view [O][D] (D contiguous).  OUT_COLS: one column, Tl adjacent k1 rows -> natural-order column.
-// OUT_ROWS: GC columns of one coset, one row tile -> row-major LDE matrix rows k*blowup + c.
-// grid.x = batch * (O / Tl)   with batch = n_cosets * (TC or traces*groups)
-template <class F, int KIND>
+// Last pass: view [O][D] (D contiguous) of one column; Tl adjacent k1 rows per work-group so that the natural-order
+// outputs form Tl-element runs.  grid.x = batch * (O / Tl)
+template <class F>
 __global__ void __launch_bounds__(1024) k_ntt_last(NttArgs<F> a) {
     typedef typename F::T T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -233,7 +200,7 @@ __global__ void __launch_bounds__(1024) k_ntt_last(NttArgs<F> a) {
 
     // tiles over the most significant earlier digit k1
     const uint32_t log1 = a.n_prev ? a.prev_log[0] : 0;
-    const uint64_t O_lo = a.O >> log1;              // combinations of the remaining earlier digits
+    const uint64_t O_lo = a.O >> log1;  // combinations of the remaining earlier digits
     const uint64_t k1_tiles = ((uint64_t)1 << log1) / a.Tl;
     const uint64_t tiles = k1_tiles * O_lo;
     uint64_t bid = blockIdx.x;
@@ -241,99 +208,49 @@ __global__ void __launch_bounds__(1024) k_ntt_last(NttArgs<F> a) {
     const uint64_t b = bid / tiles;
     const uint64_t k1_0 = (tile % k1_tiles) * a.Tl;
     const uint64_t o_rest = tile / k1_tiles;
-    // natural output index contributed by the earlier digits other than k1
+    // natural output index contributed by the earlier digits other than k1: o_rest = (k2, k3, ..), k2 most significant
     uint64_t rev_rest = 0;
     {
-        uint64_t r = o_rest;
-        uint32_t sh_out = log1;
-        // o_rest = (k2, k3, ..) with k2 most significant
-        uint32_t bits_rest = 0;
+        uint32_t sh_out = log1, bits_rest = 0;
         for (uint32_t i = 1; i < a.n_prev; i++) bits_rest += a.prev_log[i];
         uint32_t hi = bits_rest;
         for (uint32_t i = 1; i < a.n_prev; i++) {
             hi -= a.prev_log[i];
-            const uint64_t dig = (r >> hi) & (((uint64_t)1 << a.prev_log[i]) - 1);
+            const uint64_t dig = (o_rest >> hi) & (((uint64_t)1 << a.prev_log[i]) - 1);
             rev_rest |= dig << sh_out;
             sh_out += a.prev_log[i];
         }
     }
-
-    // batch decode
-    uint32_t c, col0, trace = 0, ncol_here;
-    const T *src_base;
-    if (KIND == K_EVAL) {
-        const uint32_t groups = (a.n_cols + a.GC - 1) / a.GC;
-        const uint32_t n_traces = a.TC / a.n_cols;
-        const uint32_t g = (uint32_t)(b % groups);
-        const uint64_t r2 = b / groups;
-        trace = (uint32_t)(r2 % n_traces);
-        c = (uint32_t)(r2 / n_traces);
-        col0 = g * a.GC;
-        ncol_here = min(a.GC, a.n_cols - col0);
-        const uint64_t slot0 = a.src_by_tc ? (uint64_t)trace * a.n_cols + col0
-                                           : ((uint64_t)c * a.TC + (uint64_t)trace * a.n_cols + col0);
-        src_base = a.src + slot0 * a.col_elems * W;
-    } else {
-        c = 0;
-        col0 = 0;
-        ncol_here = 1;
-        src_base = a.src + b * a.col_elems * W;
-    }
-
+    const T *src_base = a.src + b * a.col_elems * W;
     build_digit_twiddles<F>(twd, a.tw, a.logN, a.logD);
-    Pow2L<F> pre = a.pre;
-    const bool pre_on = KIND == K_EVAL && a.pre_on;
-    if (pre_on) {
-        pre.lo += (uint64_t)c * a.pre_lo_stride;
-        pre.hi += (uint64_t)c * a.pre_hi_stride;
-    }
 
-    // load: line = (t_in, cg); a line is D*W contiguous values; read in 8-value chunks per line
-    const uint32_t lines = a.Tl * a.GC;
+    // load: line t_in is D*W contiguous values; read in 8-value chunks per line
+    const uint32_t lines = a.Tl;
     const uint32_t line_vals = D * W;
     const uint32_t CH = (line_vals % 8 == 0) ? 8 : 1;
     const uint32_t total = D * V;
     for (uint32_t wk = threadIdx.x; wk < total; wk += blockDim.x) {
         const uint32_t gg = wk % CH;
         const uint32_t r = wk / CH;
-        const uint32_t line = r % lines;
+        const uint32_t t_in = r % lines;
         const uint32_t g = (r / lines) * CH + gg;  // value index inside the line
-        const uint32_t t_in = line / a.GC, cg = line - t_in * a.GC;
         const uint32_t d = g / W, w = g - d * W;
-        T val = F::zero();
-        if (cg < ncol_here) {
-            const uint64_t o_t = ((k1_0 + t_in) * O_lo) + o_rest;
-            val = src_base[((uint64_t)cg * a.col_elems + o_t * D) * W + g];
-            if (pre_on) val = F::mul(val, pre.get(d));  // single-pass evaluation: coefficient index = d
-        }
-        x[d * V + line * W + w] = val;
+        const uint64_t o_t = ((k1_0 + t_in) * O_lo) + o_rest;
+        x[d * V + t_in * W + w] = src_base[o_t * D * W + g];
     }
     lds_ntt<F>(x, twd, a.logD, V);
 
-    if (KIND == K_INTERP) {
-        T *dst = a.dst + b * a.col_elems * W;
-        for (uint32_t wk = threadIdx.x; wk < total; wk += blockDim.x) {
-            const uint32_t pos = wk / V, v = wk - pos * V;
-            const uint32_t t_in = v / W, w = v - t_in * W;
-            const uint64_t k = (k1_0 + t_in) + rev_rest + ((uint64_t)digit_reverse(pos, a.logD) << (a.logN - a.logD));
-            T val = x[wk];
-            if (a.scale_mode == SCALE_CONST)
-                val = F::mul(val, a.scale);
-            else if (a.scale_mode == SCALE_SERIES)
-                val = F::mul(val, a.out_pow.get(k));
-            dst[k * W + w] = val;
-        }
-    } else {
-        T *dst = a.dst + (uint64_t)trace * a.trace_lde_elems + (uint64_t)col0 * W;
-        const uint32_t vw = a.GC * W;  // values per (t_in) chunk
-        for (uint32_t wk = threadIdx.x; wk < total; wk += blockDim.x) {
-            const uint32_t pos = wk / V, v = wk - pos * V;
-            const uint32_t t_in = v / vw, cv = v - t_in * vw;
-            if (cv >= ncol_here * W) continue;
-            const uint64_t k = (k1_0 + t_in) + rev_rest + ((uint64_t)digit_reverse(pos, a.logD) << (a.logN - a.logD));
-            const uint64_t row = (k << a.log_blowup) + c;
-            dst[row * a.row_width + cv] = x[wk];
-        }
+    T *dst = a.dst + b * a.col_elems * W;
+    for (uint32_t wk = threadIdx.x; wk < total; wk += blockDim.x) {
+        const uint32_t pos = wk / V, v = wk - pos * V;
+        const uint32_t t_in = v / W, w = v - t_in * W;
+        const uint64_t k = (k1_0 + t_in) + rev_rest + ((uint64_t)digit_reverse(pos, a.logD) << (a.logN - a.logD));
+        T val = x[wk];
+        if (a.scale_mode == SCALE_CONST)
+            val = F::mul(val, a.scale);
+        else if (a.scale_mode == SCALE_SERIES)
+            val = F::mul(val, a.out_pow.get(k));
+        dst[k * W + w] = val;
     }
 }
 

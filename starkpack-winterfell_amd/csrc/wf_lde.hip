@@ -233,48 +233,34 @@ static uint32_t tile_target(uint32_t W) {  // adjacent elements so that a global
     return t < 1 ? 1 : t;
 }
 
-static uint32_t pow2_floor(uint32_t v) {
-    uint32_t r = 1;
-    while (r * 2 <= v) r *= 2;
-    return r;
-}
-
-template <class F, int KIND>
+template <class F>
 static int launch_dims(uint32_t logD, uint32_t V, uint32_t &threads, size_t &lds) {
     const size_t vals = ((size_t)1 << logD) * V;
     lds = (vals + ((size_t)1 << logD)) * sizeof(typename F::T);
     if (lds > 160 * 1024) return fail(WF_ERR_ARG, "internal: pass needs %zu bytes of LDS", lds);
     threads = vals >= 16384 ? 1024 : (vals >= 8192 ? 512 : 256);
     if (lds > 64 * 1024) {
-        HIP_TRY(hipFuncSetAttribute((const void *)k_ntt_strided<F, KIND>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_ntt_last<F, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_ntt_strided<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_ntt_last<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     return 0;
 }
 
-// One transform of every column of a batch.
-//   inverse        : use the inverse root
-//   src            : [TC] columns (N elements of W coordinates)
-//   OUT_COLS       : dst = [TC] columns, natural order, scaled per scale_mode
-//   OUT_ROWS       : dst = [n_traces] row-major matrices; n_cosets = blowup, coset c of trace t, column col lands in
-//                    rows k*blowup + c; `pre` holds the coset bases
+// One transform of a batch of columns in the caller's column layout (the stand-alone math::fft entry points):
+// src = [batch] columns of N elements of W coordinates, dst likewise, natural order, scaled per scale_mode.
 template <class F>
 struct XformDesc {
     typedef typename F::T T;
     const T *src;
     T *dst;
-    uint32_t logN, W, TC, n_cols, n_cosets, log_blowup;
+    uint32_t logN, W, batch;
     bool inverse;
-    uint32_t out_mode, scale_mode;
+    uint32_t scale_mode;
     T scale;
     const TableSet *out_series;
-    const TableSet *pre;
-    uint64_t row_width, trace_lde_elems;
 };
 
-template <class F, int KIND>
+template <class F>
 static int run_transform(wf_ctx *ctx, hipStream_t st, const XformDesc<F> &d) {
     typedef typename F::T T;
     TableSet *tw;
@@ -287,97 +273,57 @@ static int run_transform(wf_ctx *ctx, hipStream_t st, const XformDesc<F> &d) {
     memset(&a, 0, sizeof(a));
     a.logN = d.logN;
     a.W = d.W;
-    a.TC = d.TC;
-    a.n_cosets = d.n_cosets;
     a.col_elems = N;
     a.tw = as_pow2l<F>(*tw);
-    a.n_cols = d.n_cols;
-    a.log_blowup = d.log_blowup;
-    a.row_width = d.row_width;
-    a.trace_lde_elems = d.trace_lde_elems;
-    a.out_mode = d.out_mode;
-    if (d.pre) {
-        a.pre = as_pow2l<F>(*d.pre);
-        a.pre_lo_stride = d.pre->lo_stride;
-        a.pre_hi_stride = d.pre->hi_stride;
-    }
-    const uint64_t batch = (uint64_t)d.TC * d.n_cosets;
     // multi-pass transforms go  src -> scratch (first pass), scratch in place (middle), scratch -> dst (last pass):
     // the last pass scatters to natural order and therefore cannot run in place
     T *scratch = nullptr;
     if (plan.n_pass > 1) {
-        rc = ensure(ctx->scratch, (size_t)batch * N * d.W * sizeof(T));
+        rc = ensure(ctx->scratch, (size_t)d.batch * N * d.W * sizeof(T));
         if (rc) return rc;
         scratch = (T *)ctx->scratch.p;
     }
-
-    // strided passes
     uint32_t done_bits = 0;
     for (int pi = 0; pi + 1 < plan.n_pass; pi++) {
         a.logD = plan.dig[pi];
         a.O = (uint64_t)1 << done_bits;
         a.I = N >> (done_bits + a.logD);
         a.Tl = (uint32_t)std::min<uint64_t>(tile_target<F>(d.W), a.I);
-        a.GC = 1;
         a.V = a.Tl * d.W;
-        const bool first = pi == 0;
-        a.src = first ? d.src : scratch;
+        a.src = pi == 0 ? d.src : scratch;
         a.dst = scratch;
-        a.src_by_tc = (first && d.out_mode == OUT_ROWS) ? 1 : 0;
-        a.pre_on = (first && d.pre) ? 1 : 0;
         uint32_t threads;
         size_t lds;
-        rc = launch_dims<F, KIND>(a.logD, a.V, threads, lds);
+        rc = launch_dims<F>(a.logD, a.V, threads, lds);
         if (rc) return rc;
-        const uint64_t grid = batch * a.O * (a.I / a.Tl);
+        const uint64_t grid = (uint64_t)d.batch * a.O * (a.I / a.Tl);
         if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
-        prof_mark(ctx, st, KIND == K_EVAL ? "evaluate.strided_pass" : "interpolate.strided_pass");
-        hipLaunchKernelGGL((k_ntt_strided<F, KIND>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
+        hipLaunchKernelGGL(k_ntt_strided<F>, dim3((uint32_t)grid), dim3(threads), lds, st, a);
         HIP_TRY(hipGetLastError());
         done_bits += a.logD;
     }
-    // last pass
     {
         const int pi = plan.n_pass - 1;
+        const bool single = plan.n_pass == 1;
         a.logD = plan.dig[pi];
         a.O = (uint64_t)1 << done_bits;
         a.I = 1;
         a.n_prev = plan.n_pass - 1;
         for (int i = 0; i < pi; i++) a.prev_log[i] = plan.dig[i];
-        const bool single = plan.n_pass == 1;
         a.scale_mode = d.scale_mode;
         a.scale = d.scale;
         if (d.out_series) a.out_pow = as_pow2l<F>(*d.out_series);
-        uint64_t groups_per_coset;
-        if (d.out_mode == OUT_COLS) {
-            a.GC = 1;
-            uint32_t t = single ? 1 : std::min<uint32_t>(tile_target<F>(d.W), 1u << plan.dig[0]);
-            a.Tl = t;
-            a.src = single ? d.src : scratch;
-            a.dst = d.dst;
-            a.src_by_tc = 0;
-            groups_per_coset = d.TC;
-        } else {
-            uint32_t gc = std::max<uint32_t>(1, (F::BYTES == 8 ? 8u : 4u) / d.W);
-            a.GC = std::min<uint32_t>(gc, d.n_cols);
-            a.Tl = 1;
-            a.src = single ? d.src : scratch;
-            a.dst = d.dst;
-            a.src_by_tc = single ? 1 : 0;
-            const uint32_t groups = (d.n_cols + a.GC - 1) / a.GC;
-            groups_per_coset = (uint64_t)(d.TC / d.n_cols) * groups;
-        }
-        a.pre_on = (single && d.pre) ? 1 : 0;
-        a.V = a.Tl * a.GC * d.W;
+        a.Tl = single ? 1 : std::min<uint32_t>(tile_target<F>(d.W), 1u << plan.dig[0]);
+        a.V = a.Tl * d.W;
+        a.src = single ? d.src : scratch;
+        a.dst = d.dst;
         uint32_t threads;
         size_t lds;
-        rc = launch_dims<F, KIND>(a.logD, a.V, threads, lds);
+        rc = launch_dims<F>(a.logD, a.V, threads, lds);
         if (rc) return rc;
-        const uint64_t tiles = a.O / a.Tl;
-        const uint64_t grid = groups_per_coset * d.n_cosets * tiles;
+        const uint64_t grid = (uint64_t)d.batch * (a.O / a.Tl);
         if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
-        prof_mark(ctx, st, KIND == K_EVAL ? "evaluate.last_pass" : "interpolate.last_pass");
-        hipLaunchKernelGGL((k_ntt_last<F, KIND>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
+        hipLaunchKernelGGL(k_ntt_last<F>, dim3((uint32_t)grid), dim3(threads), lds, st, a);
         HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -950,11 +896,8 @@ static int fft_host(wf_ctx *ctx, uint32_t ext, void *buf, uint32_t logn, bool in
     d.dst = (T *)ctx->io[1].p;
     d.logN = logn;
     d.W = ext;
-    d.TC = 1;
-    d.n_cols = 1;
-    d.n_cosets = 1;
+    d.batch = 1;
     d.inverse = inverse;
-    d.out_mode = OUT_COLS;
     if (inverse) {
         if (offset16) {
             u128 off;
@@ -970,7 +913,7 @@ static int fft_host(wf_ctx *ctx, uint32_t ext, void *buf, uint32_t logn, bool in
             d.scale = f_inv<F>(F::from_u128_canonical((u128)1 << logn));
         }
     }
-    rc = run_transform<F, K_INTERP>(ctx, st, d);
+    rc = run_transform<F>(ctx, st, d);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(buf, ctx->io[1].p, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
