@@ -133,6 +133,41 @@ int wf_trace_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_trace, vo
 int wf_constraint_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_polys, void *d_lde, void *d_leaves,
                              void *d_nodes, void *stream);
 
+/* ---- the path, resident form: commitment stays in HBM, queries are served from there -------------------------------- */
+
+/* Opaque device-resident commitment: the LDE matrices of all traces, the leaves and the tree nodes (what
+ * TraceCommitment / ConstraintCommitment own in the reference: prover/src/trace/commitment.rs:21-26,
+ * prover/src/constraints/commitment.rs:21-24) plus the polynomials in column layout.  Avoids copying
+ * 0.5-16 GiB over PCIe per commitment; only the <= 255 queried rows and their Merkle paths ever leave the GPU. */
+typedef struct wf_commitment wf_commitment;
+
+/* build_trace_commitment with host inputs; polys_out (host, [n_traces*n_cols] pointers) may be NULL. */
+int wf_trace_commit_resident(wf_ctx *ctx, const wf_params *p, const void *const *trace_cols, void *const *polys_out,
+                             wf_commitment **out);
+/* build_constraint_commitment with host inputs. */
+int wf_constraint_commit_resident(wf_ctx *ctx, const wf_params *p, const void *const *poly_cols, wf_commitment **out);
+void wf_commitment_destroy(wf_commitment *c);
+/* MerkleTree::root (merkle/mod.rs:167) */
+int wf_commitment_root(const wf_commitment *c, uint8_t root_out[32]);
+/* Number of LDE rows (= leaves), hashed base elements per row over all traces, tree depth. */
+int wf_commitment_info(const wf_commitment *c, uint64_t *n_rows, uint64_t *row_elems, uint32_t *depth);
+/* Rows at `positions` (TraceCommitment::query / build_segment_queries, trace/commitment.rs:87-111,135-160;
+ * ConstraintCommitment::query, constraints/commitment.rs:54-69): rows_out receives n * row_elems base elements,
+ * row i = row positions[i] of trace 0 || trace 1 || .. (the "comb_states" that are hashed into leaf positions[i]). */
+int wf_commitment_read_rows(const wf_commitment *c, const uint64_t *positions, size_t n, void *rows_out);
+/* MerkleTree::prove (merkle/mod.rs:192-212): path_out receives (depth + 1) digests: leaf, sibling leaf, siblings
+ * bottom-up. */
+int wf_commitment_prove(const wf_commitment *c, uint64_t index, uint8_t *path_out);
+/* MerkleTree::prove_batch (merkle/mod.rs:222-284), the compressed ("octopus") multi-path proof:
+ *   leaves_out  : n digests, leaf of positions[i] at i                          (BatchMerkleProof.leaves)
+ *   nodes_out   : the node vectors back to back, at most nodes_capacity digests (BatchMerkleProof.nodes, flattened)
+ *   node_counts : length of each vector; *n_vectors of them (at most n)
+ *   depth_out   : BatchMerkleProof.depth
+ * Errors follow the reference: no positions / more than 255 -> WF_ERR_ARG, out of range or duplicate -> WF_ERR_LEAVES. */
+int wf_commitment_prove_batch(const wf_commitment *c, const uint64_t *positions, size_t n, uint8_t *leaves_out,
+                              uint8_t *nodes_out, size_t nodes_capacity, uint32_t *node_counts, size_t *n_vectors,
+                              size_t *n_nodes, uint32_t *depth_out);
+
 /* ---- building blocks (each mirrors one reference function; host buffers) ---------------------------------------- */
 
 /* fft::evaluate_poly (math/src/fft/mod.rs:85): in place, n elements of ext_degree coordinates, natural order. */

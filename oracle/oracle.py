@@ -302,3 +302,73 @@ def build_constraint_commitment(field: int, poly_cols, ext: int, log2_R: int, lo
     if rc:
         raise ValueError(f"build_constraint_commitment failed: {rc}")
     return dict(lde=lde, leaves=leaves, nodes=nodes, root=bytes(nodes[1]))
+
+
+# ----------------------------------------------------------------------------------------------- merkle proofs
+
+def merkle_prove(nodes: np.ndarray, leaves: np.ndarray, index: int):
+    """MerkleTree::prove, crypto/src/merkle/mod.rs:192-212."""
+    n = leaves.shape[0]
+    if index >= n:
+        raise ValueError("leaf index out of bounds")
+    proof = [bytes(leaves[index]), bytes(leaves[index ^ 1])]
+    i = (index + n) >> 1
+    while i > 1:
+        proof.append(bytes(nodes[i ^ 1]))
+        i >>= 1
+    return proof
+
+
+def merkle_verify(root: bytes, index: int, proof) -> bool:
+    """MerkleTree::verify, crypto/src/merkle/mod.rs:295-317."""
+    r = index & 1
+    v = merge(proof[r], proof[1 - r])
+    index = (index + 2 ** (len(proof) - 1)) >> 1
+    for p in proof[2:]:
+        v = merge(v, p) if index & 1 == 0 else merge(p, v)
+        index >>= 1
+    return v == root
+
+
+def merkle_prove_batch(nodes: np.ndarray, leaves: np.ndarray, indexes):
+    """MerkleTree::prove_batch, crypto/src/merkle/mod.rs:222-284 (incl. map_indexes :376-395 and
+    normalize_indexes :397-403).  Returns (leaves, nodes, depth) like BatchMerkleProof."""
+    n = leaves.shape[0]
+    depth = n.bit_length() - 1
+    if len(indexes) == 0:
+        raise ValueError("too few leaf indexes")
+    if len(indexes) > 255:
+        raise ValueError("too many leaf indexes")
+    index_map = {}
+    for i, idx in enumerate(indexes):
+        index_map[idx] = i
+        if idx >= n:
+            raise ValueError("leaf index out of bounds")
+    if len(index_map) != len(indexes):
+        raise ValueError("duplicate leaf index")
+    norm = sorted({idx - (idx & 1) for idx in indexes})
+    out_leaves = [None] * len(index_map)
+    out_nodes = []
+    nxt = []
+    for index in norm:
+        missing = []
+        for i in (index, index + 1):
+            v = bytes(leaves[i])
+            if i in index_map:
+                out_leaves[index_map[i]] = v
+            else:
+                missing.append(v)
+        out_nodes.append(missing)
+        nxt.append((index + n) >> 1)
+    for _ in range(1, depth):
+        cur, nxt = nxt, []
+        i = 0
+        while i < len(cur):
+            sib = cur[i] ^ 1
+            if i + 1 < len(cur) and cur[i + 1] == sib:
+                i += 1
+            else:
+                out_nodes[i].append(bytes(nodes[sib]))
+            nxt.append(sib >> 1)
+            i += 1
+    return out_leaves, out_nodes, depth

@@ -20,6 +20,8 @@ SYMBOLS = [
     "wf_ctx_create", "wf_ctx_destroy", "wf_last_error", "wf_device_count", "wf_ctx_synchronize", "wf_ctx_stream",
     "wf_ctx_profile_enable", "wf_ctx_profile_read", "wf_params_check", "wf_elem_bytes", "wf_row_width", "wf_column_bytes", "wf_lde_bytes", "wf_digests_bytes",
     "wf_trace_commit", "wf_constraint_commit", "wf_trace_commit_dev", "wf_constraint_commit_dev",
+    "wf_trace_commit_resident", "wf_constraint_commit_resident", "wf_commitment_destroy", "wf_commitment_root",
+    "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_prove", "wf_commitment_prove_batch",
     "wf_fft_evaluate_poly", "wf_fft_evaluate_poly_with_offset", "wf_fft_interpolate_poly",
     "wf_fft_interpolate_poly_with_offset", "wf_evaluate_polys_over", "wf_hash_rows", "wf_merkle_build",
 ]
@@ -79,6 +81,16 @@ def load():
         L.wf_constraint_commit.argtypes = [vp, PP, vp, vp, vp, vp, vp]
         L.wf_trace_commit_dev.argtypes = [vp, PP, vp, vp, vp, vp, vp, vp]
         L.wf_constraint_commit_dev.argtypes = [vp, PP, vp, vp, vp, vp, vp]
+        L.wf_trace_commit_resident.argtypes = [vp, PP, vp, vp, C.POINTER(vp)]
+        L.wf_constraint_commit_resident.argtypes = [vp, PP, vp, C.POINTER(vp)]
+        L.wf_commitment_destroy.argtypes = [vp]
+        L.wf_commitment_destroy.restype = None
+        L.wf_commitment_root.argtypes = [vp, vp]
+        L.wf_commitment_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(u32)]
+        L.wf_commitment_read_rows.argtypes = [vp, vp, sz, vp]
+        L.wf_commitment_prove.argtypes = [vp, C.c_uint64, vp]
+        L.wf_commitment_prove_batch.argtypes = [vp, vp, sz, vp, vp, sz, vp, C.POINTER(sz), C.POINTER(sz),
+                                                C.POINTER(u32)]
         L.wf_fft_evaluate_poly.argtypes = [vp, u32, u32, vp, sz]
         L.wf_fft_interpolate_poly.argtypes = [vp, u32, u32, vp, sz]
         L.wf_fft_interpolate_poly_with_offset.argtypes = [vp, u32, u32, vp, sz, vp]
@@ -196,6 +208,25 @@ class Context:
         _check(load().wf_constraint_commit_dev(self._h, C.byref(params), d_polys, d_lde, d_leaves, d_nodes,
                                                stream or None))
 
+    # -- the path, resident form -------------------------------------------------------------------------------------
+    def trace_commit_resident(self, params: Params, trace_cols, want_polys=False):
+        L = load()
+        _check(L.wf_params_check(C.byref(params), 0))
+        cols = [np.ascontiguousarray(c, dtype=np.uint64) for c in trace_cols]
+        polys = [np.empty_like(c) for c in cols] if want_polys else None
+        h = C.c_void_p()
+        _check(L.wf_trace_commit_resident(self._h, C.byref(params), _ptr_array(cols),
+                                          _ptr_array(polys) if polys else None, C.byref(h)))
+        return Commitment(h, params.field), polys
+
+    def constraint_commit_resident(self, params: Params, poly_cols):
+        L = load()
+        _check(L.wf_params_check(C.byref(params), 1))
+        cols = [np.ascontiguousarray(c, dtype=np.uint64) for c in poly_cols]
+        h = C.c_void_p()
+        _check(L.wf_constraint_commit_resident(self._h, C.byref(params), _ptr_array(cols), C.byref(h)))
+        return Commitment(h, params.field)
+
     # -- building blocks -----------------------------------------------------------------------------------------
     def fft_evaluate_poly(self, field, ext, poly: np.ndarray) -> np.ndarray:
         a = np.ascontiguousarray(poly, dtype=np.uint64).copy()
@@ -245,3 +276,59 @@ class Context:
         nodes = np.empty_like(lv)
         _check(load().wf_merkle_build(self._h, _p(lv), lv.shape[0], _p(nodes)))
         return nodes
+
+
+class Commitment:
+    """wf_commitment wrapper: LDE + tree resident in HBM; rows and Merkle proofs are read from there."""
+
+    def __init__(self, handle, field):
+        self._h = handle
+        self.field = field
+        n_rows, row_elems, depth = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        _check(load().wf_commitment_info(self._h, C.byref(n_rows), C.byref(row_elems), C.byref(depth)))
+        self.n_rows, self.row_elems, self.depth = n_rows.value, row_elems.value, depth.value
+
+    def close(self):
+        if self._h:
+            load().wf_commitment_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def root(self) -> bytes:
+        out = (C.c_uint8 * 32)()
+        _check(load().wf_commitment_root(self._h, out))
+        return bytes(out)
+
+    def read_rows(self, positions) -> np.ndarray:
+        pos = np.ascontiguousarray(positions, dtype=np.uint64)
+        w = ELEM_WORDS[self.field]
+        out = np.empty((len(pos), self.row_elems, w) if w > 1 else (len(pos), self.row_elems), dtype=np.uint64)
+        _check(load().wf_commitment_read_rows(self._h, _p(pos), len(pos), _p(out)))
+        return out
+
+    def prove(self, index: int):
+        out = np.empty((self.depth + 1, 32), dtype=np.uint8)
+        _check(load().wf_commitment_prove(self._h, index, _p(out)))
+        return [bytes(x) for x in out]
+
+    def prove_batch(self, positions):
+        """Returns (leaves, nodes, depth) shaped like the reference's BatchMerkleProof."""
+        pos = np.ascontiguousarray(positions, dtype=np.uint64)
+        n = len(pos)
+        cap = max(1, n) * (self.depth + 1)
+        leaves = np.empty((max(1, n), 32), dtype=np.uint8)
+        nodes = np.empty((cap, 32), dtype=np.uint8)
+        counts = np.zeros(max(1, n), dtype=np.uint32)
+        n_vec, n_nodes, depth = C.c_size_t(), C.c_size_t(), C.c_uint32()
+        _check(load().wf_commitment_prove_batch(self._h, _p(pos), n, _p(leaves), _p(nodes), cap, _p(counts),
+                                                C.byref(n_vec), C.byref(n_nodes), C.byref(depth)))
+        out, k = [], 0
+        for i in range(n_vec.value):
+            out.append([bytes(nodes[k + j]) for j in range(int(counts[i]))])
+            k += int(counts[i])
+        return [bytes(x) for x in leaves[:n]], out, depth.value

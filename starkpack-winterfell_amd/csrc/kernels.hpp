@@ -412,6 +412,29 @@ __global__ void __launch_bounds__(256) k_merkle_level(const uint32_t *__restrict
     dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
 }
 
+// Query service: gather rows of all traces at the queried positions.  grid = (n positions, n traces)
+template <class F>
+__global__ void __launch_bounds__(256) k_gather_rows(const typename F::T *__restrict__ lde, uint64_t trace_elems,
+                                                     uint32_t row_width, uint32_t epr,
+                                                     const uint64_t *__restrict__ positions,
+                                                     typename F::T *__restrict__ out) {
+    const uint32_t i = blockIdx.x, t = blockIdx.y, n_traces = gridDim.y;
+    const typename F::T *row = lde + (uint64_t)t * trace_elems + positions[i] * row_width;
+    typename F::T *dst = out + ((uint64_t)i * n_traces + t) * epr;
+    for (uint32_t e = threadIdx.x; e < epr; e += blockDim.x) dst[e] = row[e];
+}
+
+// gather 32-byte digests: src id = index < n_leaves ? leaves[index] : nodes[index - n_leaves]
+__global__ void __launch_bounds__(256) k_gather_digests(const uint4 *__restrict__ leaves, const uint4 *__restrict__ nodes,
+                                                        uint64_t n_leaves, const uint64_t *__restrict__ ids,
+                                                        uint32_t n, uint4 *__restrict__ out) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= 2 * n) return;
+    const uint64_t id = ids[g >> 1];
+    const uint4 *src = id < n_leaves ? leaves + 2 * id : nodes + 2 * (id - n_leaves);
+    out[g] = src[g & 1];
+}
+
 // Hash contiguous rows of `row_elems` elements (wf_hash_rows building block) is k_hash_rows with n_traces = 1.
 
 }  // namespace wf

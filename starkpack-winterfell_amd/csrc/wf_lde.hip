@@ -860,6 +860,236 @@ int wf_constraint_commit(wf_ctx *ctx, const wf_params *p, const void *const *pol
     return commit_host(ctx, p, true, poly_cols, nullptr, lde_out ? lde_arr : nullptr, leaves_out, nodes_out, root_out);
 }
 
+// resident form ------------------------------------------------------------------------------------------------------
+struct wf_commitment {
+    wf_ctx *ctx;
+    wf_params p;
+    void *lde, *leaves, *nodes, *polys;
+    uint64_t n_rows, row_width, epr, row_elems;
+    uint32_t depth;
+    uint8_t root[32];
+};
+
+static void free_commitment(wf_commitment *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->ctx->device);
+    if (c->lde) (void)hipFree(c->lde);
+    if (c->leaves) (void)hipFree(c->leaves);
+    if (c->nodes) (void)hipFree(c->nodes);
+    if (c->polys) (void)hipFree(c->polys);
+    delete c;
+}
+
+static int commit_resident(wf_ctx *ctx, const wf_params *p, bool constraint, const void *const *cols_in,
+                           void *const *polys_out, wf_commitment **out) {
+    if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
+    if (!out) return fail(WF_ERR_ARG, "out is null");
+    int rc = check_params(p, constraint);
+    if (rc) return rc;
+    if (!cols_in) return fail(WF_ERR_ARG, "column pointer array is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t colb = wf_column_bytes(p), ldeb = wf_lde_bytes(p), digb = wf_digests_bytes(p);
+    const size_t TC = (size_t)p->n_cols * p->n_traces;
+    for (size_t i = 0; i < TC; i++)
+        if (!cols_in[i]) return fail(WF_ERR_ARG, "column %zu is null", i);
+    wf_commitment *c = new wf_commitment();
+    memset(c, 0, sizeof(*c));
+    c->ctx = ctx;
+    c->p = *p;
+    c->n_rows = (uint64_t)1 << (p->log2_trace_len + p->log2_blowup);
+    c->row_width = wf_row_width(p);
+    c->epr = (uint64_t)p->n_cols * p->ext_degree;
+    c->row_elems = c->epr * p->n_traces;
+    c->depth = p->log2_trace_len + p->log2_blowup;
+    hipError_t e;
+    if ((e = hipMalloc(&c->lde, ldeb * p->n_traces)) != hipSuccess || (e = hipMalloc(&c->leaves, digb)) != hipSuccess ||
+        (e = hipMalloc(&c->nodes, digb)) != hipSuccess || (e = hipMalloc(&c->polys, TC * colb)) != hipSuccess) {
+        free_commitment(c);
+        return fail(WF_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    rc = ensure(ctx->io[0], TC * colb);
+    if (rc) {
+        free_commitment(c);
+        return rc;
+    }
+    hipStream_t st = ctx->stream;
+    void *stage = constraint ? c->polys : ctx->io[0].p;  // composition polys are the input themselves
+    for (size_t i = 0; i < TC; i++) {
+        e = hipMemcpyAsync((char *)stage + i * colb, cols_in[i], colb, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) {
+            free_commitment(c);
+            return fail(WF_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
+        }
+    }
+    if (constraint)
+        rc = wf_constraint_commit_dev(ctx, p, c->polys, c->lde, c->leaves, c->nodes, st);
+    else
+        rc = wf_trace_commit_dev(ctx, p, ctx->io[0].p, c->polys, c->lde, c->leaves, c->nodes, st);
+    if (rc) {
+        free_commitment(c);
+        return rc;
+    }
+    if (polys_out && !constraint)
+        for (size_t i = 0; i < TC; i++)
+            if (polys_out[i]) (void)hipMemcpyAsync(polys_out[i], (char *)c->polys + i * colb, colb, hipMemcpyDeviceToHost, st);
+    e = hipMemcpyAsync(c->root, (char *)c->nodes + 32, 32, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        free_commitment(c);
+        return fail(WF_ERR_HIP, "commitment failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return 0;
+}
+
+int wf_trace_commit_resident(wf_ctx *ctx, const wf_params *p, const void *const *trace_cols, void *const *polys_out,
+                             wf_commitment **out) {
+    return commit_resident(ctx, p, false, trace_cols, polys_out, out);
+}
+
+int wf_constraint_commit_resident(wf_ctx *ctx, const wf_params *p, const void *const *poly_cols, wf_commitment **out) {
+    return commit_resident(ctx, p, true, poly_cols, nullptr, out);
+}
+
+void wf_commitment_destroy(wf_commitment *c) { free_commitment(c); }
+
+int wf_commitment_root(const wf_commitment *c, uint8_t root_out[32]) {
+    if (!c || !root_out) return fail(WF_ERR_ARG, "null argument");
+    memcpy(root_out, c->root, 32);
+    return 0;
+}
+
+int wf_commitment_info(const wf_commitment *c, uint64_t *n_rows, uint64_t *row_elems, uint32_t *depth) {
+    if (!c) return fail(WF_ERR_ARG, "commitment is null");
+    if (n_rows) *n_rows = c->n_rows;
+    if (row_elems) *row_elems = c->row_elems;
+    if (depth) *depth = c->depth;
+    return 0;
+}
+
+static int check_positions(const wf_commitment *c, const uint64_t *positions, size_t n) {
+    if (!c || !positions) return fail(WF_ERR_ARG, "null argument");
+    if (n == 0) return fail(WF_ERR_ARG, "at least one position is required");                       // TooFewLeafIndexes
+    if (n > 255) return fail(WF_ERR_ARG, "number of positions cannot exceed 255 (got %zu)", n);      // MAX_PATHS
+    for (size_t i = 0; i < n; i++)
+        if (positions[i] >= c->n_rows)
+            return fail(WF_ERR_LEAVES, "position %llu is out of bounds (%llu rows)", (unsigned long long)positions[i],
+                        (unsigned long long)c->n_rows);                                              // LeafIndexOutOfBounds
+    return 0;
+}
+
+int wf_commitment_read_rows(const wf_commitment *c, const uint64_t *positions, size_t n, void *rows_out) {
+    int rc = check_positions(c, positions, n);
+    if (rc) return rc;
+    if (!rows_out) return fail(WF_ERR_ARG, "rows_out is null");
+    wf_ctx *ctx = c->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t eb = wf_elem_bytes(c->p.field);
+    const size_t out_bytes = n * c->row_elems * eb;
+    if ((rc = ensure(ctx->io[3], n * 8))) return rc;
+    if ((rc = ensure(ctx->io[4], out_bytes))) return rc;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->io[3].p, positions, n * 8, hipMemcpyHostToDevice, st));
+    const uint64_t trace_elems = c->n_rows * c->row_width;
+    if (c->p.field == WF_FIELD_F64)
+        hipLaunchKernelGGL(k_gather_rows<F64>, dim3((uint32_t)n, c->p.n_traces), dim3(64), 0, st, (const uint64_t *)c->lde,
+                           trace_elems, (uint32_t)c->row_width, (uint32_t)c->epr, (const uint64_t *)ctx->io[3].p,
+                           (uint64_t *)ctx->io[4].p);
+    else
+        hipLaunchKernelGGL(k_gather_rows<F128>, dim3((uint32_t)n, c->p.n_traces), dim3(64), 0, st, (const U128 *)c->lde,
+                           trace_elems, (uint32_t)c->row_width, (uint32_t)c->epr, (const uint64_t *)ctx->io[3].p,
+                           (U128 *)ctx->io[4].p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rows_out, ctx->io[4].p, out_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+// fetch digests by id (id < n_rows: leaf; else node id - n_rows) into host memory
+static int fetch_digests(const wf_commitment *c, const std::vector<uint64_t> &ids, uint8_t *out) {
+    if (ids.empty()) return 0;
+    wf_ctx *ctx = c->ctx;
+    int rc;
+    if ((rc = ensure(ctx->io[3], ids.size() * 8))) return rc;
+    if ((rc = ensure(ctx->io[4], ids.size() * 32))) return rc;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->io[3].p, ids.data(), ids.size() * 8, hipMemcpyHostToDevice, st));
+    const uint32_t n = (uint32_t)ids.size();
+    hipLaunchKernelGGL(k_gather_digests, dim3((2 * n + 255) / 256), dim3(256), 0, st, (const uint4 *)c->leaves,
+                       (const uint4 *)c->nodes, c->n_rows, (const uint64_t *)ctx->io[3].p, n, (uint4 *)ctx->io[4].p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, ctx->io[4].p, ids.size() * 32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int wf_commitment_prove(const wf_commitment *c, uint64_t index, uint8_t *path_out) {
+    if (!c || !path_out) return fail(WF_ERR_ARG, "null argument");
+    if (index >= c->n_rows) return fail(WF_ERR_LEAVES, "leaf index out of bounds");  // merkle/mod.rs:193-198
+    HIP_TRY(hipSetDevice(c->ctx->device));
+    std::vector<uint64_t> ids{index, index ^ 1};
+    for (uint64_t i = (index + c->n_rows) >> 1; i > 1; i >>= 1) ids.push_back(c->n_rows + (i ^ 1));
+    return fetch_digests(c, ids, path_out);
+}
+
+int wf_commitment_prove_batch(const wf_commitment *c, const uint64_t *positions, size_t n, uint8_t *leaves_out,
+                              uint8_t *nodes_out, size_t nodes_capacity, uint32_t *node_counts, size_t *n_vectors,
+                              size_t *n_nodes, uint32_t *depth_out) {
+    int rc = check_positions(c, positions, n);
+    if (rc) return rc;
+    if (!leaves_out || !nodes_out || !node_counts || !n_vectors || !n_nodes) return fail(WF_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(c->ctx->device));
+    // map_indexes (merkle/mod.rs:376-395): duplicates are an error
+    std::map<uint64_t, size_t> index_map;
+    for (size_t i = 0; i < n; i++) index_map[positions[i]] = i;
+    if (index_map.size() != n) return fail(WF_ERR_LEAVES, "list of positions contains duplicates");  // DuplicateLeafIndex
+    // normalize_indexes (:397-403): sorted set of even-aligned indexes
+    std::vector<uint64_t> idx;
+    for (auto &kv : index_map) {
+        uint64_t e = kv.first - (kv.first & 1);
+        if (idx.empty() || idx.back() != e) idx.push_back(e);
+    }
+    // ids of the digests of each vector, in the order prove_batch pushes them (:238-276)
+    std::vector<std::vector<uint64_t>> vec_ids(idx.size());
+    std::vector<uint64_t> next;
+    const uint64_t nl = c->n_rows;
+    for (size_t i = 0; i < idx.size(); i++) {
+        for (uint64_t j = idx[i]; j < idx[i] + 2; j++)
+            if (!index_map.count(j)) vec_ids[i].push_back(j);  // leaf id
+        next.push_back((idx[i] + nl) >> 1);
+    }
+    for (uint32_t lvl = 1; lvl < c->depth; lvl++) {
+        std::vector<uint64_t> cur = next;
+        next.clear();
+        size_t i = 0;
+        while (i < cur.size()) {
+            const uint64_t sibling = cur[i] ^ 1;
+            if (i + 1 < cur.size() && cur[i + 1] == sibling)
+                i += 1;
+            else
+                vec_ids[i].push_back(nl + sibling);  // note: indexed by position in the current list, as the reference does
+            next.push_back(sibling >> 1);
+            i += 1;
+        }
+    }
+    size_t total = 0;
+    for (auto &v : vec_ids) total += v.size();
+    if (total > nodes_capacity) return fail(WF_ERR_ARG, "nodes_out too small: %zu digests needed", total);
+    std::vector<uint64_t> ids;
+    for (size_t i = 0; i < n; i++) ids.push_back(positions[i]);
+    for (auto &v : vec_ids) ids.insert(ids.end(), v.begin(), v.end());
+    std::vector<uint8_t> buf(ids.size() * 32);
+    rc = fetch_digests(c, ids, buf.data());
+    if (rc) return rc;
+    memcpy(leaves_out, buf.data(), n * 32);
+    memcpy(nodes_out, buf.data() + n * 32, total * 32);
+    for (size_t i = 0; i < vec_ids.size(); i++) node_counts[i] = (uint32_t)vec_ids[i].size();
+    *n_vectors = vec_ids.size();
+    *n_nodes = total;
+    if (depth_out) *depth_out = c->depth;
+    return 0;
+}
+
 int wf_evaluate_polys_over(wf_ctx *ctx, const wf_params *p, const void *const *poly_cols, void *lde_out) {
     return wf_constraint_commit(ctx, p, poly_cols, lde_out, nullptr, nullptr, nullptr);
 }

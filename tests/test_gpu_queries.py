@@ -1,0 +1,83 @@
+"""GPU: resident commitments and the query service (rows + Merkle proofs read from HBM).
+
+Reference behaviour: TraceCommitment::query / build_segment_queries (prover/src/trace/commitment.rs:87-111,135-190),
+ConstraintCommitment::query (prover/src/constraints/commitment.rs:54-69), MerkleTree::prove / prove_batch
+(crypto/src/merkle/mod.rs:192-284); proof checks as in crypto/src/merkle/tests.rs:94-131,154-208."""
+import numpy as np
+import pytest
+
+from conftest import rand_cols
+
+pytestmark = pytest.mark.gpu
+F64, F128 = 1, 2
+
+
+@pytest.mark.parametrize("field,ext,logR,logB,n_cols,n_traces", [
+    (F64, 1, 10, 3, 8, 1), (F64, 1, 12, 2, 5, 3), (F128, 1, 9, 3, 10, 2), (F64, 2, 11, 3, 3, 1)])
+def test_resident_trace_commitment_queries(ctx, orc, capi, field, ext, logR, logB, n_cols, n_traces):
+    rng = np.random.default_rng(11 * logR + n_cols)
+    traces = [rand_cols(rng, field, n_cols, (1 << logR) * ext) for _ in range(n_traces)]
+    offset = 7 if field == F64 else 3
+    want = orc.build_trace_commitment(field, traces, ext, logR, logB, offset)
+    params = capi.make_params(field, ext, logR, logB, n_cols, n_traces)
+    com, polys = ctx.trace_commit_resident(params, [c for t in traces for c in t], want_polys=True)
+    N, epr = 1 << (logR + logB), n_cols * ext
+    assert com.root() == want["root"]
+    assert (com.n_rows, com.row_elems, com.depth) == (N, epr * n_traces, logR + logB)
+    for t in range(n_traces):
+        for c in range(n_cols):
+            assert np.array_equal(polys[t * n_cols + c], want["polys"][t][c])
+
+    # rows: row p of trace 0 || trace 1 || ..  (comb_states of build_segment_queries)
+    positions = [0, 1, N - 1, 5, 4, N // 2 + 3] + [int(x) for x in rng.choice(N, size=40, replace=False)]
+    positions = list(dict.fromkeys(positions))
+    rows = com.read_rows(positions)
+    for i, p in enumerate(positions):
+        for t in range(n_traces):
+            assert np.array_equal(rows[i, t * epr:(t + 1) * epr], want["lde"][t][p, :epr])
+        # the queried rows hash to the committed leaf (what the verifier re-checks, air/src/proof/queries.rs:128)
+        assert orc.hash_elements(field, rows[i]) == bytes(want["leaves"][p])
+
+    # single paths
+    for p in positions[:8]:
+        proof = com.prove(p)
+        assert proof == orc.merkle_prove(want["nodes"], want["leaves"], p)
+        assert orc.merkle_verify(want["root"], p, proof)
+
+    # batch ("octopus") proofs, including adjacent positions and a single position
+    for sel in (positions, positions[:1], [6, 7], [N - 2, N - 1, 0], sorted(positions)[:17]):
+        got = com.prove_batch(sel)
+        assert got == orc.merkle_prove_batch(want["nodes"], want["leaves"], sel)
+    com.close()
+
+
+def test_resident_constraint_commitment(ctx, orc, capi):
+    rng = np.random.default_rng(3)
+    polys = rand_cols(rng, F64, 4, (1 << 10) * 2)
+    want = orc.build_constraint_commitment(F64, polys, 2, 10, 3, 7)
+    com = ctx.constraint_commit_resident(capi.make_params(F64, 2, 10, 3, 4, 1), polys)
+    assert com.root() == want["root"]
+    pos = [3, 8191, 77, 4096]
+    rows = com.read_rows(pos)
+    for i, p in enumerate(pos):
+        assert np.array_equal(rows[i], want["lde"][p, :8])
+    assert com.prove_batch(pos) == orc.merkle_prove_batch(want["nodes"], want["leaves"], pos)
+    com.close()
+
+
+def test_query_errors(ctx, capi):
+    rng = np.random.default_rng(4)
+    cols = rand_cols(rng, F64, 2, 64)
+    com, _ = ctx.trace_commit_resident(capi.make_params(F64, 1, 6, 1, 2, 1), cols)
+    for bad, code in (([], -19), (list(range(128)) * 2, -19), ([1, 1], -18), ([128], -18)):
+        with pytest.raises(capi.WfError) as e:
+            com.prove_batch(bad)
+        assert e.value.code == code
+    with pytest.raises(capi.WfError) as e:
+        com.read_rows([500])
+    assert e.value.code == -18
+    with pytest.raises(capi.WfError) as e:
+        com.prove(128)
+    assert e.value.code == -18
+    assert len(com.prove_batch(list(range(128)))[0]) == 128   # every leaf: no internal nodes needed
+    com.close()
