@@ -133,6 +133,21 @@ int wf_trace_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_trace, vo
 int wf_constraint_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_polys, void *d_lde, void *d_leaves,
                              void *d_nodes, void *stream);
 
+/* ---- the path, coset-sharded over several GPUs (device buffers) ----------------------------------------------------- */
+
+/* One STARKPack commitment (n_traces packed traces, ONE tree) spread over W GPUs by coset: the LDE
+ * of size R*blowup is `blowup` independent coset evaluations, and coset c owns exactly the rows j = k*blowup + c.
+ * Each rank calls this with its coset range and gets
+ *   d_lde_shard    : [n_traces] matrices of (R * coset_count) rows x row_width, local row k*coset_count + (c - begin)
+ *   d_leaves_shard : R * coset_count digests in the same local order (each leaf needs only its own row of every trace)
+ * d_polys may be NULL.  The ranks then all-gather the leaf shards (the path's one exchange, RCCL), interleave them
+ * to natural order (shard.interleave_leaf_shards) and build the tree with wf_merkle_build_dev. */
+int wf_trace_commit_shard_dev(wf_ctx *ctx, const wf_params *p, uint32_t coset_begin, uint32_t coset_count,
+                              const void *d_trace, void *d_polys, void *d_lde_shard, void *d_leaves_shard,
+                              void *stream);
+/* MerkleTree::new on device buffers (leaves -> nodes), asynchronous on `stream`. */
+int wf_merkle_build_dev(wf_ctx *ctx, const void *d_leaves, size_t n_leaves, void *d_nodes, void *stream);
+
 /* ---- the path, resident form: commitment stays in HBM, queries are served from there -------------------------------- */
 
 /* Opaque device-resident commitment: the LDE matrices of all traces, the leaves and the tree nodes (what

@@ -20,7 +20,7 @@ SYMBOLS = [
     "wf_ctx_create", "wf_ctx_destroy", "wf_last_error", "wf_device_count", "wf_ctx_synchronize", "wf_ctx_stream",
     "wf_ctx_profile_enable", "wf_ctx_profile_read", "wf_params_check", "wf_elem_bytes", "wf_row_width", "wf_column_bytes", "wf_lde_bytes", "wf_digests_bytes",
     "wf_trace_commit", "wf_constraint_commit", "wf_trace_commit_dev", "wf_constraint_commit_dev",
-    "wf_trace_commit_resident", "wf_constraint_commit_resident", "wf_commitment_destroy", "wf_commitment_root",
+    "wf_trace_commit_shard_dev", "wf_merkle_build_dev", "wf_trace_commit_resident", "wf_constraint_commit_resident", "wf_commitment_destroy", "wf_commitment_root",
     "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_prove", "wf_commitment_prove_batch",
     "wf_fft_evaluate_poly", "wf_fft_evaluate_poly_with_offset", "wf_fft_interpolate_poly",
     "wf_fft_interpolate_poly_with_offset", "wf_evaluate_polys_over", "wf_hash_rows", "wf_merkle_build",
@@ -52,6 +52,28 @@ def make_params(field, ext_degree, log2_trace_len, log2_blowup, n_cols, n_traces
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7; a process can only hold one HIP runtime, and it must be
+    the one torch was built with if torch is used later in the same process (device buffers, RCCL).  Loading torch's
+    copy first makes libwf_lde.so bind to it as well (same SONAME), whatever the import order."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """dlopen libwf_lde.so (raises if it has not been built)."""
     global _lib
@@ -59,6 +81,7 @@ def load():
         path = lib_path()
         if not os.path.exists(path):
             raise WfError(-30, f"{path} not built (run __graft_entry__.build() / make -C csrc)")
+        _preload_torch_hip_runtime()
         L = C.CDLL(path)
         vp, sz, u32, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int
         PP = C.POINTER(Params)
@@ -81,6 +104,8 @@ def load():
         L.wf_constraint_commit.argtypes = [vp, PP, vp, vp, vp, vp, vp]
         L.wf_trace_commit_dev.argtypes = [vp, PP, vp, vp, vp, vp, vp, vp]
         L.wf_constraint_commit_dev.argtypes = [vp, PP, vp, vp, vp, vp, vp]
+        L.wf_trace_commit_shard_dev.argtypes = [vp, PP, u32, u32, vp, vp, vp, vp, vp]
+        L.wf_merkle_build_dev.argtypes = [vp, vp, sz, vp, vp]
         L.wf_trace_commit_resident.argtypes = [vp, PP, vp, vp, C.POINTER(vp)]
         L.wf_constraint_commit_resident.argtypes = [vp, PP, vp, C.POINTER(vp)]
         L.wf_commitment_destroy.argtypes = [vp]
@@ -207,6 +232,14 @@ class Context:
                               stream: int = 0):
         _check(load().wf_constraint_commit_dev(self._h, C.byref(params), d_polys, d_lde, d_leaves, d_nodes,
                                                stream or None))
+
+    def trace_commit_shard_dev(self, params: Params, coset_begin: int, coset_count: int, d_trace: int, d_polys: int,
+                               d_lde_shard: int, d_leaves_shard: int, stream: int = 0):
+        _check(load().wf_trace_commit_shard_dev(self._h, C.byref(params), coset_begin, coset_count, d_trace,
+                                                d_polys or None, d_lde_shard, d_leaves_shard, stream or None))
+
+    def merkle_build_dev(self, d_leaves: int, n_leaves: int, d_nodes: int, stream: int = 0):
+        _check(load().wf_merkle_build_dev(self._h, d_leaves, n_leaves, d_nodes, stream or None))
 
     # -- the path, resident form -------------------------------------------------------------------------------------
     def trace_commit_resident(self, params: Params, trace_cols, want_polys=False):

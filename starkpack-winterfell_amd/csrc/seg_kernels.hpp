@@ -56,7 +56,8 @@ struct SegArgs {
     // SEG_OUT_ROWS
     uint32_t base_cols;        // base columns per trace
     uint32_t total_base_cols;  // over all traces
-    uint32_t log_blowup;
+    uint32_t coset0;           // first coset computed by this call (coset sharding across GPUs); 0 otherwise
+    uint32_t rows_per_k;       // cosets held by the output matrix: row = k * rows_per_k + local coset (= blowup unless sharded)
     uint64_t row_width;
     uint64_t trace_lde_elems;
 };
@@ -167,8 +168,8 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
 
     Pow2L<F> pre = a.pre;
     if (a.pre_on) {
-        pre.lo += (uint64_t)c * a.pre_lo_stride;
-        pre.hi += (uint64_t)c * a.pre_hi_stride;
+        pre.lo += (uint64_t)(a.coset0 + c) * a.pre_lo_stride;
+        pre.hi += (uint64_t)(a.coset0 + c) * a.pre_hi_stride;
     }
     for (uint32_t e = threadIdx.x; e < D; e += blockDim.x) {
         twd[e] = a.digit_tw[e];
@@ -253,8 +254,8 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
 
     Pow2L<F> pre = a.pre;
     if (a.pre_on) {
-        pre.lo += (uint64_t)c * a.pre_lo_stride;
-        pre.hi += (uint64_t)c * a.pre_hi_stride;
+        pre.lo += (uint64_t)(a.coset0 + c) * a.pre_lo_stride;
+        pre.hi += (uint64_t)(a.coset0 + c) * a.pre_hi_stride;
     }
     for (uint32_t e = threadIdx.x; e < D; e += blockDim.x) {
         twd[e] = a.digit_tw[e];
@@ -291,7 +292,7 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
         for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
             const uint32_t lp = wk & (HP - 1), pos = wk >> hp_shift;
             const uint64_t k = rev_o + ((uint64_t)digit_reverse(pos, a.logD) << out_shift);
-            const uint64_t row = (k << a.log_blowup) + c;
+            const uint64_t row = k * a.rows_per_k + c;
             P2 v = *reinterpret_cast<P2 *>(x + pos * S + 2 * lp);
             const uint32_t B = g * S + 2 * lp;  // global base column of lane a
             if (B >= a.total_base_cols) continue;

@@ -383,7 +383,7 @@ struct SegDesc {
     uint32_t logN, n_seg, n_cosets;
     bool rows_out;
     const TableSet *pre;
-    uint32_t base_cols, total_base_cols, log_blowup;
+    uint32_t base_cols, total_base_cols, coset0;
     uint64_t row_width, trace_lde_elems;
 };
 
@@ -410,7 +410,8 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
     }
     a.base_cols = d.base_cols;
     a.total_base_cols = d.total_base_cols;
-    a.log_blowup = d.log_blowup;
+    a.coset0 = d.coset0;
+    a.rows_per_k = d.n_cosets;
     a.row_width = d.row_width;
     a.trace_lde_elems = d.trace_lde_elems;
     const T inv_n = inverse ? f_inv<F>(F::from_u128_canonical((u128)1 << d.logN)) : F::one();
@@ -610,10 +611,11 @@ static int path_buffers(wf_ctx *ctx, const wf_params *p, PathBufs<F> &b) {
 // coefficients in segB -> row-major LDE -> leaves -> tree
 template <class F>
 static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, const PathBufs<F> &b, void *d_lde,
-                               void *d_leaves, void *d_nodes) {
+                               void *d_leaves, void *d_nodes, uint32_t coset0 = 0, uint32_t n_cosets = 0) {
     typedef typename F::T T;
     const uint32_t W = p->ext_degree, logR = p->log2_trace_len, logB = p->log2_blowup;
-    const uint64_t Nrows = (uint64_t)1 << (logR + logB);
+    if (n_cosets == 0) n_cosets = 1u << logB;  // all of them; otherwise a shard [coset0, coset0 + n_cosets)
+    const uint64_t Nrows = (uint64_t)n_cosets << logR;
     const uint64_t row_width = wf_row_width(p);
     const uint32_t base_cols = p->n_cols * W;
 
@@ -632,12 +634,12 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
     d.out = (T *)d_lde;
     d.logN = logR;
     d.n_seg = b.n_seg;
-    d.n_cosets = 1u << logB;
+    d.n_cosets = n_cosets;
+    d.coset0 = coset0;
     d.rows_out = true;
     d.pre = cos;
     d.base_cols = base_cols;
     d.total_base_cols = b.total_base_cols;
-    d.log_blowup = logB;
     d.row_width = row_width;
     d.trace_lde_elems = Nrows * row_width;
     rc = run_seg_transform<F>(ctx, st, d);
@@ -805,6 +807,68 @@ int wf_constraint_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_poly
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     if (p->field == WF_FIELD_F64) return constraint_commit_dev<F64>(ctx, p, d_polys, d_lde, d_leaves, d_nodes, st);
     return constraint_commit_dev<F128>(ctx, p, d_polys, d_lde, d_leaves, d_nodes, st);
+}
+
+// coset-sharded form (one packed commitment spread over several GPUs) ------------------------------------
+}  // extern "C"
+
+template <class F>
+static int trace_commit_shard_dev(wf_ctx *ctx, const wf_params *p, uint32_t coset0, uint32_t n_cosets,
+                                  const void *d_trace, void *d_polys, void *d_lde, void *d_leaves, hipStream_t st) {
+    PathBufs<F> b;
+    int rc = path_buffers<F>(ctx, p, b);
+    if (rc) return rc;
+    const uint64_t R = (uint64_t)1 << p->log2_trace_len;
+    rc = run_xpose<F>(ctx, st, true, d_trace, b.segA, R, p->ext_degree, b.total_base_cols, b.n_seg);
+    if (rc) return rc;
+    SegDesc<F> d;
+    memset(&d, 0, sizeof(d));
+    d.in = b.segA;
+    d.work = b.segA;
+    d.out = b.segB;
+    d.logN = p->log2_trace_len;
+    d.n_seg = b.n_seg;
+    d.n_cosets = 1;
+    d.rows_out = false;
+    rc = run_seg_transform<F>(ctx, st, d);
+    if (rc) return rc;
+    if (d_polys) {
+        rc = run_xpose<F>(ctx, st, false, b.segB, d_polys, R, p->ext_degree, b.total_base_cols, b.n_seg);
+        if (rc) return rc;
+    }
+    return evaluate_and_commit<F>(ctx, st, p, b, d_lde, d_leaves, nullptr, coset0, n_cosets);
+}
+
+extern "C" {
+
+int wf_trace_commit_shard_dev(wf_ctx *ctx, const wf_params *p, uint32_t coset_begin, uint32_t coset_count,
+                              const void *d_trace, void *d_polys, void *d_lde_shard, void *d_leaves_shard,
+                              void *stream) {
+    if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
+    int rc = check_params(p, false);
+    if (rc) return rc;
+    if (!d_trace || !d_lde_shard || !d_leaves_shard) return fail(WF_ERR_ARG, "null device buffer");
+    const uint32_t blowup = 1u << p->log2_blowup;
+    if (coset_count == 0 || coset_begin >= blowup || coset_count > blowup - coset_begin)
+        return fail(WF_ERR_ARG, "coset range [%u, %u) is not inside [0, %u)", coset_begin, coset_begin + coset_count, blowup);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (p->field == WF_FIELD_F64)
+        return trace_commit_shard_dev<F64>(ctx, p, coset_begin, coset_count, d_trace, d_polys, d_lde_shard, d_leaves_shard, st);
+    return trace_commit_shard_dev<F128>(ctx, p, coset_begin, coset_count, d_trace, d_polys, d_lde_shard, d_leaves_shard, st);
+}
+
+int wf_merkle_build_dev(wf_ctx *ctx, const void *d_leaves, size_t n_leaves, void *d_nodes, void *stream) {
+    if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
+    if (!d_leaves || !d_nodes) return fail(WF_ERR_ARG, "null device buffer");
+    if (n_leaves < 2) return fail(WF_ERR_LEAVES, "a tree must have at least 2 leaves");
+    if (n_leaves & (n_leaves - 1)) return fail(WF_ERR_LEAVES, "number of leaves must be a power of two");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    prof_mark(ctx, st, "merkle");
+    int rc = run_merkle(st, d_leaves, n_leaves, d_nodes);
+    prof_mark(ctx, st, "between_calls");
+    return rc;
 }
 
 // host-buffer form -------------------------------------------------------------------------------------------------

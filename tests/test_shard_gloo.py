@@ -64,3 +64,52 @@ def test_partition_and_seeds():
     assert len(seeds) == 64
     one = torch.zeros((1, 32), dtype=torch.uint8)
     assert torch.equal(shard.all_gather_roots(one), one)                  # world 1: identity, no process group
+
+
+def _leaf_worker(rank, world, port, out_q):
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from starkpack_winterfell_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # every rank derives the same "full" natural-order leaves and keeps only the rows of its cosets
+    R, blowup = 64, 8
+    full = (np.arange(R * blowup * 32, dtype=np.int64) * 2654435761 % 251).astype(np.uint8).reshape(R * blowup, 32)
+    c0, nc = shard.cosets_of_rank(blowup, rank, world)
+    local = full.reshape(R, blowup, 32)[:, c0:c0 + nc].reshape(R * nc, 32)
+    got = shard.all_gather_leaf_shards(torch.from_numpy(local.copy()), R, nc)
+    out_q.put((rank, bool((got.numpy() == full).all())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_leaf_shards_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_leaf_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results == [(0, True), (1, True)]
+
+
+def test_coset_partition():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import pytest
+    from starkpack_winterfell_amd import shard
+    assert [shard.cosets_of_rank(8, r, 4) for r in range(4)] == [(0, 2), (2, 2), (4, 2), (6, 2)]
+    assert shard.cosets_of_rank(8, 0, 1) == (0, 8)
+    with pytest.raises(ValueError):
+        shard.cosets_of_rank(8, 0, 3)
+    g = torch.arange(2 * 4 * 3 * 32, dtype=torch.int64).remainder(256).to(torch.uint8).view(-1, 32)
+    out = shard.interleave_leaf_shards(g, 2, 4, 3)     # world 2, R = 4, 3 cosets per rank
+    v = g.view(2, 4, 3, 32)
+    assert torch.equal(out.view(4, 6, 32)[1, 4], v[1, 1, 1]) and torch.equal(out.view(4, 6, 32)[3, 2], v[0, 3, 2])
