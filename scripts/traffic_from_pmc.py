@@ -1,0 +1,54 @@
+"""Builds profiles/traffic.json from two rocprofv3 --pmc runs of bench.py (FETCH_SIZE and WRITE_SIZE in separate
+passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes).
+
+    python scripts/traffic_from_pmc.py <fetch counter_collection.csv> <write counter_collection.csv> <round tag>
+
+gfx950 corrections (guide, section HBM): WRITE_SIZE is exact for 16-byte-per-lane streaming stores.  FETCH_SIZE
+tallies 128-byte requests at 64 bytes, so it is doubled for kernels whose wave-instructions read >= 128 contiguous
+bytes (last passes, hashing, Merkle levels, layout changes); the strided passes gather isolated 64-byte rows
+(64-byte requests, counted exactly) and are not doubled.  Calibration: evaluate.last_pass must read the 512 MiB
+intermediate exactly once (raw counter: 256 MiB)."""
+import collections
+import csv
+import json
+import sys
+
+LOGICAL = [
+    ("interpolate", ["k_cols_to_seg", "k_seg_strided<wf::F64, 0>", "k_seg_last<wf::F64, 0>", "k_seg_to_cols"]),
+    ("evaluate", ["k_seg_strided<wf::F64, 1>", "k_seg_last<wf::F64, 1>"]),
+    ("hash_rows", ["k_hash_rows"]),
+    ("merkle", ["k_merkle_level", "k_merkle_subtree"]),
+]
+NO_DOUBLE = ("k_seg_strided",)
+
+
+def per_kernel(path, counter):
+    tot, calls = collections.Counter(), collections.Counter()
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter or "wf::" not in r["Kernel_Name"]:
+            continue
+        tot[r["Kernel_Name"]] += float(r["Counter_Value"])
+        calls[r["Kernel_Name"]] += 1
+    return tot, calls
+
+
+def main():
+    fetch, fcalls = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
+    steps = fcalls[next(k for k in fcalls if "k_hash_rows" in k)]  # one hash launch per commitment
+    out = {"_note": "HBM bytes per commitment (cfg 2) from rocprofv3 PMC; see scripts/traffic_from_pmc.py for the "
+                    "gfx950 corrections", "_round": sys.argv[3], "_steps_profiled": steps}
+    for name, pats in LOGICAL:
+        rd = wr = 0.0
+        for k in fetch:
+            if any(p in k for p in pats):
+                mult = 1.0 if any(n in k for n in NO_DOUBLE) else 2.0
+                rd += fetch[k] * 1024 * mult / steps
+                wr += write.get(k, 0.0) * 1024 / steps
+        out[name] = {"read_bytes_per_step": rd, "write_bytes_per_step": wr, "hbm_bytes_per_step": rd + wr}
+    out["path_total"] = sum(v["hbm_bytes_per_step"] for k, v in out.items() if not k.startswith("_"))
+    json.dump(out, open("profiles/traffic.json", "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+main()

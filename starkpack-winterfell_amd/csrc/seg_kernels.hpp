@@ -143,7 +143,9 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
 
 // ---------------------------------------------------------------------------------------------------------------
 // Strided pass.  grid.x = n_cosets * n_seg * O * I ; work-group = (coset c, segment g, outer o, inner i)
-template <class F>
+// EVAL only tags the instantiation (interpolation = 0 / coset evaluation = 1) so that profilers list the two uses
+// under different kernel names, like k_seg_last<F, OUT>.
+template <class F, int EVAL>
 __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
     typedef typename F::T T;
     typedef Pair<T> P2;

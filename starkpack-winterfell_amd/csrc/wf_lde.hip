@@ -362,7 +362,8 @@ static int seg_launch_dims(uint32_t logD, uint32_t &threads, size_t &lds) {
     if (lds > 160 * 1024) return fail(WF_ERR_ARG, "internal: pass needs %zu bytes of LDS", lds);
     threads = logD >= 9 ? 512 : 256;
     if (lds > 64 * 1024) {
-        HIP_TRY(hipFuncSetAttribute((const void *)k_seg_strided<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_seg_strided<F, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_seg_strided<F, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_TRY(hipFuncSetAttribute((const void *)k_seg_last<F, SEG_OUT_SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_TRY(hipFuncSetAttribute((const void *)k_seg_last<F, SEG_OUT_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
@@ -447,7 +448,10 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         const uint64_t grid = (uint64_t)d.n_cosets * d.n_seg * a.O * a.I;
         if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
         prof_mark(ctx, st, tag_s);
-        hipLaunchKernelGGL(k_seg_strided<F>, dim3((uint32_t)grid), dim3(threads), lds, st, a);
+        if (d.rows_out)
+            hipLaunchKernelGGL((k_seg_strided<F, 1>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
+        else
+            hipLaunchKernelGGL((k_seg_strided<F, 0>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
         HIP_TRY(hipGetLastError());
         done_bits += a.logD;
     }
