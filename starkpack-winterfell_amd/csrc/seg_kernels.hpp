@@ -62,15 +62,89 @@ struct SegArgs {
     uint64_t trace_lde_elems;
 };
 
-// radix-4 / radix-2 rounds on x[D][S] with two lanes per work item; twd[e] = w_D^e
+// LDS position -> output index of seg_lds_ntt: radix-16 digits while >= 4 bits remain, then radix-4, then radix-2
+__device__ __forceinline__ uint32_t seg_digit_reverse(uint32_t pos, uint32_t logD) {
+    uint32_t k = 0, cur = logD, sh = 0;
+    while (cur >= 4) {
+        k |= ((pos >> (cur - 4)) & 15u) << sh;
+        sh += 4;
+        cur -= 4;
+    }
+    while (cur >= 2) {
+        k |= ((pos >> (cur - 2)) & 3u) << sh;
+        sh += 2;
+        cur -= 2;
+    }
+    if (cur == 1) k |= (pos & 1u) << sh;
+    return k;
+}
+
+__host__ __device__ constexpr uint32_t bitrev4(uint32_t v) {
+    return ((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3);
+}
+
+// 16-point DFT in registers (decimation in frequency, constants w[j] = w_16^j): v[bitrev4(k)] = sum_a x_a w_16^(a k)
+template <class F>
+__device__ __forceinline__ void radix16(typename F::T (&v)[16], const typename F::T (&w)[8]) {
+    typedef typename F::T T;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int q = 0; q < 16; q += 2 * half) {
+#pragma unroll
+            for (int i = 0; i < half; i++) {
+                const T u = v[q + i], t = v[q + i + half];
+                v[q + i] = F::add(u, t);
+                T dlt = F::sub(u, t);
+                if (i != 0) dlt = F::mul(dlt, w[i << s]);
+                v[q + i + half] = dlt;
+            }
+        }
+    }
+}
+
+// In-place transform of x[D][S] in LDS; twd[e] = w_D^e.  Rounds: radix-16 (one lane per work item, 16 values in
+// registers) while >= 4 bits remain, then radix-4 / radix-2 (two lanes per item).  Natural order in,
+// seg_digit_reverse order out.
 template <class F>
 __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::T *twd, uint32_t logD) {
     typedef typename F::T T;
     typedef Pair<T> P2;
     constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;
     constexpr uint32_t hp_shift = HP == 4 ? 2 : 1;
+    constexpr uint32_t s_shift = S == 8 ? 3 : 2;
     const uint32_t D = 1u << logD;
     uint32_t cur = logD;
+    if (logD >= 4) {
+        T w16[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) w16[j] = twd[j * (D >> 4)];
+        while (cur >= 4) {
+            const uint32_t mlog = cur - 4, m = 1u << mlog;
+            const uint32_t nwork = (D >> 4) * S;
+            const uint32_t tshift = logD - cur;
+            const uint32_t st = m * S;
+            for (uint32_t wk = threadIdx.x; wk < nwork; wk += blockDim.x) {
+                const uint32_t l = wk & (S - 1), u = wk >> s_shift;
+                const uint32_t jp = u & (m - 1), p = u >> mlog;
+                const uint32_t base = (((p << cur) + jp) * S) + l;
+                T v[16];
+#pragma unroll
+                for (int a = 0; a < 16; a++) v[a] = x[base + a * st];
+                radix16<F>(v, w16);
+                if (jp != 0) {
+                    const uint32_t e = jp << tshift;
+#pragma unroll
+                    for (int k = 1; k < 16; k++) v[bitrev4(k)] = F::mul(v[bitrev4(k)], twd[e * k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 16; k++) x[base + k * st] = v[bitrev4(k)];
+            }
+            cur -= 4;
+            __syncthreads();
+        }
+    }
     T w4 = F::one();
     if (logD >= 2) w4 = twd[D >> 2];
     while (cur > 0) {
@@ -146,7 +220,7 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
 // EVAL only tags the instantiation (interpolation = 0 / coset evaluation = 1) so that profilers list the two uses
 // under different kernel names, like k_seg_last<F, OUT>.
 template <class F, int EVAL>
-__global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
+__global__ void __launch_bounds__(512) k_seg_strided(SegArgs<F> a) {
     typedef typename F::T T;
     typedef Pair<T> P2;
     constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;
@@ -210,7 +284,7 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
     __syncthreads();
     for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
         const uint32_t lp = wk & (HP - 1), pos = wk >> hp_shift;
-        const uint32_t k = digit_reverse(pos, a.logD);
+        const uint32_t k = seg_digit_reverse(pos, a.logD);
         P2 v = *reinterpret_cast<P2 *>(x + pos * S + 2 * lp);
         const T f = aux[k];
         v.a = F::mul(v.a, f);
@@ -222,7 +296,7 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
 // ---------------------------------------------------------------------------------------------------------------
 // Last pass.  grid.x = n_cosets * n_seg * O ; work-group = (coset c, segment g, row block o) of D contiguous rows.
 template <class F, int OUT>
-__global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
+__global__ void __launch_bounds__(512) k_seg_last(SegArgs<F> a) {
     typedef typename F::T T;
     typedef Pair<T> P2;
     constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;
@@ -282,7 +356,7 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
         T *dst = a.dst + ((uint64_t)c * a.n_seg + g) * seg_elems;
         for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
             const uint32_t lp = wk & (HP - 1), pos = wk >> hp_shift;
-            const uint64_t k = rev_o + ((uint64_t)digit_reverse(pos, a.logD) << out_shift);
+            const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse(pos, a.logD) << out_shift);
             P2 v = *reinterpret_cast<P2 *>(x + pos * S + 2 * lp);
             if (a.scale_on) {
                 v.a = F::mul(v.a, a.scale);
@@ -293,7 +367,7 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
     } else {
         for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
             const uint32_t lp = wk & (HP - 1), pos = wk >> hp_shift;
-            const uint64_t k = rev_o + ((uint64_t)digit_reverse(pos, a.logD) << out_shift);
+            const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse(pos, a.logD) << out_shift);
             const uint64_t row = k * a.rows_per_k + c;
             P2 v = *reinterpret_cast<P2 *>(x + pos * S + 2 * lp);
             const uint32_t B = g * S + 2 * lp;  // global base column of lane a
