@@ -183,6 +183,27 @@ int wf_commitment_prove_batch(const wf_commitment *c, const uint64_t *positions,
                               uint8_t *nodes_out, size_t nodes_capacity, uint32_t *node_counts, size_t *n_vectors,
                               size_t *n_nodes, uint32_t *depth_out);
 
+/* ---- FRI layer commitments ---------------------------------------------------------------------- */
+
+/* The commit half of FriProver::build_layer (fri/src/prover/mod.rs:191-203): `evals` = n elements of E (the current
+ * layer's evaluations) -> transpose_slice into n/folding rows of `folding` elements (utils/core/src/lib.rs:206-227)
+ * -> hash_values (fri/src/utils.rs:41-50) -> MerkleTree::new.  folding in {2,4,8,16} (prover/mod.rs:178-185).
+ * Outputs (each may be NULL): the transposed matrix (what FriLayer keeps as `evaluations`), leaves, nodes, root.
+ * The root goes to the channel on the host, which draws alpha (out of scope here). */
+int wf_fri_layer_commit(wf_ctx *ctx, uint32_t field, uint32_t ext_degree, const void *evals, size_t n,
+                        uint32_t folding, void *transposed_out, uint8_t *leaves_out, uint8_t *nodes_out,
+                        uint8_t *root_out);
+/* folding::apply_drp (fri/src/folding/mod.rs:85-117): rows x folding transposed evaluations, the domain offset and
+ * alpha (one element of E, in-memory representation) -> the next layer's `rows` evaluations. */
+int wf_fri_apply_drp(wf_ctx *ctx, uint32_t field, uint32_t ext_degree, const void *transposed, size_t rows,
+                     uint32_t folding, const uint8_t domain_offset[16], const void *alpha, void *out);
+/* Device-buffer forms, asynchronous on `stream` (alpha stays a host pointer: it is a kernel argument). */
+int wf_fri_layer_commit_dev(wf_ctx *ctx, uint32_t field, uint32_t ext_degree, const void *d_evals, size_t n,
+                            uint32_t folding, void *d_transposed, void *d_leaves, void *d_nodes, void *stream);
+int wf_fri_apply_drp_dev(wf_ctx *ctx, uint32_t field, uint32_t ext_degree, const void *d_transposed, size_t rows,
+                         uint32_t folding, const uint8_t domain_offset[16], const void *alpha, void *d_out,
+                         void *stream);
+
 /* ---- building blocks (each mirrors one reference function; host buffers) ---------------------------------------- */
 
 /* fft::evaluate_poly (math/src/fft/mod.rs:85): in place, n elements of ext_degree coordinates, natural order. */

@@ -22,8 +22,48 @@
 #include "field_f128.h"
 #include "field_f64.h"
 
+/* ------------------------------------------------------------------ extension-field products
+ * f64 quadratic  x^2 - x + 2 : math/src/field/f64/mod.rs:401-417
+ * f64 cubic      x^3 - x - 1 : math/src/field/f64/mod.rs:446-472
+ * f128 quadratic x^2 - x - 1 : math/src/field/f128/mod.rs:273-279 (no cubic extension: :296-314) */
+static inline void f64_ext_mul(size_t ext, const uint64_t *a, const uint64_t *b, uint64_t *out) {
+    if (ext == 1) {
+        out[0] = f64_mul(a[0], b[0]);
+    } else if (ext == 2) {
+        uint64_t a0b0 = f64_mul(a[0], b[0]), a1b1 = f64_mul(a[1], b[1]);
+        uint64_t o0 = f64_sub(a0b0, f64_add(a1b1, a1b1));
+        uint64_t o1 = f64_sub(f64_mul(f64_add(a[0], a[1]), f64_add(b[0], b[1])), a0b0);
+        out[0] = o0;
+        out[1] = o1;
+    } else {
+        uint64_t a0b0 = f64_mul(a[0], b[0]), a1b1 = f64_mul(a[1], b[1]), a2b2 = f64_mul(a[2], b[2]);
+        uint64_t s01 = f64_mul(f64_add(a[0], a[1]), f64_add(b[0], b[1]));
+        uint64_t s02 = f64_mul(f64_add(a[0], a[2]), f64_add(b[0], b[2]));
+        uint64_t s12 = f64_mul(f64_add(a[1], a[2]), f64_add(b[1], b[2]));
+        uint64_t d01 = f64_sub(a0b0, a1b1);
+        uint64_t o0 = f64_sub(f64_add(s12, d01), a2b2);
+        uint64_t o1 = f64_sub(f64_sub(f64_add(s01, s12), f64_add(a1b1, a1b1)), a0b0);
+        uint64_t o2 = f64_sub(s02, d01);
+        out[0] = o0;
+        out[1] = o1;
+        out[2] = o2;
+    }
+}
+static inline void f128_ext_mul(size_t ext, const f128e *a, const f128e *b, f128e *out) {
+    if (ext == 1) {
+        out[0] = f128_mul(a[0], b[0]);
+    } else {
+        f128e z = f128_mul(a[0], b[0]);
+        f128e o0 = f128_add(z, f128_mul(a[1], b[1]));
+        f128e o1 = f128_sub(f128_mul(f128_add(a[0], a[1]), f128_add(b[0], b[1])), z);
+        out[0] = o0;
+        out[1] = o1;
+    }
+}
+
 /* ------------------------------------------------------------------ f64 instantiation */
 #define FE uint64_t
+#define EXT_MUL(ext, a, b, out) f64_ext_mul((ext), (a), (b), (out))
 #define FN(x) orc_f64_##x
 #define FE_ADD(a, b) f64_add((a), (b))
 #define FE_SUB(a, b) f64_sub((a), (b))
@@ -48,9 +88,11 @@
 #undef FE_EXP_U64
 #undef FE_ROOT
 #undef FE_TWO_ADICITY
+#undef EXT_MUL
 
 /* ------------------------------------------------------------------ f128 instantiation */
 #define FE f128e
+#define EXT_MUL(ext, a, b, out) f128_ext_mul((ext), (a), (b), (out))
 #define FN(x) orc_f128_##x
 #define FE_ADD(a, b) f128_add((a), (b))
 #define FE_SUB(a, b) f128_sub((a), (b))
@@ -273,6 +315,30 @@ int orc_f128_evaluate_polys_over_p(const void *const *polys, size_t n_cols, size
     f128e o;
     memcpy(&o, off, 16);
     return orc_f128_evaluate_polys_over((const f128e *const *)polys, n_cols, ext, R, blowup, o, (f128e *)out, threads);
+}
+
+/* extension products and FRI helpers, pointer-typed for ctypes */
+void orc_ext_mul(int field, size_t ext, const void *a, const void *b, void *out) {
+    if (field == ORC_FIELD_F64)
+        f64_ext_mul(ext, (const uint64_t *)a, (const uint64_t *)b, (uint64_t *)out);
+    else
+        f128_ext_mul(ext, (const f128e *)a, (const f128e *)b, (f128e *)out);
+}
+void orc_transpose_slice(int field, const void *src, size_t n, size_t ext, size_t N, void *out) {
+    if (field == ORC_FIELD_F64)
+        orc_f64_transpose_slice((const uint64_t *)src, n, ext, N, (uint64_t *)out);
+    else
+        orc_f128_transpose_slice((const f128e *)src, n, ext, N, (f128e *)out);
+}
+void orc_apply_drp(int field, const void *values, size_t rows, size_t ext, size_t N, const uint8_t offset_le[16],
+                   const void *alpha, void *out, int threads) {
+    f128e off;
+    memcpy(&off, offset_le, 16);
+    if (field == ORC_FIELD_F64)
+        orc_f64_apply_drp((const uint64_t *)values, rows, ext, N, f64_new((uint64_t)off), (const uint64_t *)alpha,
+                          (uint64_t *)out, threads);
+    else
+        orc_f128_apply_drp((const f128e *)values, rows, ext, N, off, (const f128e *)alpha, (f128e *)out, threads);
 }
 
 int orc_max_threads(void) { return omp_get_max_threads(); }

@@ -82,6 +82,19 @@ int orc_build_constraint_commitment(int field, size_t ext, unsigned log2_R, unsi
                                     const uint8_t offset_le[16], const void *const *poly_cols, void *lde_out,
                                     uint8_t *leaves, uint8_t *nodes, int threads);
 
+/* --- extension fields and FRI layer pieces (fri/src/prover/mod.rs:191-226, fri/src/folding/mod.rs:85-117) */
+void orc_ext_mul(int field, size_t ext, const void *a, const void *b, void *out);
+void orc_transpose_slice(int field, const void *src, size_t n, size_t ext, size_t N, void *out);
+void orc_apply_drp(int field, const void *values, size_t rows, size_t ext, size_t N, const uint8_t offset_le[16],
+                   const void *alpha, void *out, int threads);
+void orc_f64_transpose_slice(const uint64_t *src, size_t n, size_t ext, size_t N, uint64_t *out);
+void orc_f64_apply_drp(const uint64_t *values, size_t rows, size_t ext, size_t N, uint64_t domain_offset,
+                       const uint64_t *alpha, uint64_t *out, int threads);
+void orc_f128_transpose_slice(const unsigned __int128 *src, size_t n, size_t ext, size_t N, unsigned __int128 *out);
+void orc_f128_apply_drp(const unsigned __int128 *values, size_t rows, size_t ext, size_t N,
+                        unsigned __int128 domain_offset, const unsigned __int128 *alpha, unsigned __int128 *out,
+                        int threads);
+
 int orc_max_threads(void);
 
 #ifdef __cplusplus

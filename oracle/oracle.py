@@ -70,6 +70,9 @@ def lib():
         L.orc_build_trace_commitment.argtypes = [i32, sz, C.c_uint, C.c_uint, sz, sz, vp, vp, vp, vp, vp, vp, i32]
         L.orc_build_constraint_commitment.argtypes = [i32, sz, C.c_uint, C.c_uint, sz, vp, vp, vp, vp, vp, i32]
         L.orc_blake3_hash.argtypes = [vp, sz, vp]
+        L.orc_ext_mul.argtypes = [i32, sz, vp, vp, vp]
+        L.orc_transpose_slice.argtypes = [i32, vp, sz, sz, sz, vp]
+        L.orc_apply_drp.argtypes = [i32, vp, sz, sz, sz, vp, vp, vp, i32]
         _lib = L
     return _lib
 
@@ -372,3 +375,45 @@ def merkle_prove_batch(nodes: np.ndarray, leaves: np.ndarray, indexes):
             nxt.append(sib >> 1)
             i += 1
     return out_leaves, out_nodes, depth
+
+
+# ----------------------------------------------------------------------------------------------- FRI layer pieces
+
+def ext_mul(field: int, ext: int, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    out = np.empty_like(a)
+    lib().orc_ext_mul(field, ext, _p(a), _p(b), _p(out))
+    return out
+
+
+def transpose_slice(field: int, src: np.ndarray, n: int, ext: int, N: int) -> np.ndarray:
+    """utils/core/src/lib.rs:206-227: result[i][j] = source[i + j * (n / N)]."""
+    src = np.ascontiguousarray(src, dtype=np.uint64)
+    out = np.empty_like(src)
+    lib().orc_transpose_slice(field, _p(src), n, ext, N, _p(out))
+    return out
+
+
+def apply_drp(field: int, values: np.ndarray, rows: int, ext: int, N: int, offset: int, alpha: np.ndarray,
+              threads: int = 1) -> np.ndarray:
+    """fri/src/folding/mod.rs:85-117.  values: rows x N elements of E (row major); alpha: one element of E."""
+    values = np.ascontiguousarray(values, dtype=np.uint64)
+    alpha = np.ascontiguousarray(alpha, dtype=np.uint64)
+    w = ELEM_WORDS[field]
+    out = np.empty((rows * ext, w) if w > 1 else (rows * ext,), dtype=np.uint64)
+    lib().orc_apply_drp(field, _p(values), rows, ext, N, _p(_off_bytes(offset)), _p(alpha), _p(out), threads)
+    return out
+
+
+def fri_layer_commit(field: int, evaluations: np.ndarray, n: int, ext: int, N: int, threads: int = 1):
+    """FriProver::build_layer, commit half (fri/src/prover/mod.rs:191-203): transpose_slice -> hash_values -> tree."""
+    tr = transpose_slice(field, evaluations, n, ext, N)
+    rows = n // N
+    w = ELEM_WORDS[field]
+    flat = tr.reshape(rows, -1)
+    leaves = np.empty((rows, 32), dtype=np.uint8)
+    for i in range(rows):
+        leaves[i] = np.frombuffer(hash_elements(field, flat[i]), dtype=np.uint8)
+    nodes = build_merkle_nodes(leaves, threads)
+    return dict(transposed=tr, leaves=leaves, nodes=nodes, root=bytes(nodes[1]))

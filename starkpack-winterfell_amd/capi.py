@@ -22,6 +22,7 @@ SYMBOLS = [
     "wf_trace_commit", "wf_constraint_commit", "wf_trace_commit_dev", "wf_constraint_commit_dev",
     "wf_trace_commit_shard_dev", "wf_merkle_build_dev", "wf_trace_commit_resident", "wf_constraint_commit_resident", "wf_commitment_destroy", "wf_commitment_root",
     "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_prove", "wf_commitment_prove_batch",
+    "wf_fri_layer_commit", "wf_fri_apply_drp", "wf_fri_layer_commit_dev", "wf_fri_apply_drp_dev",
     "wf_fft_evaluate_poly", "wf_fft_evaluate_poly_with_offset", "wf_fft_interpolate_poly",
     "wf_fft_interpolate_poly_with_offset", "wf_evaluate_polys_over", "wf_hash_rows", "wf_merkle_build",
 ]
@@ -116,6 +117,10 @@ def load():
         L.wf_commitment_prove.argtypes = [vp, C.c_uint64, vp]
         L.wf_commitment_prove_batch.argtypes = [vp, vp, sz, vp, vp, sz, vp, C.POINTER(sz), C.POINTER(sz),
                                                 C.POINTER(u32)]
+        L.wf_fri_layer_commit.argtypes = [vp, u32, u32, vp, sz, u32, vp, vp, vp, vp]
+        L.wf_fri_apply_drp.argtypes = [vp, u32, u32, vp, sz, u32, vp, vp, vp]
+        L.wf_fri_layer_commit_dev.argtypes = [vp, u32, u32, vp, sz, u32, vp, vp, vp, vp]
+        L.wf_fri_apply_drp_dev.argtypes = [vp, u32, u32, vp, sz, u32, vp, vp, vp, vp]
         L.wf_fft_evaluate_poly.argtypes = [vp, u32, u32, vp, sz]
         L.wf_fft_interpolate_poly.argtypes = [vp, u32, u32, vp, sz]
         L.wf_fft_interpolate_poly_with_offset.argtypes = [vp, u32, u32, vp, sz, vp]
@@ -297,6 +302,27 @@ class Context:
         lde = np.empty((n_rows, rw, w) if w > 1 else (n_rows, rw), dtype=np.uint64)
         _check(L.wf_evaluate_polys_over(self._h, C.byref(params), _ptr_array(cols), _p(lde)))
         return lde
+
+    def fri_layer_commit(self, field, ext, evals: np.ndarray, folding: int):
+        a = np.ascontiguousarray(evals, dtype=np.uint64)
+        n = a.size // (ELEM_WORDS[field] * ext)
+        rows = max(1, n // max(1, folding))
+        tr = np.empty_like(a)
+        leaves = np.empty((rows, 32), dtype=np.uint8)
+        nodes = np.empty((rows, 32), dtype=np.uint8)
+        root = np.empty(32, dtype=np.uint8)
+        _check(load().wf_fri_layer_commit(self._h, field, ext, _p(a), n, folding, _p(tr), _p(leaves), _p(nodes),
+                                          _p(root)))
+        return dict(transposed=tr, leaves=leaves, nodes=nodes, root=bytes(root))
+
+    def fri_apply_drp(self, field, ext, transposed: np.ndarray, folding: int, offset: int, alpha: np.ndarray):
+        a = np.ascontiguousarray(transposed, dtype=np.uint64)
+        w = ELEM_WORDS[field]
+        rows = a.size // (w * ext * folding)
+        al = np.ascontiguousarray(alpha, dtype=np.uint64)
+        out = np.empty((rows * ext, w) if w > 1 else (rows * ext,), dtype=np.uint64)
+        _check(load().wf_fri_apply_drp(self._h, field, ext, _p(a), rows, folding, _off16(offset), _p(al), _p(out)))
+        return out
 
     def hash_rows(self, field, rows: np.ndarray, n_rows: int, row_elems: int) -> np.ndarray:
         a = np.ascontiguousarray(rows, dtype=np.uint64)

@@ -17,6 +17,7 @@
 
 #include "kernels.hpp"
 #include "seg_kernels.hpp"
+#include "fri_kernels.hpp"
 
 using namespace wf;
 
@@ -1155,6 +1156,162 @@ int wf_commitment_prove_batch(const wf_commitment *c, const uint64_t *positions,
     *n_vectors = vec_ids.size();
     *n_nodes = total;
     if (depth_out) *depth_out = c->depth;
+    return 0;
+}
+
+// FRI layer pieces --------------------------------------------------------------------------------
+}  // extern "C"
+
+static int check_fri_args(wf_ctx *ctx, uint32_t field, uint32_t ext, size_t n, uint32_t folding, uint32_t *logn) {
+    if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
+    if (field != WF_FIELD_F64 && field != WF_FIELD_F128) return fail(WF_ERR_FIELD, "unknown field id %u", field);
+    if (ext < 1 || ext > 3 || (field == WF_FIELD_F128 && ext == 3)) return fail(WF_ERR_EXTENSION, "unsupported extension degree %u", ext);
+    if (folding != 2 && folding != 4 && folding != 8 && folding != 16)
+        return fail(WF_ERR_ARG, "folding factor %u is not supported", folding);  // fri/src/prover/mod.rs:178-185
+    if (n < 2 * (size_t)folding || (n & (n - 1))) return fail(WF_ERR_TRACE_LENGTH, "domain size must be a power of two >= 2 * folding factor");
+    uint32_t l = 0;
+    while (((size_t)1 << l) < n) l++;
+    const uint32_t adicity = field == WF_FIELD_F64 ? F64::TWO_ADICITY : F128::TWO_ADICITY;
+    if (l > adicity) return fail(WF_ERR_DOMAIN, "no multiplicative subgroup of size 2^%u in this field", l);
+    *logn = l;
+    return 0;
+}
+
+template <class F>
+static int fri_layer_commit_dev(wf_ctx *ctx, hipStream_t st, uint32_t ext, const void *d_evals, size_t n,
+                                uint32_t folding, void *d_transposed, void *d_leaves, void *d_nodes) {
+    typedef typename F::T T;
+    const uint64_t rows = n / folding;
+    prof_mark(ctx, st, "fri.transpose");
+    hipLaunchKernelGGL(k_fri_transpose<F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (const T *)d_evals,
+                       (T *)d_transposed, rows, folding, ext);
+    HIP_TRY(hipGetLastError());
+    prof_mark(ctx, st, "fri.hash_values");
+    int rc = run_hash_rows<F>(st, d_transposed, 0, rows, folding * ext, folding * ext, 1, d_leaves);
+    if (rc) return rc;
+    prof_mark(ctx, st, "fri.merkle");
+    rc = run_merkle(st, d_leaves, rows, d_nodes);
+    prof_mark(ctx, st, "between_calls");
+    return rc;
+}
+
+template <class F, int W>
+static int fri_drp_launch(hipStream_t st, uint32_t folding, const DrpArgs<F> &a) {
+    const dim3 grid((uint32_t)((a.rows + 127) / 128)), block(128);
+    switch (folding) {
+        case 2: hipLaunchKernelGGL((k_fri_drp<F, W, 2>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((k_fri_drp<F, W, 4>), grid, block, 0, st, a); break;
+        case 8: hipLaunchKernelGGL((k_fri_drp<F, W, 8>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((k_fri_drp<F, W, 16>), grid, block, 0, st, a); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <class F>
+static int fri_apply_drp_dev(wf_ctx *ctx, hipStream_t st, uint32_t ext, const void *d_transposed, size_t rows,
+                             uint32_t folding, const uint8_t offset16[16], const void *alpha_host, void *d_out) {
+    typedef typename F::T T;
+    u128 off;
+    memcpy(&off, offset16, 16);
+    if (off == 0 || off >= FieldInfo<F>::modulus()) return fail(WF_ERR_OFFSET, "domain offset must be a non-zero field element");
+    uint32_t logn = 0, logf = 0;
+    while (((size_t)1 << logn) < rows * folding) logn++;
+    while ((1u << logf) < folding) logf++;
+    TableSet *ginv;
+    int rc = root_tables<F>(ctx, logn, true, &ginv);
+    if (rc) return rc;
+    DrpArgs<F> a;
+    memset(&a, 0, sizeof(a));
+    a.values = (const T *)d_transposed;
+    a.out = (T *)d_out;
+    a.rows = rows;
+    a.ginv = as_pow2l<F>(*ginv);
+    rc = digit_table<F>(ctx, logf, true, &a.tw);
+    if (rc) return rc;
+    a.sinv = f_inv<F>(F::from_u128_canonical(off));
+    a.ninv = f_inv<F>(F::from_u128_canonical((u128)folding));
+    memcpy(a.alpha, alpha_host, ext * sizeof(T));
+    for (uint32_t w = 0; w < ext; w++)
+        if (!F::is_valid(a.alpha[w])) return fail(WF_ERR_ARG, "alpha is not a valid field element");
+    prof_mark(ctx, st, "fri.apply_drp");
+    if (ext == 1) rc = fri_drp_launch<F, 1>(st, folding, a);
+    else if (ext == 2) rc = fri_drp_launch<F, 2>(st, folding, a);
+    else {
+        if constexpr (F::FIELD_ID == 1) rc = fri_drp_launch<F, 3>(st, folding, a);
+        else rc = fail(WF_ERR_EXTENSION, "f128 has no cubic extension");
+    }
+    prof_mark(ctx, st, "between_calls");
+    return rc;
+}
+
+extern "C" {
+
+int wf_fri_layer_commit_dev(wf_ctx *ctx, uint32_t field, uint32_t ext, const void *d_evals, size_t n, uint32_t folding,
+                            void *d_transposed, void *d_leaves, void *d_nodes, void *stream) {
+    uint32_t l;
+    int rc = check_fri_args(ctx, field, ext, n, folding, &l);
+    if (rc) return rc;
+    if (!d_evals || !d_transposed || !d_leaves || !d_nodes) return fail(WF_ERR_ARG, "null device buffer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    return field == WF_FIELD_F64 ? fri_layer_commit_dev<F64>(ctx, st, ext, d_evals, n, folding, d_transposed, d_leaves, d_nodes)
+                                 : fri_layer_commit_dev<F128>(ctx, st, ext, d_evals, n, folding, d_transposed, d_leaves, d_nodes);
+}
+
+int wf_fri_apply_drp_dev(wf_ctx *ctx, uint32_t field, uint32_t ext, const void *d_transposed, size_t rows,
+                         uint32_t folding, const uint8_t domain_offset[16], const void *alpha, void *d_out,
+                         void *stream) {
+    uint32_t l;
+    int rc = check_fri_args(ctx, field, ext, rows * folding, folding, &l);
+    if (rc) return rc;
+    if (!d_transposed || !d_out || !alpha || !domain_offset) return fail(WF_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    return field == WF_FIELD_F64 ? fri_apply_drp_dev<F64>(ctx, st, ext, d_transposed, rows, folding, domain_offset, alpha, d_out)
+                                 : fri_apply_drp_dev<F128>(ctx, st, ext, d_transposed, rows, folding, domain_offset, alpha, d_out);
+}
+
+int wf_fri_layer_commit(wf_ctx *ctx, uint32_t field, uint32_t ext, const void *evals, size_t n, uint32_t folding,
+                        void *transposed_out, uint8_t *leaves_out, uint8_t *nodes_out, uint8_t *root_out) {
+    uint32_t l;
+    int rc = check_fri_args(ctx, field, ext, n, folding, &l);
+    if (rc) return rc;
+    if (!evals) return fail(WF_ERR_ARG, "evaluations pointer is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t bytes = n * ext * wf_elem_bytes(field), rows = n / folding;
+    if ((rc = ensure(ctx->io[0], bytes))) return rc;
+    if ((rc = ensure(ctx->io[2], bytes))) return rc;
+    if ((rc = ensure(ctx->io[3], rows * 32))) return rc;
+    if ((rc = ensure(ctx->io[4], rows * 32))) return rc;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->io[0].p, evals, bytes, hipMemcpyHostToDevice, st));
+    rc = wf_fri_layer_commit_dev(ctx, field, ext, ctx->io[0].p, n, folding, ctx->io[2].p, ctx->io[3].p, ctx->io[4].p, st);
+    if (rc) return rc;
+    if (transposed_out) HIP_TRY(hipMemcpyAsync(transposed_out, ctx->io[2].p, bytes, hipMemcpyDeviceToHost, st));
+    if (leaves_out) HIP_TRY(hipMemcpyAsync(leaves_out, ctx->io[3].p, rows * 32, hipMemcpyDeviceToHost, st));
+    if (nodes_out) HIP_TRY(hipMemcpyAsync(nodes_out, ctx->io[4].p, rows * 32, hipMemcpyDeviceToHost, st));
+    if (root_out) HIP_TRY(hipMemcpyAsync(root_out, (char *)ctx->io[4].p + 32, 32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int wf_fri_apply_drp(wf_ctx *ctx, uint32_t field, uint32_t ext, const void *transposed, size_t rows, uint32_t folding,
+                     const uint8_t domain_offset[16], const void *alpha, void *out) {
+    uint32_t l;
+    int rc = check_fri_args(ctx, field, ext, rows * folding, folding, &l);
+    if (rc) return rc;
+    if (!transposed || !out) return fail(WF_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t eb = ext * wf_elem_bytes(field);
+    if ((rc = ensure(ctx->io[0], rows * folding * eb))) return rc;
+    if ((rc = ensure(ctx->io[1], rows * eb))) return rc;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->io[0].p, transposed, rows * folding * eb, hipMemcpyHostToDevice, st));
+    rc = wf_fri_apply_drp_dev(ctx, field, ext, ctx->io[0].p, rows, folding, domain_offset, alpha, ctx->io[1].p, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, ctx->io[1].p, rows * eb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
 

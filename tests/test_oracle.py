@@ -261,3 +261,53 @@ def test_oracle_rejects_bad_parameters(orc):
         orc.build_trace_commitment(F64, [col], 1, 3, 1, 0)     # zero offset
     with pytest.raises(ValueError):
         orc.build_trace_commitment(F128, [col], 3, 3, 1, 3)    # no cubic extension over f128
+
+
+# ------------------------------------------------------------------------------------------------ FRI layer pieces
+@pytest.mark.parametrize("N", [2, 4, 8, 16])
+def test_apply_drp_equals_coefficient_folding(orc, N):
+    """fri/src/folding/mod.rs:40-84 (doctest): DRP of the evaluations == evaluations of the folded polynomial."""
+    from oracle import pyref as P
+    import random
+    F = P.Field("f64")
+    p, rnd = F.p, random.Random(N)
+    n, off = 64, 7
+    poly = [rnd.randrange(p) for _ in range(n // 2)] + [0] * (n // 2)
+    g = F.root_of_unity(6)
+    ev = [P.poly_eval(poly, off * pow(g, i, p) % p, p) for i in range(n)]
+    alpha = rnd.randrange(p)
+    folded = [sum(pow(alpha, j, p) * poly[N * i + j] for j in range(N)) % p for i in range(n // N)]
+    g2 = F.root_of_unity((n // N).bit_length() - 1)
+    want = [P.poly_eval(folded, pow(off, N, p) * pow(g2, i, p) % p, p) for i in range(n // N)]
+    mem = lambda v: np.array([F.to_mem(x) for x in v], dtype=np.uint64)  # noqa: E731
+    tr = orc.transpose_slice(F64, mem(ev), n, 1, N)
+    assert [int(v) for v in tr[:N]] == [F.to_mem(ev[j * (n // N)]) for j in range(N)]   # utils/core/src/lib.rs:206-227
+    got = orc.apply_drp(F64, tr, n // N, 1, N, off, mem([alpha]))
+    assert [F.from_mem(int(v)) for v in got] == want
+
+
+def test_extension_products(orc):
+    """f64 quadratic x^2-x+2 / cubic x^3-x-1 (f64/mod.rs:401-472), f128 quadratic x^2-x-1 (f128/mod.rs:273-279),
+    checked against schoolbook polynomial arithmetic on Python integers; one/zero identities (f64/tests.rs:246-260)."""
+    import random
+    rnd = random.Random(9)
+    p, q = P64, P128
+    mem = lambda v: np.array([(x << 64) % p for x in v], dtype=np.uint64)  # noqa: E731
+    val = lambda a: [int(x) * pow(2**64, -1, p) % p for x in a]  # noqa: E731
+    for _ in range(100):
+        a = [rnd.randrange(p) for _ in range(3)]
+        b = [rnd.randrange(p) for _ in range(3)]
+        c0, c1, c2 = a[0] * b[0], a[0] * b[1] + a[1] * b[0], a[1] * b[1]
+        assert val(orc.ext_mul(F64, 2, mem(a[:2]), mem(b[:2]))) == [(c0 - 2 * c2) % p, (c1 + c2) % p]
+        c = [0] * 5
+        for i in range(3):
+            for j in range(3):
+                c[i + j] += a[i] * b[j]
+        assert val(orc.ext_mul(F64, 3, mem(a), mem(b))) == [(c[0] + c[3]) % p, (c[1] + c[3] + c[4]) % p, (c[2] + c[4]) % p]
+        x = [rnd.randrange(q) for _ in range(2)]
+        y = [rnd.randrange(q) for _ in range(2)]
+        got = orc.f128_to_ints(orc.ext_mul(F128, 2, orc.f128_from_ints(x), orc.f128_from_ints(y)))
+        assert got == [(x[0] * y[0] + x[1] * y[1]) % q, (x[0] * y[1] + x[1] * y[0] + x[1] * y[1]) % q]
+    r = mem([5, 9])
+    assert np.array_equal(orc.ext_mul(F64, 2, r, mem([1, 0])), r)
+    assert not orc.ext_mul(F64, 2, r, mem([0, 0])).any()
