@@ -204,6 +204,17 @@ int wf_fri_apply_drp_dev(wf_ctx *ctx, uint32_t field, uint32_t ext_degree, const
                          uint32_t folding, const uint8_t domain_offset[16], const void *alpha, void *d_out,
                          void *stream);
 
+/* ---- out-of-domain evaluation ----------------------------------------------------------------------- */
+
+/* ColMatrix::evaluate_columns_at (prover/src/matrix/col_matrix.rs:249-254): every column (n coefficients of
+ * ext_degree coordinates) evaluated at one point z of z_ext_degree coordinates (z_ext_degree == ext_degree, or
+ * ext_degree == 1): out receives n_cols elements of z's field.  TracePolyTable::get_ood_frame
+ * (prover/src/trace/poly_table.rs:67-70) is two calls (z and z*g), CompositionPoly::evaluate_at one. */
+int wf_evaluate_columns_at(wf_ctx *ctx, uint32_t field, uint32_t ext_degree, const void *const *poly_cols,
+                           size_t n_cols, size_t n, const void *z, uint32_t z_ext_degree, void *out);
+/* The same on the polynomials a resident commitment keeps in HBM ([n_traces][n_cols] columns). */
+int wf_commitment_evaluate_polys_at(const wf_commitment *c, const void *z, uint32_t z_ext_degree, void *out);
+
 /* ---- building blocks (each mirrors one reference function; host buffers) ---------------------------------------- */
 
 /* fft::evaluate_poly (math/src/fft/mod.rs:85): in place, n elements of ext_degree coordinates, natural order. */

@@ -341,4 +341,11 @@ void orc_apply_drp(int field, const void *values, size_t rows, size_t ext, size_
         orc_f128_apply_drp((const f128e *)values, rows, ext, N, off, (const f128e *)alpha, (f128e *)out, threads);
 }
 
+void orc_eval_column_at(int field, const void *poly, size_t n, size_t ext_c, const void *z, size_t ext_z, void *out) {
+    if (field == ORC_FIELD_F64)
+        orc_f64_eval_column_at((const uint64_t *)poly, n, ext_c, (const uint64_t *)z, ext_z, (uint64_t *)out);
+    else
+        orc_f128_eval_column_at((const f128e *)poly, n, ext_c, (const f128e *)z, ext_z, (f128e *)out);
+}
+
 int orc_max_threads(void) { return omp_get_max_threads(); }

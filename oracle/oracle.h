@@ -95,6 +95,13 @@ void orc_f128_apply_drp(const unsigned __int128 *values, size_t rows, size_t ext
                         unsigned __int128 domain_offset, const unsigned __int128 *alpha, unsigned __int128 *out,
                         int threads);
 
+/* --- out-of-domain evaluation (prover/src/trace/poly_table.rs:60-73, matrix/col_matrix.rs:249-254) */
+void orc_eval_column_at(int field, const void *poly, size_t n, size_t ext_c, const void *z, size_t ext_z, void *out);
+void orc_f64_eval_column_at(const uint64_t *poly, size_t n, size_t ext_c, const uint64_t *z, size_t ext_z,
+                            uint64_t *out);
+void orc_f128_eval_column_at(const unsigned __int128 *poly, size_t n, size_t ext_c, const unsigned __int128 *z,
+                             size_t ext_z, unsigned __int128 *out);
+
 int orc_max_threads(void);
 
 #ifdef __cplusplus

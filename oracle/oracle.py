@@ -70,6 +70,7 @@ def lib():
         L.orc_build_trace_commitment.argtypes = [i32, sz, C.c_uint, C.c_uint, sz, sz, vp, vp, vp, vp, vp, vp, i32]
         L.orc_build_constraint_commitment.argtypes = [i32, sz, C.c_uint, C.c_uint, sz, vp, vp, vp, vp, vp, i32]
         L.orc_blake3_hash.argtypes = [vp, sz, vp]
+        L.orc_eval_column_at.argtypes = [i32, vp, sz, sz, vp, sz, vp]
         L.orc_ext_mul.argtypes = [i32, sz, vp, vp, vp]
         L.orc_transpose_slice.argtypes = [i32, vp, sz, sz, sz, vp]
         L.orc_apply_drp.argtypes = [i32, vp, sz, sz, sz, vp, vp, vp, i32]
@@ -417,3 +418,14 @@ def fri_layer_commit(field: int, evaluations: np.ndarray, n: int, ext: int, N: i
         leaves[i] = np.frombuffer(hash_elements(field, flat[i]), dtype=np.uint8)
     nodes = build_merkle_nodes(leaves, threads)
     return dict(transposed=tr, leaves=leaves, nodes=nodes, root=bytes(nodes[1]))
+
+
+def eval_column_at(field: int, poly: np.ndarray, ext_c: int, z: np.ndarray, ext_z: int) -> np.ndarray:
+    """ColMatrix::evaluate_columns_at for one column (col_matrix.rs:249-254): P(z), coefficients embedded into z's field."""
+    poly = np.ascontiguousarray(poly, dtype=np.uint64)
+    z = np.ascontiguousarray(z, dtype=np.uint64)
+    w = ELEM_WORDS[field]
+    n = poly.size // (w * ext_c)
+    out = np.empty((ext_z, w) if w > 1 else (ext_z,), dtype=np.uint64)
+    lib().orc_eval_column_at(field, _p(poly), n, ext_c, _p(z), ext_z, _p(out))
+    return out

@@ -22,7 +22,7 @@ SYMBOLS = [
     "wf_trace_commit", "wf_constraint_commit", "wf_trace_commit_dev", "wf_constraint_commit_dev",
     "wf_trace_commit_shard_dev", "wf_merkle_build_dev", "wf_trace_commit_resident", "wf_constraint_commit_resident", "wf_commitment_destroy", "wf_commitment_root",
     "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_prove", "wf_commitment_prove_batch",
-    "wf_fri_layer_commit", "wf_fri_apply_drp", "wf_fri_layer_commit_dev", "wf_fri_apply_drp_dev",
+    "wf_evaluate_columns_at", "wf_commitment_evaluate_polys_at", "wf_fri_layer_commit", "wf_fri_apply_drp", "wf_fri_layer_commit_dev", "wf_fri_apply_drp_dev",
     "wf_fft_evaluate_poly", "wf_fft_evaluate_poly_with_offset", "wf_fft_interpolate_poly",
     "wf_fft_interpolate_poly_with_offset", "wf_evaluate_polys_over", "wf_hash_rows", "wf_merkle_build",
 ]
@@ -117,6 +117,8 @@ def load():
         L.wf_commitment_prove.argtypes = [vp, C.c_uint64, vp]
         L.wf_commitment_prove_batch.argtypes = [vp, vp, sz, vp, vp, sz, vp, C.POINTER(sz), C.POINTER(sz),
                                                 C.POINTER(u32)]
+        L.wf_evaluate_columns_at.argtypes = [vp, u32, u32, vp, sz, sz, vp, u32, vp]
+        L.wf_commitment_evaluate_polys_at.argtypes = [vp, vp, u32, vp]
         L.wf_fri_layer_commit.argtypes = [vp, u32, u32, vp, sz, u32, vp, vp, vp, vp]
         L.wf_fri_apply_drp.argtypes = [vp, u32, u32, vp, sz, u32, vp, vp, vp]
         L.wf_fri_layer_commit_dev.argtypes = [vp, u32, u32, vp, sz, u32, vp, vp, vp, vp]
@@ -303,6 +305,15 @@ class Context:
         _check(L.wf_evaluate_polys_over(self._h, C.byref(params), _ptr_array(cols), _p(lde)))
         return lde
 
+    def evaluate_columns_at(self, field, ext, poly_cols, z: np.ndarray, z_ext: int) -> np.ndarray:
+        cols = [np.ascontiguousarray(c, dtype=np.uint64) for c in poly_cols]
+        w = ELEM_WORDS[field]
+        n = cols[0].size // (w * ext)
+        zz = np.ascontiguousarray(z, dtype=np.uint64)
+        out = np.empty((len(cols), z_ext, w) if w > 1 else (len(cols), z_ext), dtype=np.uint64)
+        _check(load().wf_evaluate_columns_at(self._h, field, ext, _ptr_array(cols), len(cols), n, _p(zz), z_ext, _p(out)))
+        return out
+
     def fri_layer_commit(self, field, ext, evals: np.ndarray, folding: int):
         a = np.ascontiguousarray(evals, dtype=np.uint64)
         n = a.size // (ELEM_WORDS[field] * ext)
@@ -368,6 +379,13 @@ class Commitment:
         w = ELEM_WORDS[self.field]
         out = np.empty((len(pos), self.row_elems, w) if w > 1 else (len(pos), self.row_elems), dtype=np.uint64)
         _check(load().wf_commitment_read_rows(self._h, _p(pos), len(pos), _p(out)))
+        return out
+
+    def evaluate_polys_at(self, z: np.ndarray, z_ext: int, n_cols_total: int) -> np.ndarray:
+        zz = np.ascontiguousarray(z, dtype=np.uint64)
+        w = ELEM_WORDS[self.field]
+        out = np.empty((n_cols_total, z_ext, w) if w > 1 else (n_cols_total, z_ext), dtype=np.uint64)
+        _check(load().wf_commitment_evaluate_polys_at(self._h, _p(zz), z_ext, _p(out)))
         return out
 
     def prove(self, index: int):

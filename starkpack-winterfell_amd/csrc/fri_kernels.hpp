@@ -133,4 +133,56 @@ __global__ void __launch_bounds__(256) k_fri_drp(DrpArgs<F> a) {
     for (int w = 0; w < W; w++) a.out[i * W + w] = acc.c[w];
 }
 
+// Out-of-domain evaluation: ColMatrix::evaluate_columns_at (prover/src/matrix/col_matrix.rs:249-254),
+// i.e. polynom::eval of every column at one point z of an extension field (TracePolyTable::get_ood_frame,
+// prover/src/trace/poly_table.rs:60-73).  One work-group per column: every lane runs Horner over a contiguous chunk,
+// lane 0 then folds the partial values with z^chunk.
+template <class F>
+struct EvalAtArgs {
+    typedef typename F::T T;
+    const T *polys;   // [n_cols] columns of n elements of WC coordinates
+    T *out;           // [n_cols] elements of WZ coordinates
+    uint64_t n;
+    T z[3];
+};
+
+template <class F, int WC, int WZ>
+__global__ void __launch_bounds__(256) k_eval_columns_at(EvalAtArgs<F> a) {
+    typedef typename F::T T;
+    typedef Ext<F, WZ> E;
+    __shared__ __attribute__((aligned(16))) unsigned char sh_raw[256 * sizeof(E)];
+    E *partial = reinterpret_cast<E *>(sh_raw);
+    const T *poly = a.polys + (uint64_t)blockIdx.x * a.n * WC;
+    const uint32_t nt = (uint32_t)(a.n < 256 ? a.n : 256);
+    const uint64_t chunk = a.n / nt;  // n and nt are powers of two
+    E z;
+#pragma unroll
+    for (int w = 0; w < WZ; w++) z.c[w] = a.z[w];
+    if (threadIdx.x < nt) {
+        const uint64_t k0 = (uint64_t)threadIdx.x * chunk;
+        E acc;
+#pragma unroll
+        for (int w = 0; w < WZ; w++) acc.c[w] = F::zero();
+        for (uint64_t k = k0 + chunk; k-- > k0;) {
+            acc = ext_mul<F, WZ>(acc, z);
+#pragma unroll
+            for (int w = 0; w < WC; w++) acc.c[w] = F::add(acc.c[w], poly[k * WC + w]);
+        }
+        partial[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        E zc = z;  // z^chunk by squaring (chunk is a power of two)
+        for (uint64_t c = 1; c < chunk; c <<= 1) zc = ext_mul<F, WZ>(zc, zc);
+        E acc = partial[nt - 1];
+        for (int t = (int)nt - 2; t >= 0; t--) {
+            acc = ext_mul<F, WZ>(acc, zc);
+#pragma unroll
+            for (int w = 0; w < WZ; w++) acc.c[w] = F::add(acc.c[w], partial[t].c[w]);
+        }
+#pragma unroll
+        for (int w = 0; w < WZ; w++) a.out[(uint64_t)blockIdx.x * WZ + w] = acc.c[w];
+    }
+}
+
 }  // namespace wf

@@ -1315,6 +1315,87 @@ int wf_fri_apply_drp(wf_ctx *ctx, uint32_t field, uint32_t ext, const void *tran
     return 0;
 }
 
+// out-of-domain evaluation -------------------------------------------------------------------------
+}  // extern "C"
+
+template <class F>
+static int eval_columns_at_dev(wf_ctx *ctx, hipStream_t st, const void *d_polys, size_t n_cols, size_t n, uint32_t ext_c,
+                               const void *z_host, uint32_t ext_z, void *d_out) {
+    typedef typename F::T T;
+    EvalAtArgs<F> a;
+    memset(&a, 0, sizeof(a));
+    a.polys = (const T *)d_polys;
+    a.out = (T *)d_out;
+    a.n = n;
+    memcpy(a.z, z_host, ext_z * sizeof(T));
+    for (uint32_t w = 0; w < ext_z; w++)
+        if (!F::is_valid(a.z[w])) return fail(WF_ERR_ARG, "z is not a valid field element");
+    const dim3 grid((uint32_t)n_cols), block(256);
+    prof_mark(ctx, st, "ood.evaluate_columns_at");
+    const uint32_t key = ext_c * 10 + ext_z;
+    switch (key) {
+        case 11: hipLaunchKernelGGL((k_eval_columns_at<F, 1, 1>), grid, block, 0, st, a); break;
+        case 12: hipLaunchKernelGGL((k_eval_columns_at<F, 1, 2>), grid, block, 0, st, a); break;
+        case 22: hipLaunchKernelGGL((k_eval_columns_at<F, 2, 2>), grid, block, 0, st, a); break;
+        case 13:
+            if constexpr (F::FIELD_ID == 1) { hipLaunchKernelGGL((k_eval_columns_at<F, 1, 3>), grid, block, 0, st, a); break; }
+            return fail(WF_ERR_EXTENSION, "f128 has no cubic extension");
+        case 33:
+            if constexpr (F::FIELD_ID == 1) { hipLaunchKernelGGL((k_eval_columns_at<F, 3, 3>), grid, block, 0, st, a); break; }
+            return fail(WF_ERR_EXTENSION, "f128 has no cubic extension");
+        default:
+            return fail(WF_ERR_EXTENSION, "cannot evaluate degree-%u extension coefficients at a degree-%u extension point", ext_c, ext_z);
+    }
+    HIP_TRY(hipGetLastError());
+    prof_mark(ctx, st, "between_calls");
+    return 0;
+}
+
+extern "C" {
+
+int wf_commitment_evaluate_polys_at(const wf_commitment *c, const void *z, uint32_t z_ext_degree, void *out) {
+    if (!c || !z || !out) return fail(WF_ERR_ARG, "null argument");
+    wf_ctx *ctx = c->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n_cols = (size_t)c->p.n_cols * c->p.n_traces, n = (size_t)1 << c->p.log2_trace_len;
+    const size_t out_bytes = n_cols * z_ext_degree * wf_elem_bytes(c->p.field);
+    int rc = ensure(ctx->io[4], out_bytes);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    rc = c->p.field == WF_FIELD_F64
+             ? eval_columns_at_dev<F64>(ctx, st, c->polys, n_cols, n, c->p.ext_degree, z, z_ext_degree, ctx->io[4].p)
+             : eval_columns_at_dev<F128>(ctx, st, c->polys, n_cols, n, c->p.ext_degree, z, z_ext_degree, ctx->io[4].p);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, ctx->io[4].p, out_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int wf_evaluate_columns_at(wf_ctx *ctx, uint32_t field, uint32_t ext_degree, const void *const *poly_cols,
+                           size_t n_cols, size_t n, const void *z, uint32_t z_ext_degree, void *out) {
+    if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
+    if (field != WF_FIELD_F64 && field != WF_FIELD_F128) return fail(WF_ERR_FIELD, "unknown field id %u", field);
+    if (n < 2 || (n & (n - 1))) return fail(WF_ERR_TRACE_LENGTH, "size must be a power of two >= 2");
+    if (!poly_cols || !z || !out || n_cols == 0) return fail(WF_ERR_ARG, "null argument");
+    int rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t colb = n * ext_degree * wf_elem_bytes(field), out_bytes = n_cols * z_ext_degree * wf_elem_bytes(field);
+    if ((rc = ensure(ctx->io[0], n_cols * colb))) return rc;
+    if ((rc = ensure(ctx->io[4], out_bytes))) return rc;
+    hipStream_t st = ctx->stream;
+    for (size_t i = 0; i < n_cols; i++) {
+        if (!poly_cols[i]) return fail(WF_ERR_ARG, "column %zu is null", i);
+        HIP_TRY(hipMemcpyAsync((char *)ctx->io[0].p + i * colb, poly_cols[i], colb, hipMemcpyHostToDevice, st));
+    }
+    rc = field == WF_FIELD_F64
+             ? eval_columns_at_dev<F64>(ctx, st, ctx->io[0].p, n_cols, n, ext_degree, z, z_ext_degree, ctx->io[4].p)
+             : eval_columns_at_dev<F128>(ctx, st, ctx->io[0].p, n_cols, n, ext_degree, z, z_ext_degree, ctx->io[4].p);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, ctx->io[4].p, out_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
 int wf_evaluate_polys_over(wf_ctx *ctx, const wf_params *p, const void *const *poly_cols, void *lde_out) {
     return wf_constraint_commit(ctx, p, poly_cols, lde_out, nullptr, nullptr, nullptr);
 }
