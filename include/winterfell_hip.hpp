@@ -10,6 +10,9 @@
 //   CompositionPoly<E>      prover/src/constraints/composition_poly.rs:21-98
 //   ConstraintCommitment<E> prover/src/constraints/commitment.rs:21-69
 //   Prover                  prover/src/lib.rs:615-715 (build_trace_commitment, build_constraint_commitment)
+//   BatchMerkleProof        crypto/src/merkle/proofs.rs:31-38
+//   TraceCommitment<E>      prover/src/trace/commitment.rs:21-111 (resident form: LDE + tree stay in HBM; query()
+//                           returns the queried rows of all packed traces and the batch Merkle proof)
 //
 // Header-only; link with -lwf_lde.  Elements are the reference's in-memory representations:
 //   F64Element  = Montgomery u64 (math/src/field/f64/mod.rs:48-53)   F128Element = canonical u128
@@ -19,6 +22,7 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -310,5 +314,97 @@ class Prover {
     }
     wf_ctx *ctx_ = nullptr;
 };
+
+// ------------------------------------------------------------------------------------------------- resident commitments
+struct BatchMerkleProof {  // crypto/src/merkle/proofs.rs:31-38
+    std::vector<Digest> leaves;
+    std::vector<std::vector<Digest>> nodes;
+    uint8_t depth = 0;
+};
+
+// TraceCommitment (prover/src/trace/commitment.rs:21-111) whose data stay on the GPU: only queried rows and their
+// Merkle proofs are copied to the host.  Built by Prover-like free functions below.
+template <class E>
+class TraceCommitment {
+  public:
+    TraceCommitment(wf_commitment *h, size_t n_traces, size_t elements_per_row)
+        : h_(h), n_traces_(n_traces), epr_(elements_per_row) {}
+    ~TraceCommitment() { wf_commitment_destroy(h_); }
+    TraceCommitment(const TraceCommitment &) = delete;
+    TraceCommitment &operator=(const TraceCommitment &) = delete;
+
+    Digest main_trace_root() const {  // commitment.rs:137-140
+        Digest r;
+        wf_check(wf_commitment_root(h_, r.data()));
+        return r;
+    }
+    size_t tree_depth() const {
+        uint32_t d = 0;
+        wf_check(wf_commitment_info(h_, nullptr, nullptr, &d));
+        return d;
+    }
+    // TraceCommitment::query (commitment.rs:87-111): for every position the row of trace 0 || trace 1 || ..
+    // (comb_states), per-trace rows can be sliced out of it, plus the batch proof against the single tree.
+    std::pair<std::vector<std::vector<typename E::BaseField>>, BatchMerkleProof> query(
+        const std::vector<size_t> &positions) const {
+        std::vector<uint64_t> pos(positions.begin(), positions.end());
+        const size_t n = pos.size(), row_elems = n_traces_ * epr_;
+        std::vector<typename E::BaseField> flat(n * row_elems);
+        wf_check(wf_commitment_read_rows(h_, pos.data(), n, flat.data()));
+        std::vector<std::vector<typename E::BaseField>> rows;
+        for (size_t i = 0; i < n; i++) rows.emplace_back(flat.begin() + i * row_elems, flat.begin() + (i + 1) * row_elems);
+        const size_t depth = tree_depth();
+        BatchMerkleProof proof;
+        proof.leaves.resize(n);
+        std::vector<Digest> nodes(n * (depth + 1));
+        std::vector<uint32_t> counts(n);
+        size_t n_vec = 0, n_nodes = 0;
+        uint32_t d = 0;
+        wf_check(wf_commitment_prove_batch(h_, pos.data(), n, proof.leaves[0].data(), nodes[0].data(), nodes.size(),
+                                           counts.data(), &n_vec, &n_nodes, &d));
+        size_t k = 0;
+        for (size_t i = 0; i < n_vec; i++) {
+            proof.nodes.emplace_back(nodes.begin() + k, nodes.begin() + k + counts[i]);
+            k += counts[i];
+        }
+        proof.depth = (uint8_t)d;
+        return {std::move(rows), std::move(proof)};
+    }
+
+  private:
+    wf_commitment *h_;
+    size_t n_traces_, epr_;
+};
+
+// build_trace_commitment that leaves the commitment on the device (polys are returned to the host as the reference does)
+template <class E>
+inline std::pair<std::unique_ptr<TraceCommitment<E>>, std::vector<ColMatrix<E>>> build_resident_trace_commitment(
+    const Prover &prover, const std::vector<const ColMatrix<E> *> &traces, const StarkDomain &domain) {
+    if (traces.empty()) throw std::invalid_argument("at least one trace is required");
+    const size_t rows = traces[0]->num_rows(), cols = traces[0]->num_cols();
+    wf_params p;
+    std::memset(&p, 0, sizeof(p));
+    p.field = E::FIELD;
+    p.ext_degree = E::EXTENSION_DEGREE;
+    p.log2_trace_len = ilog2_exact(rows, "trace length");
+    p.log2_blowup = ilog2_exact(domain.trace_to_lde_blowup(), "blowup factor");
+    p.n_cols = (uint32_t)cols;
+    p.n_traces = (uint32_t)traces.size();
+    p.digest_bytes = 32;
+    unsigned __int128 off = domain.offset();
+    std::memcpy(p.domain_offset, &off, 16);
+    std::vector<const void *> in;
+    for (auto t : traces)
+        for (size_t c = 0; c < cols; c++) in.push_back(t->get_column(c).data());
+    std::vector<std::vector<std::vector<E>>> polys(traces.size(), std::vector<std::vector<E>>(cols, std::vector<E>(rows)));
+    std::vector<void *> polys_out;
+    for (auto &t : polys)
+        for (auto &c : t) polys_out.push_back(c.data());
+    wf_commitment *h = nullptr;
+    wf_check(wf_trace_commit_resident(prover.context(), &p, in.data(), polys_out.data(), &h));
+    std::vector<ColMatrix<E>> trace_polys;
+    for (auto &t : polys) trace_polys.emplace_back(std::move(t));
+    return {std::make_unique<TraceCommitment<E>>(h, traces.size(), cols * E::EXTENSION_DEGREE), std::move(trace_polys)};
+}
 
 }  // namespace winterfell

@@ -202,8 +202,46 @@ static void errors_like_the_reference() {
     std::printf("errors_like_the_reference ok\n");
 }
 
+static void resident_commitment_query() {
+    // TraceCommitment::query on a commitment that never leaves the GPU (trace/commitment.rs:87-111)
+    const size_t n = 64, blowup = 8, cols = 4;
+    std::vector<ColMatrix<F64Element>> traces;
+    uint64_t s = 777;
+    for (int t = 0; t < 2; t++) {
+        std::vector<std::vector<F64Element>> c(cols, std::vector<F64Element>(n));
+        for (auto &col : c)
+            for (auto &e : col) {
+                s = s * 6364136223846793005ull + 1442695040888963407ull;
+                e.inner = orc_f64_new(s >> 5);
+            }
+        traces.emplace_back(c);
+    }
+    StarkDomain domain(n, blowup, 7);
+    Prover prover(0);
+    auto [full_ldes, full_tree, full_polys] = prover.build_trace_commitment<F64Element>({&traces[0], &traces[1]}, domain);
+    auto [com, polys] = build_resident_trace_commitment<F64Element>(prover, {&traces[0], &traces[1]}, domain);
+    EXPECT(com->main_trace_root() == full_tree.root());
+    EXPECT(com->tree_depth() == 9);
+    EXPECT(polys[1].get_column(2) == full_polys[1].get_column(2));
+    std::vector<size_t> positions{5, 4, 511, 100, 0};
+    auto [rows, proof] = com->query(positions);
+    EXPECT(rows.size() == positions.size() && proof.leaves.size() == positions.size() && proof.depth == 9);
+    for (size_t i = 0; i < positions.size(); i++) {
+        EXPECT(rows[i].size() == 2 * cols);
+        for (int t = 0; t < 2; t++)
+            for (size_t c = 0; c < cols; c++) EXPECT(rows[i][t * cols + c] == full_ldes[t].get(c, positions[i]));
+        Digest h;
+        orc_hash_elements(ORC_FIELD_F64, rows[i].data(), rows[i].size(), h.data());
+        EXPECT(h == proof.leaves[i] && h == full_tree.leaves()[positions[i]]);
+    }
+    // positions 4 and 5 are siblings: their pair needs no leaf-level node (merkle/mod.rs:238-252)
+    EXPECT(proof.nodes.size() == 4);
+    std::printf("resident_commitment_query ok\n");
+}
+
 int main() {
     extend_and_commit_trace_table();
+    resident_commitment_query();
     starkpack_two_traces_f64();
     constraint_commitment_quadratic();
     errors_like_the_reference();
