@@ -31,13 +31,29 @@ struct F64 {
     static WF_HD T zero() { return 0; }
     static WF_HD T one() { return 0xFFFFFFFFull; }  // 2^64 mod p
 
-    // x * 2^-64 mod p for x < p * 2^64
+    // x * 2^-64 mod p for x < p * 2^64 (math/src/field/f64/mod.rs:651-661 computes the same value)
     static WF_HD uint64_t mont_reduce(uint64_t xl, uint64_t xh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // explicit 32-bit carry chains: 8 VALU (the 64-bit formulation below compiles to ~16 on gfx950)
+        const uint32_t l0 = (uint32_t)xl, l1 = (uint32_t)(xl >> 32), h0 = (uint32_t)xh, h1 = (uint32_t)(xh >> 32);
+        uint32_t ah, t, bl, rl, u, rh, r2l;
+        const uint32_t e = __builtin_add_overflow(l1, l0, &ah);  // a = xl + (xl << 32) = (ah : l0), carry e
+        const uint32_t b1 = __builtin_sub_overflow(l0, ah, &t);  // b = a - (a >> 32) - e
+        const uint32_t b2 = __builtin_sub_overflow(t, e, &bl);
+        const uint32_t bh = ah - (b1 | b2);
+        const uint32_t c1 = __builtin_sub_overflow(h0, bl, &rl);  // r = xh - b
+        const uint32_t c2 = __builtin_sub_overflow(h1, bh, &u);
+        const uint32_t c3 = __builtin_sub_overflow(u, c1, &rh);
+        const uint32_t m = 0u - (c2 | c3);                        // borrowed: r += p, i.e. r -= 2^32 - 1
+        const uint32_t d1 = __builtin_sub_overflow(rl, m, &r2l);
+        return ((uint64_t)(rh - d1) << 32) | r2l;
+#else
         uint64_t a = xl + (xl << 32);
         uint64_t e = a < xl;
         uint64_t b = a - (a >> 32) - e;
         uint64_t r = xh - b;
         return xh < b ? r - 0xFFFFFFFFull : r;
+#endif
     }
     static WF_HD T mul(T a, T b) {
 #if defined(__HIP_DEVICE_COMPILE__)
