@@ -92,10 +92,11 @@ __device__ __forceinline__ void merge(const uint32_t (&m)[16], uint32_t (&out)[8
 // Hash of a message of `len` bytes (len a multiple of 4) delivered block by block:
 // load(block_index, m) must fill the 16 words of 64-byte block `block_index`, zero-padded past `len`.
 // MAX_DEPTH bounds the subtree stack: messages up to 2^MAX_DEPTH KiB.
-template <class LoadBlock, int MAX_DEPTH = 20>
+// MULTI = false promises len <= 1024 (one chunk) and keeps the subtree stack (private memory) out of the kernel.
+template <bool MULTI, class LoadBlock, int MAX_DEPTH = 20>
 __device__ __forceinline__ void hash_stream(uint64_t len, LoadBlock load, uint32_t (&out)[8]) {
     uint32_t m[16];
-    if (len <= 1024) {
+    if (!MULTI || len <= 1024) {
         set_iv(out);
         uint32_t nblocks = len == 0 ? 1u : (uint32_t)((len + 63) >> 6);
         for (uint32_t b = 0; b < nblocks; b++) {
@@ -106,6 +107,7 @@ __device__ __forceinline__ void hash_stream(uint64_t len, LoadBlock load, uint32
         }
         return;
     }
+    if constexpr (MULTI) {
     uint32_t stack[MAX_DEPTH][8];
     int sp = 0;
     uint64_t nchunks = (len + 1023) >> 10;
@@ -150,6 +152,7 @@ __device__ __forceinline__ void hash_stream(uint64_t len, LoadBlock load, uint32
     }
 #pragma unroll
     for (int i = 0; i < 8; i++) out[i] = cv[i];
+    }
 }
 
 }  // namespace b3

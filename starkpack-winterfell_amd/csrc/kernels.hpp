@@ -285,7 +285,7 @@ __device__ __forceinline__ void elem_words<F128>(U128 v, uint32_t *w) {
     w[3] = (uint32_t)(v.hi >> 32);
 }
 
-template <class F>
+template <class F, bool MULTI>
 __global__ void __launch_bounds__(256) k_hash_rows(HashArgs<F> a) {
     typedef typename F::T T;
     constexpr uint32_t EPB = 64 / F::BYTES;  // elements per 64-byte block
@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(256) k_hash_rows(HashArgs<F> a) {
                 }
             }
         };
-        b3::hash_stream(len, load, out);
+        b3::hash_stream<MULTI>(len, load, out);
     } else {
         auto load = [&](uint64_t bi, uint32_t(&m)[16]) {
             const uint64_t e0 = bi * EPB;
@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(256) k_hash_rows(HashArgs<F> a) {
                 }
             }
         };
-        b3::hash_stream(len, load, out);
+        b3::hash_stream<MULTI>(len, load, out);
     }
     uint4 *dst = reinterpret_cast<uint4 *>(a.leaves + j * 8);
     dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
@@ -433,6 +433,35 @@ __global__ void __launch_bounds__(256) k_gather_digests(const uint4 *__restrict_
     const uint64_t id = ids[g >> 1];
     const uint4 *src = id < n_leaves ? leaves + 2 * id : nodes + 2 * (id - n_leaves);
     out[g] = src[g & 1];
+}
+
+// Two Merkle levels per launch: lane i reads four children (128 contiguous bytes), writes parents 2i, 2i+1 and
+// grandparent i.  Halves the launches and the re-reads of the level-per-launch form for the wide levels.
+__global__ void __launch_bounds__(256) k_merkle_level2(const uint32_t *__restrict__ children,
+                                                       uint32_t *__restrict__ parents,
+                                                       uint32_t *__restrict__ grandparents, uint64_t n_grand) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_grand) return;
+    const uint4 *src = reinterpret_cast<const uint4 *>(children + i * 32);
+    uint32_t m[16], cv[8], g[16];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint4 q0 = src[4 * h], q1 = src[4 * h + 1], q2 = src[4 * h + 2], q3 = src[4 * h + 3];
+        m[0] = q0.x; m[1] = q0.y; m[2] = q0.z; m[3] = q0.w;
+        m[4] = q1.x; m[5] = q1.y; m[6] = q1.z; m[7] = q1.w;
+        m[8] = q2.x; m[9] = q2.y; m[10] = q2.z; m[11] = q2.w;
+        m[12] = q3.x; m[13] = q3.y; m[14] = q3.z; m[15] = q3.w;
+        b3::merge(m, cv);
+        uint4 *dst = reinterpret_cast<uint4 *>(parents + (2 * i + h) * 8);
+        dst[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+        dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) g[8 * h + k] = cv[k];
+    }
+    b3::merge(g, cv);
+    uint4 *dst = reinterpret_cast<uint4 *>(grandparents + i * 8);
+    dst[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+    dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
 }
 
 // Hash contiguous rows of `row_elems` elements (wf_hash_rows building block) is k_hash_rows with n_traces = 1.

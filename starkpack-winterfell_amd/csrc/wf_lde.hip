@@ -523,7 +523,10 @@ static int run_hash_rows(hipStream_t st, const void *lde, uint64_t trace_elems, 
     h.leaves = (uint32_t *)leaves;
     const uint32_t threads = 256;
     const uint64_t grid = (n_rows + threads - 1) / threads;
-    hipLaunchKernelGGL(k_hash_rows<F>, dim3((uint32_t)grid), dim3(threads), 0, st, h);
+    if ((uint64_t)n_traces * epr * F::BYTES <= 1024)  // single BLAKE3 chunk: the stack-free instantiation
+        hipLaunchKernelGGL((k_hash_rows<F, false>), dim3((uint32_t)grid), dim3(threads), 0, st, h);
+    else
+        hipLaunchKernelGGL((k_hash_rows<F, true>), dim3((uint32_t)grid), dim3(threads), 0, st, h);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -536,7 +539,13 @@ static int run_merkle(hipStream_t st, const void *leaves, uint64_t n_leaves, voi
         const uint64_t n_par = n_children >> 1;
         const uint32_t threads = 256;
         const uint64_t grid = (n_par + threads - 1) / threads;
-        if (n_par >= (1u << 15)) {  // a level that still fills the chip: one lane per node, one level per launch
+        if (n_par >= (1u << 16)) {  // two levels that still fill the chip: one lane per grandparent
+            const uint64_t n_grand = n_par >> 1;
+            hipLaunchKernelGGL(k_merkle_level2, dim3((uint32_t)((n_grand + threads - 1) / threads)), dim3(threads), 0, st,
+                               children, (uint32_t *)nodes + n_par * 8, (uint32_t *)nodes + n_grand * 8, n_grand);
+            HIP_TRY(hipGetLastError());
+            n_children = n_grand;
+        } else if (n_par >= (1u << 15)) {  // a level that still fills the chip: one lane per node, one level per launch
             hipLaunchKernelGGL(k_merkle_level, dim3((uint32_t)grid), dim3(threads), 0, st, children,
                                (uint32_t *)nodes + n_par * 8, n_par);
             HIP_TRY(hipGetLastError());

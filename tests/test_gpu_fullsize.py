@@ -104,3 +104,60 @@ def test_cfg2_2_20_x8(ctx, orc, capi):
     lab = ctx.trace_commit(p12, both)["lde"][0]
     for j in (0, 5, 4097, 32767):
         assert [L.orc_f64_add(int(a), int(b)) for a, b in zip(la[j], lb[j])] == [int(v) for v in lab[j]]
+
+
+def test_cfg3_2_22_x64_device_resident(ctx, orc, capi):
+    """BASELINE configs[2]: 2^22 rows x 64 columns f64, blowup 8 (16 GiB LDE) through the device-buffer form, checked by
+    size-independent properties on samples: P_c interpolates the trace, LDE rows are coset evaluations, leaves hash
+    rows (512-byte rows: 8 BLAKE3 blocks), nodes merge children.  (Quadratic-extension composition columns are
+    compared in full against the oracle at smaller sizes in test_gpu_parity.py::test_constraint_commit.)"""
+    import torch
+    logR, logB, C = 22, 3, 64
+    R, N = 1 << logR, 1 << (logR + logB)
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    trace = torch.randint(-2**63, 2**63 - 1, (C * R,), dtype=torch.int64, device=dev, generator=gen)
+    trace = torch.where((trace >> 32) == -1, trace & 0x7FFFFFFFFFFFFFFF, trace)
+    polys = torch.empty_like(trace)
+    lde = torch.empty(N * C, dtype=torch.int64, device=dev)
+    leaves = torch.empty((N, 32), dtype=torch.uint8, device=dev)
+    nodes = torch.empty((N, 32), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    params = capi.make_params(F64, 1, logR, logB, C, 1)
+    with torch.cuda.stream(stream):
+        ctx.trace_commit_dev(params, trace.data_ptr(), polys.data_ptr(), lde.data_ptr(), leaves.data_ptr(),
+                             nodes.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ctx.trace_commit_dev(params, trace.data_ptr(), polys.data_ptr(), lde.data_ptr(), leaves.data_ptr(),
+                             nodes.data_ptr(), stream.cuda_stream)
+        e1.record()
+        torch.cuda.synchronize()
+    print(f"cfg3 2^22 x 64: {e0.elapsed_time(e1):.2f} ms per commitment")
+    L = orc.lib()
+    u64 = lambda t: t.cpu().numpy().view(np.uint64)  # noqa: E731
+    lde2 = lde.view(N, C)
+    for c in (0, 37, 63):
+        pc = u64(polys[c * R:(c + 1) * R])
+        tc = trace[c * R:(c + 1) * R]
+        w = L.orc_f64_get_root_of_unity(logR)
+        samp = [0, 1, R - 1, 1234567]
+        xs = np.array([L.orc_f64_exp(w, i) for i in samp], dtype=np.uint64)
+        assert np.array_equal(orc.eval_many(F64, pc, xs), u64(tc[samp]))
+        g = L.orc_f64_get_root_of_unity(logR + logB)
+        off = L.orc_f64_new(7)
+        js = [0, 9, N - 1, 23456789]
+        xs = np.array([L.orc_f64_mul(off, L.orc_f64_exp(g, j)) for j in js], dtype=np.uint64)
+        assert np.array_equal(orc.eval_many(F64, pc, xs), u64(lde2[js, c]))
+    for j in (0, 5, N - 1, 31415926):
+        assert bytes(u64(leaves[j]).view(np.uint8)) == orc.hash_elements(F64, u64(lde2[j]))   # 512-byte rows: 8 blocks
+    nh = nodes.cpu().numpy()
+    lh = leaves[:4096].cpu().numpy()
+    for i in (1, 2, 3, 1000, N // 4 + 5, N // 2 - 1):
+        assert bytes(nh[i]) == orc.merge(bytes(nh[2 * i]), bytes(nh[2 * i + 1]))
+    for k in (0, 1, 2047):
+        assert bytes(nh[N // 2 + k]) == orc.merge(bytes(lh[2 * k]), bytes(lh[2 * k + 1]))
+    del lde, lde2, leaves, nodes, trace, polys
+    torch.cuda.empty_cache()
