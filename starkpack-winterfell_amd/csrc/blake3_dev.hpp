@@ -155,5 +155,61 @@ __device__ __forceinline__ void hash_stream(uint64_t len, LoadBlock load, uint32
     }
 }
 
+// Chaining value of chunk `c` (clen bytes, 1..1024) of a multi-chunk message: load(block_in_chunk, m) fills a block.
+template <class LoadBlock>
+__device__ __forceinline__ void chunk_cv(uint64_t c, uint32_t clen, LoadBlock load, uint32_t (&cv)[8]) {
+    uint32_t m[16];
+    const uint32_t nblocks = (clen + 63) >> 6;
+    set_iv(cv);
+    for (uint32_t b = 0; b < nblocks; b++) {
+        load(b, m);
+        const uint32_t blen = clen - b * 64 < 64 ? clen - b * 64 : 64;
+        const uint32_t flags = (b == 0 ? CHUNK_START : 0u) | (b == nblocks - 1 ? (uint32_t)CHUNK_END : 0u);
+        compress(cv, m, (uint32_t)c, (uint32_t)(c >> 32), blen, flags);
+    }
+}
+
+// Root of the BLAKE3 tree over n >= 2 chunk chaining values cvs[0..n) (8 words each, in memory): the left subtree
+// of every node covers the largest power of two of chunks strictly smaller than the node's total.
+template <int MAX_DEPTH = 24>
+__device__ __forceinline__ void merge_chunk_cvs(const uint32_t *cvs, uint64_t n, uint32_t (&out)[8]) {
+    uint32_t stack[MAX_DEPTH][8];
+    uint32_t m[16], cv[8];
+    int sp = 0;
+    for (uint64_t c = 0; c < n; c++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) cv[i] = cvs[c * 8 + i];
+        if (c + 1 < n) {
+            uint64_t total = c + 1;
+            while ((total & 1) == 0) {
+                sp--;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    m[i] = stack[sp][i];
+                    m[8 + i] = cv[i];
+                }
+                set_iv(cv);
+                compress(cv, m, 0, 0, 64, PARENT);
+                total >>= 1;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) stack[sp][i] = cv[i];
+            sp++;
+        }
+    }
+    while (sp > 0) {
+        sp--;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            m[i] = stack[sp][i];
+            m[8 + i] = cv[i];
+        }
+        set_iv(cv);
+        compress(cv, m, 0, 0, 64, PARENT | (sp == 0 ? (uint32_t)ROOT : 0u));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = cv[i];
+}
+
 }  // namespace b3
 }  // namespace wf

@@ -322,15 +322,37 @@ __global__ void __launch_bounds__(256) k_hash_rows(HashArgs<F> a) {
         };
         b3::hash_stream<MULTI>(len, load, out);
     } else {
-        auto load = [&](uint64_t bi, uint32_t(&m)[16]) {
-            const uint64_t e0 = bi * EPB;
+        // rows of several traces back to back; blocks are requested in increasing order, so the (trace, column)
+        // position is carried along instead of being recomputed with divisions
+        uint32_t t = 0, col = 0;
+        const T *rowp = a.lde + j * a.row_width;
+        const bool whole_blocks = a.epr % EPB == 0;  // every 64-byte block lies inside one trace's row
+        auto load = [&](uint64_t, uint32_t(&m)[16]) {
+            if (whole_blocks && t < a.n_traces) {
+                const uint4 *q = reinterpret_cast<const uint4 *>(rowp + col);
+                T ev[EPB];
+                uint4 *dstv = reinterpret_cast<uint4 *>(ev);
+#pragma unroll
+                for (uint32_t i = 0; i < 4; i++) dstv[i] = q[i];
+#pragma unroll
+                for (uint32_t i = 0; i < EPB; i++) elem_words<F>(ev[i], &m[i * WPE]);
+                col += EPB;
+                if (col == a.epr) {
+                    col = 0;
+                    t++;
+                    rowp += a.trace_elems;
+                }
+                return;
+            }
 #pragma unroll
             for (uint32_t i = 0; i < EPB; i++) {
-                const uint64_t e = e0 + i;
-                if (e < total_elems) {
-                    const uint64_t t = e / a.epr;
-                    const uint32_t col = (uint32_t)(e - t * a.epr);
-                    elem_words<F>(a.lde[t * a.trace_elems + j * a.row_width + col], &m[i * WPE]);
+                if (t < a.n_traces) {
+                    elem_words<F>(rowp[col], &m[i * WPE]);
+                    if (++col == a.epr) {
+                        col = 0;
+                        t++;
+                        rowp += a.trace_elems;
+                    }
                 } else {
 #pragma unroll
                     for (uint32_t q = 0; q < WPE; q++) m[i * WPE + q] = 0;
@@ -340,6 +362,56 @@ __global__ void __launch_bounds__(256) k_hash_rows(HashArgs<F> a) {
         b3::hash_stream<MULTI>(len, load, out);
     }
     uint4 *dst = reinterpret_cast<uint4 *>(a.leaves + j * 8);
+    dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
+    dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+}
+
+// Rows longer than one BLAKE3 chunk (1024 bytes: packed traces, wide traces): one lane per (row, chunk) computes the
+// chunk chaining values, a second kernel folds each row's chaining values into the leaf.  Keeps the chip busy when
+// there are few, long rows (e.g. 512 packed traces of 2^10 steps: 8192 rows of 80 chunks).
+template <class F>
+__global__ void __launch_bounds__(256) k_hash_chunks(HashArgs<F> a, uint32_t chunks_per_row, uint32_t *cvs) {
+    typedef typename F::T T;
+    constexpr uint32_t EPB = 64 / F::BYTES, WPE = F::BYTES / 4, EPC = 1024 / F::BYTES;
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.n_rows * chunks_per_row) return;
+    // consecutive lanes take consecutive rows of the same chunk index: coalescing across rows like k_hash_rows
+    const uint64_t c = g / a.n_rows, j = g - c * a.n_rows;
+    const uint64_t total_elems = (uint64_t)a.n_traces * a.epr;
+    const uint64_t e0 = c * EPC;
+    const uint32_t celems = (uint32_t)(total_elems - e0 < EPC ? total_elems - e0 : EPC);
+    uint32_t t = (uint32_t)(e0 / a.epr), col = (uint32_t)(e0 - (uint64_t)t * a.epr), left = celems;
+    const T *rowp = a.lde + (uint64_t)t * a.trace_elems + j * a.row_width;
+    auto load = [&](uint32_t, uint32_t(&m)[16]) {
+#pragma unroll
+        for (uint32_t i = 0; i < EPB; i++) {
+            if (left) {
+                elem_words<F>(rowp[col], &m[i * WPE]);
+                left--;
+                if (++col == a.epr) {
+                    col = 0;
+                    rowp += a.trace_elems;
+                }
+            } else {
+#pragma unroll
+                for (uint32_t q = 0; q < WPE; q++) m[i * WPE + q] = 0;
+            }
+        }
+    };
+    uint32_t cv[8];
+    b3::chunk_cv(c, celems * F::BYTES, load, cv);
+    uint4 *dst = reinterpret_cast<uint4 *>(cvs + (j * chunks_per_row + c) * 8);
+    dst[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+    dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+}
+
+__global__ void __launch_bounds__(256) k_hash_merge_chunks(const uint32_t *__restrict__ cvs, uint32_t chunks_per_row,
+                                                           uint64_t n_rows, uint32_t *__restrict__ leaves) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_rows) return;
+    uint32_t out[8];
+    b3::merge_chunk_cvs(cvs + j * chunks_per_row * 8, chunks_per_row, out);
+    uint4 *dst = reinterpret_cast<uint4 *>(leaves + j * 8);
     dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
     dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
 }

@@ -24,6 +24,9 @@ template <class F>
 struct SegCfg {
     static constexpr uint32_t S = 64 / F::BYTES;  // lanes per segment row
     static constexpr uint32_t HP = S / 2;         // lane pairs per row
+    // radix-16 rounds keep 16 values (+ 8 constants) in registers: 2 VGPRs per value for f64; for f128 (4 per value)
+    // that costs half the occupancy and runs slower than radix-4 rounds
+    static constexpr bool RADIX16 = F::BYTES == 8;
 };
 
 template <class T>
@@ -63,9 +66,10 @@ struct SegArgs {
 };
 
 // LDS position -> output index of seg_lds_ntt: radix-16 digits while >= 4 bits remain, then radix-4, then radix-2
+template <class F>
 __device__ __forceinline__ uint32_t seg_digit_reverse(uint32_t pos, uint32_t logD) {
     uint32_t k = 0, cur = logD, sh = 0;
-    while (cur >= 4) {
+    while (SegCfg<F>::RADIX16 && cur >= 4) {
         k |= ((pos >> (cur - 4)) & 15u) << sh;
         sh += 4;
         cur -= 4;
@@ -116,7 +120,7 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
     constexpr uint32_t s_shift = S == 8 ? 3 : 2;
     const uint32_t D = 1u << logD;
     uint32_t cur = logD;
-    if (logD >= 4) {
+    if (SegCfg<F>::RADIX16 && logD >= 4) {
         T w16[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) w16[j] = twd[j * (D >> 4)];
@@ -284,7 +288,7 @@ __global__ void __launch_bounds__(512) k_seg_strided(SegArgs<F> a) {
     __syncthreads();
     for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
         const uint32_t lp = wk & (HP - 1), pos = wk >> hp_shift;
-        const uint32_t k = seg_digit_reverse(pos, a.logD);
+        const uint32_t k = seg_digit_reverse<F>(pos, a.logD);
         P2 v = *reinterpret_cast<P2 *>(x + pos * S + 2 * lp);
         const T f = aux[k];
         v.a = F::mul(v.a, f);
@@ -356,7 +360,7 @@ __global__ void __launch_bounds__(512) k_seg_last(SegArgs<F> a) {
         T *dst = a.dst + ((uint64_t)c * a.n_seg + g) * seg_elems;
         for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
             const uint32_t lp = wk & (HP - 1), pos = wk >> hp_shift;
-            const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse(pos, a.logD) << out_shift);
+            const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << out_shift);
             P2 v = *reinterpret_cast<P2 *>(x + pos * S + 2 * lp);
             if (a.scale_on) {
                 v.a = F::mul(v.a, a.scale);
@@ -367,7 +371,7 @@ __global__ void __launch_bounds__(512) k_seg_last(SegArgs<F> a) {
     } else {
         for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
             const uint32_t lp = wk & (HP - 1), pos = wk >> hp_shift;
-            const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse(pos, a.logD) << out_shift);
+            const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << out_shift);
             const uint64_t row = k * a.rows_per_k + c;
             P2 v = *reinterpret_cast<P2 *>(x + pos * S + 2 * lp);
             const uint32_t B = g * S + 2 * lp;  // global base column of lane a

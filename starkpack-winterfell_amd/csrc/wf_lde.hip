@@ -63,6 +63,7 @@ struct wf_ctx {
     size_t prof_n = 0;
     DevBuf scratch;   // evaluation intermediate [cosets][columns][R]
     DevBuf io[5];     // staging for the host-buffer API: trace, polys, lde, leaves, nodes
+    DevBuf hash_tmp;  // chunk chaining values of rows longer than one BLAKE3 chunk
 };
 
 static void prof_mark(wf_ctx *ctx, hipStream_t st, const char *name) {
@@ -511,7 +512,7 @@ static int run_xpose(wf_ctx *ctx, hipStream_t st, bool to_seg, const void *src, 
 
 // ------------------------------------------------------------------------------------------------- hashing + tree
 template <class F>
-static int run_hash_rows(hipStream_t st, const void *lde, uint64_t trace_elems, uint64_t n_rows, uint32_t row_width,
+static int run_hash_rows(wf_ctx *ctx, hipStream_t st, const void *lde, uint64_t trace_elems, uint64_t n_rows, uint32_t row_width,
                          uint32_t epr, uint32_t n_traces, void *leaves) {
     HashArgs<F> h;
     h.lde = (const typename F::T *)lde;
@@ -523,10 +524,22 @@ static int run_hash_rows(hipStream_t st, const void *lde, uint64_t trace_elems, 
     h.leaves = (uint32_t *)leaves;
     const uint32_t threads = 256;
     const uint64_t grid = (n_rows + threads - 1) / threads;
-    if ((uint64_t)n_traces * epr * F::BYTES <= 1024)  // single BLAKE3 chunk: the stack-free instantiation
+    const uint64_t row_bytes = (uint64_t)n_traces * epr * F::BYTES;
+    if (row_bytes <= 1024) {  // single BLAKE3 chunk: one lane per row, no subtree stack
         hipLaunchKernelGGL((k_hash_rows<F, false>), dim3((uint32_t)grid), dim3(threads), 0, st, h);
-    else
-        hipLaunchKernelGGL((k_hash_rows<F, true>), dim3((uint32_t)grid), dim3(threads), 0, st, h);
+    } else {                  // one lane per (row, chunk), then one lane per row folds the chaining values
+        const uint64_t chunks = (row_bytes + 1023) / 1024;
+        if (chunks > 0xFFFFFFFFull || n_rows * chunks > 0x7FFFFFFFull * threads)
+            return fail(WF_ERR_ARG, "rows too long for one launch");
+        int rc = ensure(ctx->hash_tmp, (size_t)n_rows * chunks * 32);
+        if (rc) return rc;
+        const uint64_t g2 = (n_rows * chunks + threads - 1) / threads;
+        hipLaunchKernelGGL(k_hash_chunks<F>, dim3((uint32_t)g2), dim3(threads), 0, st, h, (uint32_t)chunks,
+                           (uint32_t *)ctx->hash_tmp.p);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_hash_merge_chunks, dim3((uint32_t)grid), dim3(threads), 0, st,
+                           (const uint32_t *)ctx->hash_tmp.p, (uint32_t)chunks, n_rows, (uint32_t *)leaves);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -661,7 +674,7 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
 
     if (d_leaves) {
         prof_mark(ctx, st, "hash_rows");
-        rc = run_hash_rows<F>(st, d_lde, Nrows * row_width, Nrows, (uint32_t)row_width, base_cols, p->n_traces, d_leaves);
+        rc = run_hash_rows<F>(ctx, st, d_lde, Nrows * row_width, Nrows, (uint32_t)row_width, base_cols, p->n_traces, d_leaves);
         if (rc) return rc;
         if (d_nodes) {
             prof_mark(ctx, st, "merkle");
@@ -754,6 +767,7 @@ void wf_ctx_destroy(wf_ctx *ctx) {
     if (ctx->scratch.p) (void)hipFree(ctx->scratch.p);
     for (auto &b : ctx->io)
         if (b.p) (void)hipFree(b.p);
+    if (ctx->hash_tmp.p) (void)hipFree(ctx->hash_tmp.p);
     for (auto e : ctx->prof_ev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1196,7 +1210,7 @@ static int fri_layer_commit_dev(wf_ctx *ctx, hipStream_t st, uint32_t ext, const
                        (T *)d_transposed, rows, folding, ext);
     HIP_TRY(hipGetLastError());
     prof_mark(ctx, st, "fri.hash_values");
-    int rc = run_hash_rows<F>(st, d_transposed, 0, rows, folding * ext, folding * ext, 1, d_leaves);
+    int rc = run_hash_rows<F>(ctx, st, d_transposed, 0, rows, folding * ext, folding * ext, 1, d_leaves);
     if (rc) return rc;
     prof_mark(ctx, st, "fri.merkle");
     rc = run_merkle(st, d_leaves, rows, d_nodes);
@@ -1546,9 +1560,9 @@ int wf_hash_rows(wf_ctx *ctx, uint32_t field, const void *rows, size_t n_rows, s
     hipStream_t st = ctx->stream;
     if (bytes) HIP_TRY(hipMemcpyAsync(ctx->io[2].p, rows, bytes, hipMemcpyHostToDevice, st));
     if (field == WF_FIELD_F64)
-        rc = run_hash_rows<F64>(st, ctx->io[2].p, 0, n_rows, (uint32_t)row_elems, (uint32_t)row_elems, 1, ctx->io[3].p);
+        rc = run_hash_rows<F64>(ctx, st, ctx->io[2].p, 0, n_rows, (uint32_t)row_elems, (uint32_t)row_elems, 1, ctx->io[3].p);
     else
-        rc = run_hash_rows<F128>(st, ctx->io[2].p, 0, n_rows, (uint32_t)row_elems, (uint32_t)row_elems, 1, ctx->io[3].p);
+        rc = run_hash_rows<F128>(ctx, st, ctx->io[2].p, 0, n_rows, (uint32_t)row_elems, (uint32_t)row_elems, 1, ctx->io[3].p);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(digests_out, ctx->io[3].p, n_rows * 32, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
