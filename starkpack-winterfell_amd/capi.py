@@ -81,6 +81,12 @@ def load():
     if _lib is None:
         path = lib_path()
         if not os.path.exists(path):
+            # a fresh checkout: compile in-tree if the ROCm toolchain is there (hipcc cross-compiles without a GPU)
+            import shutil
+            if os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc"):
+                from .build import build
+                build()
+        if not os.path.exists(path):
             raise WfError(-30, f"{path} not built (run __graft_entry__.build() / make -C csrc)")
         _preload_torch_hip_runtime()
         L = C.CDLL(path)
