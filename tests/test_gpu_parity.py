@@ -199,3 +199,36 @@ def test_large_transform_plans(ctx, orc, capi, field, logR, logB, n_cols):
     want_i = cols[0].copy()
     orc.interpolate_poly(field, want_i, 1 << logR, 1, tw_inv)
     assert np.array_equal(ctx.fft_interpolate_poly(field, 1, cols[0]), want_i)
+
+
+def _random_configs(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        field = int(rng.integers(1, 3))
+        ext = int(rng.integers(1, 4 if field == F64 else 3))
+        logR = int(rng.integers(3, 13))
+        logB = int(rng.integers(1, 5))
+        n_cols = int(rng.integers(1, 21))
+        n_traces = int(rng.integers(1, 5))
+        if (1 << (logR + logB)) * n_cols * ext * n_traces > (1 << 22):
+            n_traces, n_cols = 1, min(n_cols, 8)
+        offset = int(rng.integers(2, 2**62))
+        out.append((field, ext, logR, logB, n_cols, n_traces, offset))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _random_configs(48, 20240661), ids=lambda c: "-".join(str(x) for x in c[:6]))
+def test_random_shapes(ctx, orc, capi, cfg):
+    """Seeded sweep over shapes (field, extension, length, blowup, width, packed traces) and random domain offsets."""
+    field, ext, logR, logB, n_cols, n_traces, offset = cfg
+    rng = np.random.default_rng(offset % 2**32)
+    traces = [rand_cols(rng, field, n_cols, (1 << logR) * ext) for _ in range(n_traces)]
+    want = orc.build_trace_commitment(field, traces, ext, logR, logB, offset)
+    params = capi.make_params(field, ext, logR, logB, n_cols, n_traces, offset)
+    got = ctx.trace_commit(params, [c for t in traces for c in t])
+    for t in range(n_traces):
+        assert np.array_equal(got["lde"][t], want["lde"][t])
+        for c in range(n_cols):
+            assert np.array_equal(got["polys"][t * n_cols + c], want["polys"][t][c])
+    assert np.array_equal(got["nodes"], want["nodes"])
