@@ -81,11 +81,13 @@ int wf_ctx_synchronize(wf_ctx *ctx);
 /* The context's hipStream_t (as void*), for callers that interleave their own work. */
 void *wf_ctx_stream(wf_ctx *ctx);
 
-/* Per-launch timing of the *_commit_dev calls: with profiling enabled an event is recorded on the call's stream in
- * front of every kernel launch and at the end of the call; events accumulate over calls.  wf_ctx_profile_read waits
+/* Timing of the *_commit_dev calls with HIP events on the call's stream.  on = 1: one event in front of every logical
+ * kernel (names "interpolate", "evaluate", "hash_rows", "merkle") and at the end of the call -- 5 events per
+ * commitment, ~1 % overhead; on = 2: an event in front of every kernel launch (names such as
+ * "evaluate.strided_pass"; ~3 % overhead); on = 0: off.  Events accumulate over calls.  wf_ctx_profile_read waits
  * for the last recorded event, returns the number of (name, milliseconds) pairs written (at most max_entries) and
- * clears the log; names are static strings such as "evaluate.strided_pass" ("between_calls" = gap to the next
- * call).  Used by bench.py for the roofline figures; off by default. */
+ * clears the log ("between_calls" = gap to the next call).  Used by bench.py for the roofline figures; off by
+ * default. */
 int wf_ctx_profile_enable(wf_ctx *ctx, int on);
 int wf_ctx_profile_read(wf_ctx *ctx, int max_entries, const char **names, float *ms);
 

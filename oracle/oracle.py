@@ -21,8 +21,12 @@ ELEM_WORDS = {F64: 1, F128: 2}
 
 def build(force: bool = False) -> str:
     """Compile oracle/liboracle.so with gcc (oracle/Makefile)."""
-    if force or not os.path.exists(_LIB_PATH):
-        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    import shutil
+    if shutil.which("make") and shutil.which("gcc"):  # make is a no-op when the library is up to date
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []) + ["liboracle.so"],
+                              stdout=subprocess.DEVNULL)
+    elif not os.path.exists(_LIB_PATH):
+        raise RuntimeError("oracle/liboracle.so is missing and there is no gcc/make to build it")
     return _LIB_PATH
 
 

@@ -19,7 +19,7 @@ leaves = torch.empty((N, 32), dtype=torch.uint8, device=dev)
 nodes = torch.empty((N, 32), dtype=torch.uint8, device=dev)
 p = capi.make_params(field, ext, logR, logB, n_cols, n_traces)
 s = torch.cuda.Stream(device=dev)
-ctx.profile_enable(True)
+ctx.profile_enable(2)
 with torch.cuda.stream(s):
     for _ in range(2):
         ctx.trace_commit_dev(p, trace.data_ptr(), polys.data_ptr(), lde.data_ptr(), leaves.data_ptr(), nodes.data_ptr(), s.cuda_stream)

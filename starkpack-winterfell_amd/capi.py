@@ -183,8 +183,9 @@ class Context:
     def synchronize(self):
         _check(load().wf_ctx_synchronize(self._h))
 
-    def profile_enable(self, on: bool = True):
-        _check(load().wf_ctx_profile_enable(self._h, int(on)))
+    def profile_enable(self, level: int = 1):
+        """0 off, 1 one event per logical kernel, 2 one event per launch."""
+        _check(load().wf_ctx_profile_enable(self._h, int(level)))
 
     def profile_read(self):
         """[(launch name, milliseconds)] of the *_commit_dev calls since the last read (waits for them)."""

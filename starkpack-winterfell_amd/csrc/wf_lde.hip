@@ -57,6 +57,7 @@ struct wf_ctx {
     // 2 = coset bases (aux = log blowup), 3 = output series for interpolate_with_offset
     std::map<std::tuple<int, int, int, int, uint64_t, uint64_t>, TableSet> tables;
     // optional per-launch timing (wf_ctx_profile_*): an event is recorded in front of every kernel launch
+    int prof_level = 0;  // 0 off, 1 one event per logical kernel (interpolate / evaluate / hash_rows / merkle), 2 per launch
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
     std::vector<const char *> prof_name;
@@ -66,8 +67,26 @@ struct wf_ctx {
     DevBuf hash_tmp;  // chunk chaining values of rows longer than one BLAKE3 chunk
 };
 
+// logical kernel of a mark: the text before the first '.', with the layout changes counted as interpolation
+static int prof_group(const char *name) {
+    if (!strncmp(name, "layout", 6) || !strncmp(name, "interpolate", 11)) return 1;
+    if (!strncmp(name, "evaluate", 8)) return 2;
+    if (!strncmp(name, "hash_rows", 9)) return 3;
+    if (!strncmp(name, "merkle", 6)) return 4;
+    if (!strncmp(name, "between_calls", 13)) return 5;
+    return 6 + (int)(unsigned char)name[0] + 256 * (int)(unsigned char)name[4];
+}
+
 static void prof_mark(wf_ctx *ctx, hipStream_t st, const char *name) {
     if (!ctx->prof_on) return;
+    if (ctx->prof_level == 1 && ctx->prof_n > 0 && prof_group(ctx->prof_name[ctx->prof_n - 1]) == prof_group(name)) return;
+    if (ctx->prof_level == 1) {  // coarse marks carry the logical kernel's name
+        switch (prof_group(name)) {
+            case 1: name = "interpolate"; break;
+            case 2: name = "evaluate"; break;
+            default: break;
+        }
+    }
     if (ctx->prof_n == ctx->prof_ev.size()) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return;
@@ -784,6 +803,7 @@ void *wf_ctx_stream(wf_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 int wf_ctx_profile_enable(wf_ctx *ctx, int on) {
     if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
     ctx->prof_on = on != 0;
+    ctx->prof_level = on == 1 ? 1 : 2;
     ctx->prof_n = 0;
     return 0;
 }
