@@ -61,6 +61,9 @@ struct SegArgs {
     uint32_t total_base_cols;  // over all traces
     uint32_t coset0;           // first coset computed by this call (coset sharding across GPUs); 0 otherwise
     uint32_t rows_per_k;       // cosets held by the output matrix: row = k * rows_per_k + local coset (= blowup unless sharded)
+    // coset-packed lanes (narrow matrices: total_base_cols <= S/2): a row holds 2^cpr_log cosets x 2^lg_log lanes;
+    // lane L = (local coset L >> lg_log, column L & (2^lg_log - 1)); n_cosets then counts coset GROUPS
+    uint32_t cpr_log, lg_log;
     uint64_t row_width;
     uint64_t trace_lde_elems;
 };
@@ -223,7 +226,7 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
 // Strided pass.  grid.x = n_cosets * n_seg * O * I ; work-group = (coset c, segment g, outer o, inner i)
 // EVAL only tags the instantiation (interpolation = 0 / coset evaluation = 1) so that profilers list the two uses
 // under different kernel names, like k_seg_last<F, OUT>.
-template <class F, int EVAL>
+template <class F, int EVAL, bool PACKED = false>
 __global__ void __launch_bounds__(512) k_seg_strided(SegArgs<F> a) {
     typedef typename F::T T;
     typedef Pair<T> P2;
@@ -247,13 +250,26 @@ __global__ void __launch_bounds__(512) k_seg_strided(SegArgs<F> a) {
     T *dst = a.dst + ((uint64_t)c * a.n_seg + g) * seg_elems;
 
     Pow2L<F> pre = a.pre;
-    if (a.pre_on) {
+    // PACKED: the two lanes of this thread may belong to different cosets; their tables and h_c^i factors
+    Pow2L<F> pre_a = a.pre, pre_b = a.pre;
+    const uint32_t lane_a = 2 * (threadIdx.x & (HP - 1)), lane_b = lane_a + 1;  // blockDim is a multiple of HP
+    // a packed lane is live if its column exists and its local coset is one of the 2^cpr_log of this row
+    const bool act_a = PACKED && (lane_a & ((1u << a.lg_log) - 1)) < a.total_base_cols && (lane_a >> a.lg_log) < (1u << a.cpr_log);
+    const bool act_b = PACKED && (lane_b & ((1u << a.lg_log) - 1)) < a.total_base_cols && (lane_b >> a.lg_log) < (1u << a.cpr_log);
+    if (PACKED && a.pre_on) {
+        const uint32_t ca = a.coset0 + (c << a.cpr_log) + (act_a ? (lane_a >> a.lg_log) : 0);
+        const uint32_t cb = a.coset0 + (c << a.cpr_log) + (act_b ? (lane_b >> a.lg_log) : 0);
+        pre_a.lo += (uint64_t)ca * a.pre_lo_stride;
+        pre_a.hi += (uint64_t)ca * a.pre_hi_stride;
+        pre_b.lo += (uint64_t)cb * a.pre_lo_stride;
+        pre_b.hi += (uint64_t)cb * a.pre_hi_stride;
+    } else if (a.pre_on) {
         pre.lo += (uint64_t)(a.coset0 + c) * a.pre_lo_stride;
         pre.hi += (uint64_t)(a.coset0 + c) * a.pre_hi_stride;
     }
     for (uint32_t e = threadIdx.x; e < D; e += blockDim.x) {
         twd[e] = a.digit_tw[e];
-        if (a.pre_on) aux[e] = pre.get((uint64_t)e * a.I);  // h_c^(d*I); the h_c^i part goes into the output table
+        if (!PACKED && a.pre_on) aux[e] = pre.get((uint64_t)e * a.I);  // h_c^(d*I); h_c^i goes into the output table
     }
     __syncthreads();
 
@@ -261,11 +277,19 @@ __global__ void __launch_bounds__(512) k_seg_strided(SegArgs<F> a) {
     const uint64_t row0 = o * D * a.I + i;  // row index of d = 0; rows of this group are I apart
     for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
         const uint32_t lp = wk & (HP - 1), d = wk >> hp_shift;
-        P2 v = *reinterpret_cast<const P2 *>(src + (row0 + (uint64_t)d * a.I) * S + 2 * lp);
-        if (a.pre_on) {
-            const T f = aux[d];
-            v.a = F::mul(v.a, f);
-            v.b = F::mul(v.b, f);
+        P2 v;
+        if (PACKED && a.pre_on) {  // replicate the polynomial's lanes into every coset group of the row
+            const uint32_t lgm = (1u << a.lg_log) - 1, cola = lane_a & lgm, colb = lane_b & lgm;
+            const T *srow = src + (row0 + (uint64_t)d * a.I) * S;
+            v.a = act_a ? F::mul(srow[cola], pre_a.get((uint64_t)d * a.I)) : F::zero();
+            v.b = act_b ? F::mul(srow[colb], pre_b.get((uint64_t)d * a.I)) : F::zero();
+        } else {
+            v = *reinterpret_cast<const P2 *>(src + (row0 + (uint64_t)d * a.I) * S + 2 * lp);
+            if (a.pre_on) {
+                const T f = aux[d];
+                v.a = F::mul(v.a, f);
+                v.b = F::mul(v.b, f);
+            }
         }
         *reinterpret_cast<P2 *>(x + d * S + 2 * lp) = v;
     }
@@ -276,8 +300,8 @@ __global__ void __launch_bounds__(512) k_seg_strided(SegArgs<F> a) {
     {
         const uint32_t tw_shift = a.logN - a.logD - (63 - __builtin_clzll(a.I));
         T start = a.scale_on ? a.scale : F::one();
-        if (a.pre_on) start = pre.get(i);
-        const bool trivial = !a.scale_on && !a.pre_on;
+        if (!PACKED && a.pre_on) start = pre.get(i);
+        const bool trivial = !a.scale_on && (PACKED || !a.pre_on);
         for (uint32_t k = threadIdx.x; k < D; k += blockDim.x) {
             const uint64_t e = ((uint64_t)k * i) << tw_shift;
             T f = a.tw.get(e);
@@ -286,6 +310,11 @@ __global__ void __launch_bounds__(512) k_seg_strided(SegArgs<F> a) {
         }
     }
     __syncthreads();
+    T start_a = F::one(), start_b = F::one();
+    if (PACKED && a.pre_on) {  // h_c^i of each lane's coset (the table above carries only the twiddle)
+        start_a = pre_a.get(i);
+        start_b = pre_b.get(i);
+    }
     for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
         const uint32_t lp = wk & (HP - 1), pos = wk >> hp_shift;
         const uint32_t k = seg_digit_reverse<F>(pos, a.logD);
@@ -293,13 +322,17 @@ __global__ void __launch_bounds__(512) k_seg_strided(SegArgs<F> a) {
         const T f = aux[k];
         v.a = F::mul(v.a, f);
         v.b = F::mul(v.b, f);
+        if (PACKED && a.pre_on) {
+            v.a = F::mul(v.a, start_a);
+            v.b = F::mul(v.b, start_b);
+        }
         *reinterpret_cast<P2 *>(dst + (row0 + (uint64_t)k * a.I) * S + 2 * lp) = v;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Last pass.  grid.x = n_cosets * n_seg * O ; work-group = (coset c, segment g, row block o) of D contiguous rows.
-template <class F, int OUT>
+template <class F, int OUT, bool PACKED = false>
 __global__ void __launch_bounds__(512) k_seg_last(SegArgs<F> a) {
     typedef typename F::T T;
     typedef Pair<T> P2;
@@ -332,23 +365,42 @@ __global__ void __launch_bounds__(512) k_seg_last(SegArgs<F> a) {
         }
     }
 
-    Pow2L<F> pre = a.pre;
-    if (a.pre_on) {
+    Pow2L<F> pre = a.pre, pre_a = a.pre, pre_b = a.pre;
+    const uint32_t lane_a = 2 * (threadIdx.x & (HP - 1)), lane_b = lane_a + 1;
+    const bool act_a = PACKED && (lane_a & ((1u << a.lg_log) - 1)) < a.total_base_cols && (lane_a >> a.lg_log) < (1u << a.cpr_log);
+    const bool act_b = PACKED && (lane_b & ((1u << a.lg_log) - 1)) < a.total_base_cols && (lane_b >> a.lg_log) < (1u << a.cpr_log);
+    if (PACKED && a.pre_on) {
+        const uint32_t ca = a.coset0 + (c << a.cpr_log) + (act_a ? (lane_a >> a.lg_log) : 0);
+        const uint32_t cb = a.coset0 + (c << a.cpr_log) + (act_b ? (lane_b >> a.lg_log) : 0);
+        pre_a.lo += (uint64_t)ca * a.pre_lo_stride;
+        pre_a.hi += (uint64_t)ca * a.pre_hi_stride;
+        pre_b.lo += (uint64_t)cb * a.pre_lo_stride;
+        pre_b.hi += (uint64_t)cb * a.pre_hi_stride;
+    } else if (a.pre_on) {
         pre.lo += (uint64_t)(a.coset0 + c) * a.pre_lo_stride;
         pre.hi += (uint64_t)(a.coset0 + c) * a.pre_hi_stride;
     }
     for (uint32_t e = threadIdx.x; e < D; e += blockDim.x) {
         twd[e] = a.digit_tw[e];
-        if (a.pre_on) aux[e] = pre.get(e);  // single-pass evaluation: row index = coefficient index
+        if (!PACKED && a.pre_on) aux[e] = pre.get(e);  // single-pass evaluation: row index = coefficient index
     }
     __syncthreads();
     const uint32_t nitems = D * HP;
     for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
-        P2 v = *reinterpret_cast<const P2 *>(src + 2 * (uint64_t)wk);
-        if (a.pre_on) {
-            const T f = aux[wk >> hp_shift];
-            v.a = F::mul(v.a, f);
-            v.b = F::mul(v.b, f);
+        P2 v;
+        if (PACKED && a.pre_on) {  // single pass: replicate the polynomial row into the coset groups, scaled per lane
+            const uint32_t d = wk >> hp_shift;
+            const uint32_t lgm = (1u << a.lg_log) - 1, cola = lane_a & lgm, colb = lane_b & lgm;
+            const T *srow = src + (uint64_t)d * S;
+            v.a = act_a ? F::mul(srow[cola], pre_a.get(d)) : F::zero();
+            v.b = act_b ? F::mul(srow[colb], pre_b.get(d)) : F::zero();
+        } else {
+            v = *reinterpret_cast<const P2 *>(src + 2 * (uint64_t)wk);
+            if (a.pre_on) {
+                const T f = aux[wk >> hp_shift];
+                v.a = F::mul(v.a, f);
+                v.b = F::mul(v.b, f);
+            }
         }
         *reinterpret_cast<P2 *>(x + 2 * wk) = v;
     }
@@ -367,6 +419,21 @@ __global__ void __launch_bounds__(512) k_seg_last(SegArgs<F> a) {
                 v.b = F::mul(v.b, a.scale);
             }
             *reinterpret_cast<P2 *>(dst + k * S + 2 * lp) = v;
+        }
+    } else if (PACKED) {
+        const uint32_t lgm = (1u << a.lg_log) - 1;
+        for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
+            const uint32_t pos = wk >> hp_shift;
+            const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << out_shift);
+            P2 v = *reinterpret_cast<P2 *>(x + pos * S + lane_a);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t L = lane_a + h, col = L & lgm, cl = L >> a.lg_log;
+                if (!(h ? act_b : act_a)) continue;
+                const uint32_t t0 = col / a.base_cols, c0 = col - t0 * a.base_cols;
+                const uint64_t row = k * a.rows_per_k + ((uint64_t)c << a.cpr_log) + cl;
+                a.dst[(uint64_t)t0 * a.trace_lde_elems + row * a.row_width + c0] = h ? v.b : v.a;
+            }
         }
     } else {
         for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {

@@ -385,6 +385,8 @@ static int seg_launch_dims(uint32_t logD, uint32_t &threads, size_t &lds) {
     if (lds > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void *)k_seg_strided<F, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_TRY(hipFuncSetAttribute((const void *)k_seg_strided<F, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_seg_strided<F, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_seg_last<F, SEG_OUT_ROWS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_TRY(hipFuncSetAttribute((const void *)k_seg_last<F, SEG_OUT_SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_TRY(hipFuncSetAttribute((const void *)k_seg_last<F, SEG_OUT_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
@@ -437,6 +439,23 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
     a.row_width = d.row_width;
     a.trace_lde_elems = d.trace_lde_elems;
     const T inv_n = inverse ? f_inv<F>(F::from_u128_canonical((u128)1 << d.logN)) : F::one();
+    // narrow matrices (evaluation of <= S/2 base columns: composition / DEEP polynomials): pack several cosets into the
+    // lanes of a row instead of leaving them empty
+    uint32_t n_groups = d.n_cosets;
+    bool packed = false;
+    if (d.rows_out && d.n_seg == 1 && d.total_base_cols * 2 <= SegCfg<F>::S && d.n_cosets >= 2) {
+        uint32_t lg = 0;
+        while ((1u << lg) < d.total_base_cols) lg++;
+        uint32_t cpr = 0;
+        while ((2u << cpr) <= (SegCfg<F>::S >> lg) && d.n_cosets % (2u << cpr) == 0) cpr++;
+        if (cpr > 0) {
+            packed = true;
+            a.cpr_log = cpr;
+            a.lg_log = lg;
+            n_groups = d.n_cosets >> cpr;
+            a.n_cosets = n_groups;
+        }
+    }
     const char *tag_s = d.rows_out ? "evaluate.strided_pass" : "interpolate.strided_pass";
     const char *tag_l = d.rows_out ? "evaluate.last_pass" : "interpolate.last_pass";
 
@@ -466,10 +485,12 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         size_t lds;
         rc = seg_launch_dims<F>(a.logD, threads, lds);
         if (rc) return rc;
-        const uint64_t grid = (uint64_t)d.n_cosets * d.n_seg * a.O * a.I;
+        const uint64_t grid = (uint64_t)n_groups * d.n_seg * a.O * a.I;
         if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
         prof_mark(ctx, st, tag_s);
-        if (d.rows_out)
+        if (d.rows_out && packed)
+            hipLaunchKernelGGL((k_seg_strided<F, 1, true>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
+        else if (d.rows_out)
             hipLaunchKernelGGL((k_seg_strided<F, 1>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
         else
             hipLaunchKernelGGL((k_seg_strided<F, 0>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
@@ -496,10 +517,12 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         size_t lds;
         rc = seg_launch_dims<F>(a.logD, threads, lds);
         if (rc) return rc;
-        const uint64_t grid = (uint64_t)d.n_cosets * d.n_seg * a.O;
+        const uint64_t grid = (uint64_t)n_groups * d.n_seg * a.O;
         if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
         prof_mark(ctx, st, tag_l);
-        if (d.rows_out)
+        if (d.rows_out && packed)
+            hipLaunchKernelGGL((k_seg_last<F, SEG_OUT_ROWS, true>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
+        else if (d.rows_out)
             hipLaunchKernelGGL((k_seg_last<F, SEG_OUT_ROWS>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
         else
             hipLaunchKernelGGL((k_seg_last<F, SEG_OUT_SEG>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
