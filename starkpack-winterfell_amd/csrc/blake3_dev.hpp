@@ -12,9 +12,6 @@ namespace b3 {
 
 enum : uint32_t { CHUNK_START = 1, CHUNK_END = 2, PARENT = 4, ROOT = 8 };
 
-__device__ __constant__ const uint32_t IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au,
-                                                0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
-
 // message word index used at position i of round r (sigma applied r times)
 __host__ __device__ constexpr int sched(int r, int i) {
     constexpr int P[16] = {2, 6, 3, 10, 7, 0, 4, 13, 1, 11, 12, 5, 9, 14, 15, 8};
@@ -89,69 +86,19 @@ __device__ __forceinline__ void merge(const uint32_t (&m)[16], uint32_t (&out)[8
     compress(out, m, 0, 0, 64, CHUNK_START | CHUNK_END | ROOT);
 }
 
-// Hash of a message of `len` bytes (len a multiple of 4) delivered block by block:
+// Hash of a message of `len` <= 1024 bytes (one chunk; len a multiple of 4) delivered block by block:
 // load(block_index, m) must fill the 16 words of 64-byte block `block_index`, zero-padded past `len`.
-// MAX_DEPTH bounds the subtree stack: messages up to 2^MAX_DEPTH KiB.
-// MULTI = false promises len <= 1024 (one chunk) and keeps the subtree stack (private memory) out of the kernel.
-template <bool MULTI, class LoadBlock, int MAX_DEPTH = 20>
+// Longer messages go through chunk_cv + merge_chunk_cvs below (one lane per chunk).
+template <class LoadBlock>
 __device__ __forceinline__ void hash_stream(uint64_t len, LoadBlock load, uint32_t (&out)[8]) {
     uint32_t m[16];
-    if (!MULTI || len <= 1024) {
-        set_iv(out);
-        uint32_t nblocks = len == 0 ? 1u : (uint32_t)((len + 63) >> 6);
-        for (uint32_t b = 0; b < nblocks; b++) {
-            load((uint64_t)b, m);
-            uint32_t blen = (uint32_t)(len - (uint64_t)b * 64 < 64 ? len - (uint64_t)b * 64 : 64);
-            uint32_t flags = (b == 0 ? CHUNK_START : 0u) | (b == nblocks - 1 ? (CHUNK_END | ROOT) : 0u);
-            compress(out, m, 0, 0, blen, flags);
-        }
-        return;
-    }
-    if constexpr (MULTI) {
-    uint32_t stack[MAX_DEPTH][8];
-    int sp = 0;
-    uint64_t nchunks = (len + 1023) >> 10;
-    uint32_t cv[8];
-    for (uint64_t c = 0; c < nchunks; c++) {
-        uint64_t clen = len - c * 1024 < 1024 ? len - c * 1024 : 1024;
-        uint32_t nblocks = (uint32_t)((clen + 63) >> 6);
-        set_iv(cv);
-        for (uint32_t b = 0; b < nblocks; b++) {
-            load(c * 16 + b, m);
-            uint32_t blen = (uint32_t)(clen - (uint64_t)b * 64 < 64 ? clen - (uint64_t)b * 64 : 64);
-            uint32_t flags = (b == 0 ? CHUNK_START : 0u) | (b == nblocks - 1 ? (uint32_t)CHUNK_END : 0u);
-            compress(cv, m, (uint32_t)c, (uint32_t)(c >> 32), blen, flags);
-        }
-        if (c + 1 < nchunks) {
-            uint64_t total = c + 1;
-            while ((total & 1) == 0) {  // merge completed subtrees
-                sp--;
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    m[i] = stack[sp][i];
-                    m[8 + i] = cv[i];
-                }
-                set_iv(cv);
-                compress(cv, m, 0, 0, 64, PARENT);
-                total >>= 1;
-            }
-#pragma unroll
-            for (int i = 0; i < 8; i++) stack[sp][i] = cv[i];
-            sp++;
-        }
-    }
-    while (sp > 0) {
-        sp--;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            m[i] = stack[sp][i];
-            m[8 + i] = cv[i];
-        }
-        set_iv(cv);
-        compress(cv, m, 0, 0, 64, PARENT | (sp == 0 ? (uint32_t)ROOT : 0u));
-    }
-#pragma unroll
-    for (int i = 0; i < 8; i++) out[i] = cv[i];
+    set_iv(out);
+    const uint32_t nblocks = len == 0 ? 1u : (uint32_t)((len + 63) >> 6);
+    for (uint32_t b = 0; b < nblocks; b++) {
+        load((uint64_t)b, m);
+        const uint32_t blen = (uint32_t)(len - (uint64_t)b * 64 < 64 ? len - (uint64_t)b * 64 : 64);
+        const uint32_t flags = (b == 0 ? CHUNK_START : 0u) | (b == nblocks - 1 ? (CHUNK_END | ROOT) : 0u);
+        compress(out, m, 0, 0, blen, flags);
     }
 }
 

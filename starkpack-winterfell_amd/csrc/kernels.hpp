@@ -285,7 +285,8 @@ __device__ __forceinline__ void elem_words<F128>(U128 v, uint32_t *w) {
     w[3] = (uint32_t)(v.hi >> 32);
 }
 
-template <class F, bool MULTI>
+// Rows of at most one BLAKE3 chunk (1024 bytes); longer rows use k_hash_chunks + k_hash_merge_chunks.
+template <class F>
 __global__ void __launch_bounds__(256) k_hash_rows(HashArgs<F> a) {
     typedef typename F::T T;
     constexpr uint32_t EPB = 64 / F::BYTES;  // elements per 64-byte block
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(256) k_hash_rows(HashArgs<F> a) {
                 }
             }
         };
-        b3::hash_stream<MULTI>(len, load, out);
+        b3::hash_stream(len, load, out);
     } else {
         // rows of several traces back to back; blocks are requested in increasing order, so the (trace, column)
         // position is carried along instead of being recomputed with divisions
@@ -359,7 +360,7 @@ __global__ void __launch_bounds__(256) k_hash_rows(HashArgs<F> a) {
                 }
             }
         };
-        b3::hash_stream<MULTI>(len, load, out);
+        b3::hash_stream(len, load, out);
     }
     uint4 *dst = reinterpret_cast<uint4 *>(a.leaves + j * 8);
     dst[0] = make_uint4(out[0], out[1], out[2], out[3]);

@@ -568,7 +568,7 @@ static int run_hash_rows(wf_ctx *ctx, hipStream_t st, const void *lde, uint64_t 
     const uint64_t grid = (n_rows + threads - 1) / threads;
     const uint64_t row_bytes = (uint64_t)n_traces * epr * F::BYTES;
     if (row_bytes <= 1024) {  // single BLAKE3 chunk: one lane per row, no subtree stack
-        hipLaunchKernelGGL((k_hash_rows<F, false>), dim3((uint32_t)grid), dim3(threads), 0, st, h);
+        hipLaunchKernelGGL(k_hash_rows<F>, dim3((uint32_t)grid), dim3(threads), 0, st, h);
     } else {                  // one lane per (row, chunk), then one lane per row folds the chaining values
         const uint64_t chunks = (row_bytes + 1023) / 1024;
         if (chunks > 0xFFFFFFFFull || n_rows * chunks > 0x7FFFFFFFull * threads)
