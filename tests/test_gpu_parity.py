@@ -85,6 +85,9 @@ CASES = [
     (F128, 1, 12, 3, 10, 2),   # two passes, packed
     (F128, 2, 11, 2, 3, 1),    # quadratic extension over f128
     (F128, 1, 7, 3, 10, 8),    # 8 packed traces: 1280-byte combined rows -> multi-chunk BLAKE3
+    (F64, 1, 8, 1, 255, 1),    # MAX_TRACE_WIDTH columns (air/src/air/trace_info.rs:37): 32 segments, 2040-byte rows
+    (F64, 1, 11, 7, 2, 1),     # blowup 128 on a two-pass transform, narrow matrix (coset-packed lanes)
+    (F128, 2, 4, 1, 127, 2),   # 508 base columns per row x 2 traces: 16 KiB rows, 16 BLAKE3 chunks each
 ]
 
 
