@@ -315,10 +315,15 @@ __global__ void __launch_bounds__(512) k_seg_strided(SegArgs<F> a) {
         start_a = pre_a.get(i);
         start_b = pre_b.get(i);
     }
-    for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
-        const uint32_t lp = wk & (HP - 1), pos = wk >> hp_shift;
-        const uint32_t k = seg_digit_reverse<F>(pos, a.logD);
-        P2 v = *reinterpret_cast<P2 *>(x + pos * S + 2 * lp);
+    // this thread's row positions are pos0 + j * pstride (see k_seg_last): rev(pos) = rev(pos0) | rev(j * pstride)
+    const uint32_t pstride = blockDim.x >> hp_shift, pos0 = threadIdx.x >> hp_shift;
+    if (pos0 >= D) return;
+    const uint32_t k0 = seg_digit_reverse<F>(pos0, a.logD);
+    T *dst_lane = dst + row0 * S + lane_a;
+    const uint64_t k_stride = a.I * S;
+    for (uint32_t pj = 0; pj < D; pj += pstride) {
+        const uint32_t k = k0 | seg_digit_reverse<F>(pj, a.logD);
+        P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
         const T f = aux[k];
         v.a = F::mul(v.a, f);
         v.b = F::mul(v.b, f);
@@ -326,7 +331,7 @@ __global__ void __launch_bounds__(512) k_seg_strided(SegArgs<F> a) {
             v.a = F::mul(v.a, start_a);
             v.b = F::mul(v.b, start_b);
         }
-        *reinterpret_cast<P2 *>(dst + (row0 + (uint64_t)k * a.I) * S + 2 * lp) = v;
+        *reinterpret_cast<P2 *>(dst_lane + (uint64_t)k * k_stride) = v;
     }
 }
 
@@ -407,52 +412,64 @@ __global__ void __launch_bounds__(512) k_seg_last(SegArgs<F> a) {
     __syncthreads();
     seg_lds_ntt<F>(x, twd, a.logD);
 
+    // Store.  Work item = (row position pos, lane pair); this thread's positions are pos0 + j * pstride, j = 0, 1, ..
+    // (pstride is a power of two > pos0), so its output indices are rev(pos0) | rev(j * pstride): the per-thread
+    // part is computed once, the per-iteration part is wave-uniform (scalar ALU), and everything that depends only on
+    // the lane (column, trace, destination base) is hoisted out of the loop.
     const uint32_t out_shift = a.logN - a.logD;
+    const uint32_t pstride = blockDim.x >> hp_shift, pos0 = threadIdx.x >> hp_shift;
+    const uint32_t k0 = seg_digit_reverse<F>(pos0, a.logD);
+    if (pos0 >= D) return;  // more threads than work items (tiny transforms)
     if (OUT == SEG_OUT_SEG) {
-        T *dst = a.dst + ((uint64_t)c * a.n_seg + g) * seg_elems;
-        for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
-            const uint32_t lp = wk & (HP - 1), pos = wk >> hp_shift;
-            const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << out_shift);
-            P2 v = *reinterpret_cast<P2 *>(x + pos * S + 2 * lp);
+        T *dst = a.dst + ((uint64_t)c * a.n_seg + g) * seg_elems + lane_a;
+        for (uint32_t pj = 0; pj < D; pj += pstride) {
+            const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, a.logD)) << out_shift);
+            P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
             if (a.scale_on) {
                 v.a = F::mul(v.a, a.scale);
                 v.b = F::mul(v.b, a.scale);
             }
-            *reinterpret_cast<P2 *>(dst + k * S + 2 * lp) = v;
-        }
-    } else if (PACKED) {
-        const uint32_t lgm = (1u << a.lg_log) - 1;
-        for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
-            const uint32_t pos = wk >> hp_shift;
-            const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << out_shift);
-            P2 v = *reinterpret_cast<P2 *>(x + pos * S + lane_a);
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const uint32_t L = lane_a + h, col = L & lgm, cl = L >> a.lg_log;
-                if (!(h ? act_b : act_a)) continue;
-                const uint32_t t0 = col / a.base_cols, c0 = col - t0 * a.base_cols;
-                const uint64_t row = k * a.rows_per_k + ((uint64_t)c << a.cpr_log) + cl;
-                a.dst[(uint64_t)t0 * a.trace_lde_elems + row * a.row_width + c0] = h ? v.b : v.a;
-            }
+            *reinterpret_cast<P2 *>(dst + k * S) = v;
         }
     } else {
-        for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
-            const uint32_t lp = wk & (HP - 1), pos = wk >> hp_shift;
-            const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << out_shift);
-            const uint64_t row = k * a.rows_per_k + c;
-            P2 v = *reinterpret_cast<P2 *>(x + pos * S + 2 * lp);
-            const uint32_t B = g * S + 2 * lp;  // global base column of lane a
-            if (B >= a.total_base_cols) continue;
-            const uint32_t t0 = B / a.base_cols, c0 = B - t0 * a.base_cols;
-            T *p0 = a.dst + (uint64_t)t0 * a.trace_lde_elems + row * a.row_width + c0;
-            if (c0 + 1 < a.base_cols && (c0 & 1) == 0) {
-                *reinterpret_cast<P2 *>(p0) = v;  // both lanes in the same trace, 16-byte aligned
+        // destination of each lane for k = 0: dst + trace * trace_elems + (coset) * row_width + column
+        const uint64_t k_stride = (uint64_t)a.rows_per_k * a.row_width;  // elements between consecutive k
+        T *pa = nullptr, *pb = nullptr;
+        bool pair_store = false;
+        if (PACKED) {
+            const uint32_t lgm = (1u << a.lg_log) - 1;
+            if (act_a) {
+                const uint32_t col = lane_a & lgm, t0 = col / a.base_cols;
+                pa = a.dst + (uint64_t)t0 * a.trace_lde_elems +
+                     (((uint64_t)c << a.cpr_log) + (lane_a >> a.lg_log)) * a.row_width + (col - t0 * a.base_cols);
+            }
+            if (act_b) {
+                const uint32_t col = lane_b & lgm, t1 = col / a.base_cols;
+                pb = a.dst + (uint64_t)t1 * a.trace_lde_elems +
+                     (((uint64_t)c << a.cpr_log) + (lane_b >> a.lg_log)) * a.row_width + (col - t1 * a.base_cols);
+            }
+        } else {
+            const uint32_t B = g * S + lane_a;  // global base column of lane a
+            if (B < a.total_base_cols) {
+                const uint32_t t0 = B / a.base_cols, c0 = B - t0 * a.base_cols;
+                pa = a.dst + (uint64_t)t0 * a.trace_lde_elems + (uint64_t)c * a.row_width + c0;
+                pair_store = c0 + 1 < a.base_cols && (c0 & 1) == 0;  // both lanes in one trace, 16-byte aligned
+            }
+            if (B + 1 < a.total_base_cols) {
+                const uint32_t t1 = (B + 1) / a.base_cols, c1 = (B + 1) - t1 * a.base_cols;
+                pb = a.dst + (uint64_t)t1 * a.trace_lde_elems + (uint64_t)c * a.row_width + c1;
+            }
+        }
+        if (!pa && !pb) return;
+        for (uint32_t pj = 0; pj < D; pj += pstride) {
+            const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, a.logD)) << out_shift);
+            const P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
+            const uint64_t off = k * k_stride;
+            if (pair_store) {
+                *reinterpret_cast<P2 *>(pa + off) = v;
             } else {
-                *p0 = v.a;
-                if (B + 1 < a.total_base_cols) {
-                    const uint32_t t1 = (B + 1) / a.base_cols, c1 = (B + 1) - t1 * a.base_cols;
-                    a.dst[(uint64_t)t1 * a.trace_lde_elems + row * a.row_width + c1] = v.b;
-                }
+                if (pa) pa[off] = v.a;
+                if (pb) pb[off] = v.b;
             }
         }
     }
