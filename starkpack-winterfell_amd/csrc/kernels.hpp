@@ -513,8 +513,7 @@ __global__ void __launch_bounds__(256) k_gather_digests(const uint4 *__restrict_
 __global__ void __launch_bounds__(256) k_merkle_level2(const uint32_t *__restrict__ children,
                                                        uint32_t *__restrict__ parents,
                                                        uint32_t *__restrict__ grandparents, uint64_t n_grand) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_grand) return;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_grand; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint4 *src = reinterpret_cast<const uint4 *>(children + i * 32);
     uint32_t m[16], cv[8], g[16];
 #pragma unroll
@@ -535,6 +534,7 @@ __global__ void __launch_bounds__(256) k_merkle_level2(const uint32_t *__restric
     uint4 *dst = reinterpret_cast<uint4 *>(grandparents + i * 8);
     dst[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
     dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+    }
 }
 
 // Hash contiguous rows of `row_elems` elements (wf_hash_rows building block) is k_hash_rows with n_traces = 1.

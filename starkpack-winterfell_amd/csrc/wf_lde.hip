@@ -596,7 +596,8 @@ static int run_merkle(hipStream_t st, const void *leaves, uint64_t n_leaves, voi
         const uint64_t grid = (n_par + threads - 1) / threads;
         if (n_par >= (1u << 16)) {  // two levels that still fill the chip: one lane per grandparent
             const uint64_t n_grand = n_par >> 1;
-            hipLaunchKernelGGL(k_merkle_level2, dim3((uint32_t)((n_grand + threads - 1) / threads)), dim3(threads), 0, st,
+            const uint64_t blocks2 = std::min<uint64_t>((n_grand + threads - 1) / threads, 256 * 8);  // grid-stride
+            hipLaunchKernelGGL(k_merkle_level2, dim3((uint32_t)blocks2), dim3(threads), 0, st,
                                children, (uint32_t *)nodes + n_par * 8, (uint32_t *)nodes + n_grand * 8, n_grand);
             HIP_TRY(hipGetLastError());
             n_children = n_grand;
