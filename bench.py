@@ -110,13 +110,20 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; the modulo only matters for rehearsals of the multi-rank control flow on a box with fewer GPUs
+    # than ranks (WF_BENCH_BACKEND=gloo) -- RCCL itself refuses two ranks on one device
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    backend = os.environ.get("WF_BENCH_BACKEND", "nccl")
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     model = work_model()
-    ctx = capi.Context(local_rank)
+    ctx = capi.Context(dev_index)
     params = capi.make_params(capi.F64, 1, LOG_R, LOG_B, N_COLS, 1)
     R, N = 1 << LOG_R, 1 << (LOG_R + LOG_B)
     proof_id = shard.proofs_of_rank(world, rank, world)[0]
@@ -156,7 +163,7 @@ def main():
         for name, ms in ctx.profile_read():
             per_launch.setdefault(name, []).append(ms)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())

@@ -44,6 +44,8 @@ def all_gather_leaf_shards(local_leaves: torch.Tensor, trace_len: int, per_rank:
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local_leaves.clone()
     world = dist.get_world_size(group)
+    if dist.get_backend(group) != "nccl" and local_leaves.is_cuda:  # gloo rehearsal: collectives on host copies
+        return all_gather_leaf_shards(local_leaves.cpu(), trace_len, per_rank, group).to(local_leaves.device)
     out = torch.empty((world * local_leaves.shape[0], 32), dtype=torch.uint8, device=local_leaves.device)
     dist.all_gather_into_tensor(out, local_leaves.contiguous(), group=group)
     return interleave_leaf_shards(out, world, trace_len, per_rank)
@@ -55,6 +57,8 @@ def all_gather_roots(local_roots: torch.Tensor, group=None) -> torch.Tensor:
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local_roots.clone()
     world = dist.get_world_size(group)
+    if dist.get_backend(group) != "nccl" and local_roots.is_cuda:  # gloo rehearsal: collectives on host copies
+        return all_gather_roots(local_roots.cpu(), group).to(local_roots.device)
     out = torch.empty((world * local_roots.shape[0], 32), dtype=torch.uint8, device=local_roots.device)
     dist.all_gather_into_tensor(out, local_roots.contiguous(), group=group)
     return out
