@@ -1,0 +1,72 @@
+// Bring-up microbenchmark: issue rate of individual gfx950 VALU instructions (wave-instructions per SIMD cycle).
+//   hipcc -O3 --offload-arch=gfx950 scripts/instr_rate.hip -o build/instr_rate
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define REP8(x) x x x x x x x x
+#define REP64(x) REP8(REP8(x))
+
+#define KERNEL(name, body)                                                        \
+    __global__ void name(uint32_t *out, int iters) {                              \
+        uint32_t a = threadIdx.x, b = a * 3 + 1, c = a ^ 0x55, d = a + 7;         \
+        uint64_t p = a, q = b;                                                    \
+        (void)p; (void)q;                                                         \
+        for (int i = 0; i < iters; i++) { REP64(body) }                           \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d ^ (uint32_t)p ^ (uint32_t)q; \
+    }
+
+KERNEL(k_add, asm volatile("v_add_u32 %0, %0, %1" : "+v"(a) : "v"(b)); asm volatile("v_add_u32 %0, %0, %1" : "+v"(c) : "v"(d));)
+KERNEL(k_xor, asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a) : "v"(b)); asm volatile("v_xor_b32 %0, %0, %1" : "+v"(c) : "v"(d));)
+KERNEL(k_alignbit, asm volatile("v_alignbit_b32 %0, %0, %0, 7" : "+v"(a)); asm volatile("v_alignbit_b32 %0, %0, %0, 12" : "+v"(c));)
+KERNEL(k_add3, asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(d)); asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(c) : "v"(d), "v"(b));)
+KERNEL(k_mul_lo, asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a) : "v"(b)); asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(c) : "v"(d));)
+KERNEL(k_mul_hi, asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a) : "v"(b)); asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(c) : "v"(d));)
+KERNEL(k_mad64, asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(p) : "v"(b), "v"(d) : "vcc"); asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q) : "v"(d), "v"(b) : "vcc");)
+KERNEL(k_lshl_add64, asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(p) : "v"(q)); asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(q) : "v"(p));)
+KERNEL(k_cndmask, asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(b) : "vcc"); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(c) : "v"(d) : "vcc");)
+KERNEL(k_addco, asm volatile("v_add_co_u32 %0, vcc, %0, %1\n v_addc_co_u32 %2, vcc, %2, %3, vcc" : "+v"(a), "+v"(c) : "v"(b), "v"(d) : "vcc"); )
+KERNEL(k_cmp64, asm volatile("v_cmp_lt_u64 vcc, %0, %1" : : "v"(p), "v"(q) : "vcc"); asm volatile("v_cmp_lt_u64 vcc, %0, %1" : : "v"(q), "v"(p) : "vcc");)
+KERNEL(k_fma32, asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(d)); asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(c) : "v"(d), "v"(b));)
+KERNEL(k_mad24, asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(d)); asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(c) : "v"(d), "v"(b));)
+KERNEL(k_pkfma, asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p) : "v"(q)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(q) : "v"(p));)
+
+template <class K>
+static void run(const char *name, K kern, uint32_t *out) {
+    const int blocks = 256 * 8, threads = 256, iters = 200;  // 8 waves per SIMD
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, out, iters);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, out, iters);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double wave_instr = (double)blocks * (threads / 64) * iters * 64 * 2;  // 2 instructions per REP body
+    const double per_simd_per_s = wave_instr / (256.0 * 4) / (ms * 1e-3);
+    printf("%-14s %8.3f ms  %6.2f G wave-instr/s per SIMD  (= %4.2f cycles per wave-instr at 2.4 GHz)\n", name, ms,
+           per_simd_per_s / 1e9, 2.4e9 / per_simd_per_s);
+}
+
+int main() {
+    uint32_t *out;
+    (void)hipMalloc(&out, 256 * 8 * 256 * 4);
+    run("v_add_u32", k_add, out);
+    run("v_xor_b32", k_xor, out);
+    run("v_alignbit", k_alignbit, out);
+    run("v_add3_u32", k_add3, out);
+    run("v_mul_lo_u32", k_mul_lo, out);
+    run("v_mul_hi_u32", k_mul_hi, out);
+    run("v_mad_u64_u32", k_mad64, out);
+    run("v_lshl_add_u64", k_lshl_add64, out);
+    run("v_cndmask", k_cndmask, out);
+    run("add_co+addc", k_addco, out);
+    run("v_cmp_lt_u64", k_cmp64, out);
+    run("v_fma_f32", k_fma32, out);
+    run("v_mad_u32_u24", k_mad24, out);
+    run("v_pk_fma_f32", k_pkfma, out);
+    return 0;
+}
