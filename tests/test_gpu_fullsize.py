@@ -52,6 +52,25 @@ def test_do_work_f128(ctx, orc, capi):
     assert got["root"] == want["root"]
 
 
+def test_cfg5_do_work_f128_2_18(ctx, orc, capi):
+    """BASELINE configs[4] substitute: the do_work trace (x -> x^3 + 42 in column 0, the start value in
+    the other nine columns; examples/src/do_work/prover.rs:62-80) over f128 at 2^18 rows, blowup 8, path only."""
+    logR = 18
+    R = 1 << logR
+    col0, x = [], 7
+    for _ in range(R):
+        col0.append(x)
+        x = (pow(x, 3, P128) + 42) % P128
+    cols = [orc.f128_from_ints(col0)] + [orc.f128_from_ints([7] * R) for _ in range(9)]
+    want = orc.build_trace_commitment(F128, [cols], 1, logR, 3, 3, threads=16)
+    got = ctx.trace_commit(capi.make_params(F128, 1, logR, 3, 10, 1), cols)
+    assert got["root"] == want["root"]
+    assert np.array_equal(got["lde"][0], want["lde"][0])
+    assert np.array_equal(got["polys"][0], want["polys"][0][0])
+    # the constant columns interpolate to constant polynomials
+    assert np.array_equal(got["polys"][3][0], np.array([7, 0], dtype=np.uint64)) and not got["polys"][3][1:].any()
+
+
 def test_cfg2_2_20_x8(ctx, orc, capi):
     logR, logB, C = 20, 3, 8
     R, N = 1 << logR, 1 << (logR + logB)
