@@ -119,13 +119,171 @@ struct F128 {
 
     static WF_HD T zero() { return T{0, 0}; }
     static WF_HD T one() { return T{1, 0}; }
+    // ---- device arithmetic on explicit 32-bit limbs (gfx950 has no 64-bit multiplier or 128-bit carry chain; the
+    // unsigned __int128 formulation below compiles to 163 / 16 / 22 VALU for mul / add / sub, this one to 78 / 14 / 13)
+    static constexpr uint32_t C0 = 0xFFFFFFFFu, C1 = 0x2CFFu;  // limbs of C
+    static constexpr uint32_t K = 45u << 8;                   // C + 1 = K * 2^32
+    static WF_HD void limbs(T x, uint32_t (&l)[4]) {
+        l[0] = (uint32_t)x.lo;
+        l[1] = (uint32_t)(x.lo >> 32);
+        l[2] = (uint32_t)x.hi;
+        l[3] = (uint32_t)(x.hi >> 32);
+    }
+    static WF_HD T unlimbs(const uint32_t (&l)[4]) {
+        return T{((uint64_t)l[1] << 32) | l[0], ((uint64_t)l[3] << 32) | l[2]};
+    }
+    static WF_HD uint32_t adc(uint32_t a, uint32_t b, uint32_t cin, uint32_t &cout) {
+        uint32_t s;
+        const uint32_t c1 = __builtin_add_overflow(a, b, &s);
+        const uint32_t c2 = __builtin_add_overflow(s, cin, &s);
+        cout = c1 | c2;
+        return s;
+    }
+    static WF_HD uint32_t sbb(uint32_t a, uint32_t b, uint32_t bin, uint32_t &bout) {
+        uint32_t s;
+        const uint32_t c1 = __builtin_sub_overflow(a, b, &s);
+        const uint32_t c2 = __builtin_sub_overflow(s, bin, &s);
+        bout = c1 | c2;
+        return s;
+    }
+    static WF_HD uint64_t mad32(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
+    static WF_HD uint64_t pair32(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+    // y = z + C mod 2^128, returns the carry out (set  <=>  z >= p)
+    static WF_HD uint32_t add_c(const uint32_t (&z)[4], uint32_t (&y)[4]) {
+        uint32_t c = __builtin_add_overflow(z[0], C0, &y[0]);
+        y[1] = adc(z[1], C1, c, c);
+        c = __builtin_add_overflow(z[2], c, &y[2]);
+        c = __builtin_add_overflow(z[3], c, &y[3]);
+        return c;
+    }
+    static WF_HD T add_limbs(T x, T y) {
+        uint32_t a[4], b[4], s[4], t[4], r[4], c;
+        limbs(x, a);
+        limbs(y, b);
+        c = __builtin_add_overflow(a[0], b[0], &s[0]);
+        s[1] = adc(a[1], b[1], c, c);
+        s[2] = adc(a[2], b[2], c, c);
+        s[3] = adc(a[3], b[3], c, c);
+        const uint32_t c2 = add_c(s, t);
+        const bool take = (c | c2) != 0;  // wrapped at 2^128 or landed in [p, 2^128): subtract p = add C
+#pragma unroll
+        for (int i = 0; i < 4; i++) r[i] = take ? t[i] : s[i];
+        return unlimbs(r);
+    }
+    static WF_HD T sub_limbs(T x, T y) {
+        uint32_t a[4], b[4], d[4], r[4], bo, q;
+        limbs(x, a);
+        limbs(y, b);
+        bo = __builtin_sub_overflow(a[0], b[0], &d[0]);
+        d[1] = sbb(a[1], b[1], bo, bo);
+        d[2] = sbb(a[2], b[2], bo, bo);
+        d[3] = sbb(a[3], b[3], bo, bo);
+        const uint32_t m = 0u - bo;  // borrowed: add p = subtract C (mod 2^128)
+        q = __builtin_sub_overflow(d[0], m, &r[0]);
+        r[1] = sbb(d[1], C1 & m, q, q);
+        q = __builtin_sub_overflow(d[2], q, &r[2]);
+        r[3] = d[3] - q;
+        return unlimbs(r);
+    }
+    static WF_HD T mul_limbs(T x, T y) {
+        uint32_t a[4], b[4], r[8];
+        limbs(x, a);
+        limbs(y, b);
+        // 256-bit product, row by row; every mad's addend stays below 2^33, so a 32x32+64 mad cannot overflow
+        {
+            uint64_t p[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) p[j] = mad32(a[j], b[0], 0);
+            uint32_t c;
+            r[0] = (uint32_t)p[0];
+            c = __builtin_add_overflow((uint32_t)(p[0] >> 32), (uint32_t)p[1], &r[1]);
+            r[2] = adc((uint32_t)(p[1] >> 32), (uint32_t)p[2], c, c);
+            r[3] = adc((uint32_t)(p[2] >> 32), (uint32_t)p[3], c, c);
+            r[4] = (uint32_t)(p[3] >> 32) + c;
+        }
+#pragma unroll
+        for (int i = 1; i < 4; i++) {
+            uint32_t carry = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint64_t t;
+                if (j == 0) {
+                    t = mad32(a[j], b[i], pair32(r[i + j], 0));
+                } else {
+                    uint32_t lo;
+                    const uint32_t cc = __builtin_add_overflow(r[i + j], carry, &lo);
+                    t = mad32(a[j], b[i], pair32(lo, cc));
+                }
+                r[i + j] = (uint32_t)t;
+                carry = (uint32_t)(t >> 32);
+            }
+            r[i + 4] = carry;
+        }
+        // first fold: L + H*C = L + ((H*K) << 32) - H with H = r[4..7]; the result v has 6 limbs, v[5] < 2^15
+        uint32_t hk[5], v[6];
+        {
+            uint64_t t = mad32(r[4], K, 0);
+            hk[0] = (uint32_t)t;
+            t = mad32(r[5], K, pair32((uint32_t)(t >> 32), 0));
+            hk[1] = (uint32_t)t;
+            t = mad32(r[6], K, pair32((uint32_t)(t >> 32), 0));
+            hk[2] = (uint32_t)t;
+            t = mad32(r[7], K, pair32((uint32_t)(t >> 32), 0));
+            hk[3] = (uint32_t)t;
+            hk[4] = (uint32_t)(t >> 32);
+            uint32_t c, w1, w2, w3, w4, w5, bo;
+            c = __builtin_add_overflow(r[1], hk[0], &w1);
+            w2 = adc(r[2], hk[1], c, c);
+            w3 = adc(r[3], hk[2], c, c);
+            c = __builtin_add_overflow(hk[3], c, &w4);
+            w5 = hk[4] + c;
+            bo = __builtin_sub_overflow(r[0], r[4], &v[0]);
+            v[1] = sbb(w1, r[5], bo, bo);
+            v[2] = sbb(w2, r[6], bo, bo);
+            v[3] = sbb(w3, r[7], bo, bo);
+            bo = __builtin_sub_overflow(w4, bo, &v[4]);
+            v[5] = w5 - bo;
+        }
+        // second fold: t = v[5]:v[4] < 2^47, z = v[0..3] + ((t*K) << 32) - t with t*K < 2^61
+        uint32_t z[4], net;
+        {
+            const uint64_t t0 = mad32(v[4], K, 0);
+            const uint32_t tk0 = (uint32_t)t0;
+            const uint32_t tk1 = (uint32_t)(t0 >> 32) + v[5] * K;
+            uint32_t c, w1, w2, w3, bo;
+            c = __builtin_add_overflow(v[1], tk0, &w1);
+            w2 = adc(v[2], tk1, c, c);
+            c = __builtin_add_overflow(v[3], c, &w3);
+            bo = __builtin_sub_overflow(v[0], v[4], &z[0]);
+            z[1] = sbb(w1, v[5], bo, bo);
+            bo = __builtin_sub_overflow(w2, bo, &z[2]);
+            bo = __builtin_sub_overflow(w3, bo, &z[3]);
+            net = c ^ bo;  // the integer is non-negative: (carry, borrow) is (0,0), (1,0) or (1,1)
+        }
+        // net set: the value is z + 2^128 = z + C (mod p), already below p; otherwise subtract p once if z >= p
+        uint32_t t[4], out[4];
+        const uint32_t cy = add_c(z, t);
+        const bool take = (net | cy) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) out[i] = take ? t[i] : z[i];
+        return unlimbs(out);
+    }
+
     static WF_HD T add(T a, T b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return add_limbs(a, b);
+#else
         u128 x = w(a), z = P() - w(b);
         return n(x < z ? x + w(b) : x - z);
+#endif
     }
     static WF_HD T sub(T a, T b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return sub_limbs(a, b);
+#else
         u128 x = w(a), y = w(b);
         return n(x < y ? P() - y + x : x - y);
+#endif
     }
     // 64x64 -> 128
     static WF_HD void mul64(uint64_t a, uint64_t b, uint64_t &lo, uint64_t &hi) {
@@ -140,6 +298,13 @@ struct F128 {
     }
     // (a * b) mod p : 256-bit schoolbook product folded twice with 2^128 = C (mod p)
     static WF_HD T mul(T a, T b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return mul_limbs(a, b);
+#else
+        return mul_wide(a, b);
+#endif
+    }
+    static WF_HD T mul_wide(T a, T b) {
         uint64_t p0l, p0h, p1l, p1h, p2l, p2h, p3l, p3h;
         mul64(a.lo, b.lo, p0l, p0h);
         mul64(a.lo, b.hi, p1l, p1h);

@@ -1,0 +1,65 @@
+// CPU check of the 32-bit-limb f128 arithmetic that the device code uses (csrc/field.hpp: add_limbs / sub_limbs /
+// mul_limbs) against the wide unsigned __int128 formulation and against a bit-serial double-and-add product.
+// Edge patterns: values next to p, next to 0, all-ones / all-zero limbs, single bits.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "../../starkpack-winterfell_amd/csrc/field.hpp"
+
+typedef unsigned __int128 u128;
+using wf::F128;
+using wf::U128;
+
+static u128 P;
+static u128 addmod(u128 a, u128 b) {
+    u128 s = a + b;
+    if (s < a || s >= P) s -= P;
+    return s;
+}
+static u128 mulmod(u128 a, u128 b) {
+    u128 r = 0;
+    for (int i = 127; i >= 0; i--) {
+        r = addmod(r, r);
+        if ((b >> i) & 1) r = addmod(r, a);
+    }
+    return r;
+}
+static uint64_t rs = 88172645463325252ull;
+static uint64_t rnd() {
+    rs ^= rs << 13;
+    rs ^= rs >> 7;
+    rs ^= rs << 17;
+    return rs;
+}
+static u128 pattern(long mode) {
+    u128 x = ((u128)rnd() << 64) | rnd();
+    switch (mode % 6) {
+        case 0: return x % P;
+        case 1: return P - 1 - (rnd() % 1000);
+        case 2: return rnd() % 1000;
+        case 3: return ((x % P) | (((u128)0xFFFFFFFFull) << (32 * (rnd() % 3)))) % P;
+        case 4: return ((P - 1) & ~(((u128)0xFFFFFFFFull) << (32 * (rnd() % 4)))) % P;
+        default: return ((u128)1 << (rnd() % 128)) % P;
+    }
+}
+static U128 n(u128 v) { return U128{(uint64_t)v, (uint64_t)(v >> 64)}; }
+static u128 w(U128 v) { return ((u128)v.hi << 64) | v.lo; }
+
+int main(int argc, char **argv) {
+    const long iters = argc > 1 ? atol(argv[1]) : 400000;
+    P = F128::P();
+    long bad = 0;
+    for (long it = 0; it < iters; it++) {
+        u128 a = pattern(it), b = pattern(it / 6);
+        if (it == 0) a = b = P - 1;
+        if (it == 1) { a = 0; b = P - 1; }
+        const u128 m = w(F128::mul_limbs(n(a), n(b)));
+        if (m != w(F128::mul_wide(n(a), n(b))) || m != mulmod(a, b)) bad++;
+        if (w(F128::add_limbs(n(a), n(b))) != addmod(a, b)) bad++;
+        const u128 d = a >= b ? a - b : a + (P - b);
+        if (w(F128::sub_limbs(n(a), n(b))) != d) bad++;
+    }
+    printf("checked %ld triples, bad=%ld\n", iters, bad);
+    if (bad == 0) printf("ALL OK\n");
+    return bad != 0;
+}
