@@ -487,36 +487,71 @@ struct XposeArgs {
     uint32_t total_base_cols;
 };
 
-// grid.x = n_seg * ceil(R / (256 / S)); one thread per (row, lane)
+// Both directions stage XPOSE_TILES tiles of (256 / S rows) x (S lanes) through LDS so that the column side is
+// accessed in runs of 256 B (f64) / 1 KiB (f128) per column and the segment side in whole 64-byte rows.
+// grid.x = n_seg * ceil(R / (XPOSE_TILES * 256 / S))
+constexpr uint32_t XPOSE_TILES = 4;
+
 template <class F>
 __global__ void __launch_bounds__(256) k_cols_to_seg(XposeArgs<F> a) {
-    constexpr uint32_t S = SegCfg<F>::S, RPB = 256 / S;
+    typedef typename F::T T;
+    constexpr uint32_t S = SegCfg<F>::S, RPT = 256 / S, RPB = RPT * XPOSE_TILES;
+    __shared__ T tile[XPOSE_TILES][RPT][S + 1];
     const uint64_t blocks_per_seg = (a.R + RPB - 1) / RPB;
     const uint32_t g = (uint32_t)(blockIdx.x / blocks_per_seg);
-    const uint64_t r = (blockIdx.x % blocks_per_seg) * RPB + threadIdx.x / S;
-    const uint32_t l = threadIdx.x % S;
-    if (r >= a.R) return;
-    const uint32_t B = g * S + l;
-    typename F::T v = F::zero();
-    if (B < a.total_base_cols) {
+    const uint64_t r0 = (blockIdx.x % blocks_per_seg) * RPB;
+    {
+        const uint32_t rl = threadIdx.x % RPT, l = threadIdx.x / RPT;
+        const uint32_t B = g * S + l;
+        const bool live = B < a.total_base_cols;
         const uint32_t col = B / a.W, w = B - col * a.W;
-        v = a.src[((uint64_t)col * a.R + r) * a.W + w];
+#pragma unroll
+        for (uint32_t j = 0; j < XPOSE_TILES; j++) {
+            const uint64_t r = r0 + j * RPT + rl;
+            T v = F::zero();
+            if (live && r < a.R) v = a.src[((uint64_t)col * a.R + r) * a.W + w];
+            tile[j][rl][l] = v;
+        }
     }
-    a.dst[((uint64_t)g * a.R + r) * S + l] = v;
+    __syncthreads();
+    {
+        const uint32_t rl = threadIdx.x / S, l = threadIdx.x % S;
+#pragma unroll
+        for (uint32_t j = 0; j < XPOSE_TILES; j++) {
+            const uint64_t r = r0 + j * RPT + rl;
+            if (r < a.R) a.dst[((uint64_t)g * a.R + r) * S + l] = tile[j][rl][l];
+        }
+    }
 }
 
 template <class F>
 __global__ void __launch_bounds__(256) k_seg_to_cols(XposeArgs<F> a) {
-    constexpr uint32_t S = SegCfg<F>::S, RPB = 256 / S;
+    typedef typename F::T T;
+    constexpr uint32_t S = SegCfg<F>::S, RPT = 256 / S, RPB = RPT * XPOSE_TILES;
+    __shared__ T tile[XPOSE_TILES][RPT][S + 1];
     const uint64_t blocks_per_seg = (a.R + RPB - 1) / RPB;
     const uint32_t g = (uint32_t)(blockIdx.x / blocks_per_seg);
-    const uint64_t r = (blockIdx.x % blocks_per_seg) * RPB + threadIdx.x / S;
-    const uint32_t l = threadIdx.x % S;
-    if (r >= a.R) return;
-    const uint32_t B = g * S + l;
-    if (B >= a.total_base_cols) return;
-    const uint32_t col = B / a.W, w = B - col * a.W;
-    a.dst[((uint64_t)col * a.R + r) * a.W + w] = a.src[((uint64_t)g * a.R + r) * S + l];
+    const uint64_t r0 = (blockIdx.x % blocks_per_seg) * RPB;
+    {
+        const uint32_t rl = threadIdx.x / S, l = threadIdx.x % S;
+#pragma unroll
+        for (uint32_t j = 0; j < XPOSE_TILES; j++) {
+            const uint64_t r = r0 + j * RPT + rl;
+            if (r < a.R) tile[j][rl][l] = a.src[((uint64_t)g * a.R + r) * S + l];
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t rl = threadIdx.x % RPT, l = threadIdx.x / RPT;
+        const uint32_t B = g * S + l;
+        if (B >= a.total_base_cols) return;
+        const uint32_t col = B / a.W, w = B - col * a.W;
+#pragma unroll
+        for (uint32_t j = 0; j < XPOSE_TILES; j++) {
+            const uint64_t r = r0 + j * RPT + rl;
+            if (r < a.R) a.dst[((uint64_t)col * a.R + r) * a.W + w] = tile[j][rl][l];
+        }
+    }
 }
 
 }  // namespace wf

@@ -540,7 +540,7 @@ static int run_xpose(wf_ctx *ctx, hipStream_t st, bool to_seg, const void *src, 
     x.R = R;
     x.W = W;
     x.total_base_cols = total_base_cols;
-    constexpr uint32_t RPB = 256 / SegCfg<F>::S;
+    constexpr uint32_t RPB = XPOSE_TILES * 256 / SegCfg<F>::S;
     const uint64_t grid = (uint64_t)n_seg * ((R + RPB - 1) / RPB);
     if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch");
     prof_mark(ctx, st, to_seg ? "layout.cols_to_segments" : "layout.segments_to_cols");
