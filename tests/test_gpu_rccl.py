@@ -1,0 +1,71 @@
+"""GPU: the RCCL leg of the multi-GPU helpers on the one device this box has -- a world of one rank over the "nccl"
+backend (= RCCL on ROCm): communicator creation, the uint8 all-gathers `shard.py` issues, and bench.py's
+distributed control flow.  The N > 1 exchange itself is covered by the gloo tests (tests/test_shard_gloo.py)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["WF_ROOT"])
+from starkpack_winterfell_amd import shard
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=dev)
+x = torch.arange(3 * 32, dtype=torch.uint8, device=dev).reshape(3, 32)
+out = torch.empty((3, 32), dtype=torch.uint8, device=dev)
+dist.all_gather_into_tensor(out, x)          # the call shard.all_gather_roots makes for world > 1
+assert torch.equal(out, x)
+leaves = torch.arange(8 * 32, dtype=torch.uint8, device=dev).reshape(8, 32)
+full = shard.all_gather_leaf_shards(leaves, 8, 1)
+assert torch.equal(full, leaves)
+t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL OK")
+"""
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _env():
+    env = dict(os.environ)
+    env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()), "RANK": "0", "LOCAL_RANK": "0",
+                "WORLD_SIZE": "1", "WF_ROOT": ROOT, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    return env
+
+
+def test_rccl_world_of_one(capi):
+    capi.load()
+    out = subprocess.run([sys.executable, "-c", SCRIPT], env=_env(), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "RCCL OK" in out.stdout
+
+
+def test_bench_line_contract(capi):
+    """bench.py prints one JSON line carrying the contract's keys (short run, no CPU baseline)."""
+    capi.load()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
+    assert j["roots_gathered"] == 3
