@@ -1,0 +1,17 @@
+#!/bin/bash
+# Tuning aid: build variants of libwf_lde.so with experiment macros into build/exp_<name>/ and time cfg 2 with each
+# (run the timing part on the GPU box:  WF_LDE_LIB=build/exp_<name>/libwf_lde.so python scripts/time_config.py 1 1 20 3 8 1).
+set -e
+cd "$(dirname "$0")/.."
+build_variant() {  # name, extra flags
+    mkdir -p build/exp_$1
+    /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-function -Wno-pass-failed -ffp-contract=off \
+        $2 -shared -o build/exp_$1/libwf_lde.so starkpack-winterfell_amd/csrc/wf_lde.hip
+}
+build_variant skip_ntt "-DWF_EXP_SKIP_NTT"
+build_variant no_xcd "-DWF_EXP_NO_XCD_REMAP"
+build_variant skip_store "-DWF_EXP_SKIP_STORE"
+build_variant skip_load "-DWF_EXP_SKIP_LOAD"
+build_variant skip_mem "-DWF_EXP_SKIP_LOAD -DWF_EXP_SKIP_STORE"
+build_variant skip_ntt_store "-DWF_EXP_SKIP_NTT -DWF_EXP_SKIP_STORE"
+build_variant skip_ntt_load "-DWF_EXP_SKIP_NTT -DWF_EXP_SKIP_LOAD"

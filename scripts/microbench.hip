@@ -56,6 +56,8 @@ template <int VAR>
 __device__ __forceinline__ uint64_t mulv(uint64_t a, uint64_t b) {
     if (VAR == 0) return mul_v0(a, b);
     if (VAR == 1) return mul_v1(a, b);
+    if (VAR == 3) return F64::mul_pow2<12>(a);   // shift twiddles of the radix-16 block
+    if (VAR == 4) return F64::div_pow2<24>(a);
     return mul_v2(a, b);
 }
 
@@ -176,6 +178,10 @@ int main() {
     printf("butterfly v1              : %8.1f Gbfly/s\n", nthreads * 2.0 * iters / ms / 1e6);
     ms = timeit([&] { hipLaunchKernelGGL(k_bfly<2>, dim3(blocks), dim3(threads), 0, 0, io, iters); }, 5);
     printf("butterfly v2              : %8.1f Gbfly/s\n", nthreads * 2.0 * iters / ms / 1e6);
+    ms = timeit([&] { hipLaunchKernelGGL(k_bfly<3>, dim3(blocks), dim3(threads), 0, 0, io, iters); }, 5);
+    printf("butterfly, w = 2^12 shift : %8.1f Gbfly/s\n", nthreads * 2.0 * iters / ms / 1e6);
+    ms = timeit([&] { hipLaunchKernelGGL(k_bfly<4>, dim3(blocks), dim3(threads), 0, 0, io, iters); }, 5);
+    printf("butterfly, w = 2^-24 shift: %8.1f Gbfly/s\n", nthreads * 2.0 * iters / ms / 1e6);
     ms = timeit([&] { hipLaunchKernelGGL(k_blake, dim3(blocks), dim3(threads), 0, 0, (uint32_t *)io, 200); }, 5);
     printf("blake3 compress           : %8.2f Gcompress/s\n", nthreads * 200.0 / ms / 1e6);
 

@@ -15,4 +15,5 @@ def build(force: bool = False) -> str:
 
 
 def lib_path() -> str:
-    return LIB
+    # WF_LDE_LIB: load another build of the same library (tuning experiments: scripts/exp_variants.sh)
+    return os.environ.get("WF_LDE_LIB") or LIB

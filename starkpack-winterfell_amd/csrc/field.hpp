@@ -93,6 +93,24 @@ struct F64 {
         return a < b ? r - 0xFFFFFFFFull : r;
 #endif
     }
+    // x * 2^K and x * 2^-K for 0 < K <= 32 without a general product (2 is a 192nd root of unity: 2^64 = 2^32 - 1,
+    // 2^96 = -1).  x * 2^K = lo + hi * 2^64 = lo + hi * (2^32 - 1); x * 2^-K = (x >> K) - (x mod 2^K) * 2^(96 - K)
+    // = q - m * (2^32 - 1) with m = (x mod 2^K) << (32 - K).  9 VALU each against 17 for mul; Montgomery form is
+    // preserved because the factor is a plain integer.
+    template <int K>
+    static WF_HD T mul_pow2(T x) {
+        static_assert(K > 0 && K <= 32, "shift out of range");
+        const uint64_t lo = x << K;
+        const uint64_t hi = x >> (64 - K);
+        return add(lo, (hi << 32) - hi);  // add() reduces any 64-bit lo correctly here: see the bound in DESIGN.md §4
+    }
+    template <int K>
+    static WF_HD T div_pow2(T x) {
+        static_assert(K > 0 && K <= 32, "shift out of range");
+        const uint64_t q = x >> K;
+        const uint64_t m = (uint64_t)((uint32_t)x << (32 - K));
+        return sub(q, (m << 32) - m);
+    }
     static WF_HD T from_canonical(uint64_t v) { return mul(v % P, R2); }
     static WF_HD uint64_t to_canonical(T x) { return mont_reduce(x, 0); }
     static WF_HD T from_u128_canonical(u128 v) { return from_canonical((uint64_t)(v % (u128)P)); }

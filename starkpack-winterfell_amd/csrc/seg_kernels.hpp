@@ -27,6 +27,7 @@ struct SegCfg {
     // radix-16 rounds keep 16 values (+ 8 constants) in registers: 2 VGPRs per value for f64; for f128 (4 per value)
     // that costs half the occupancy and runs slower than radix-4 rounds
     static constexpr bool RADIX16 = F::BYTES == 8;
+    static constexpr uint32_t LOAD_BATCH = F::BYTES == 8 ? 8 : 4;  // 16- / 32-byte loads kept in flight per thread
 };
 
 template <class T>
@@ -35,6 +36,20 @@ struct alignas(16) Pair {
 };
 
 enum : int { SEG_OUT_SEG = 0, SEG_OUT_ROWS = 1 };
+
+// Work-groups are dispatched to the 8 XCDs round-robin (blockIdx % 8), each XCD with its own L2.  This maps blockIdx
+// to a logical index such that 8 consecutive logical indices run back to back on ONE XCD: the kernels make those the
+// work-groups that write neighbouring 64-byte pieces of the same 512 bytes (adjacent inner positions of a strided pass,
+// the cosets of one row group in the last pass), so that the pieces meet in that XCD's L2 and leave as whole lines.
+__device__ __forceinline__ uint64_t xcd_group_index(uint64_t b, uint64_t total) {
+#ifndef WF_EXP_NO_XCD_REMAP
+    if ((total & 63) != 0) return b;
+    const uint64_t xcd = b & 7, seq = b >> 3;
+    return (((seq >> 3) << 3) + xcd) * 8 + (seq & 7);
+#else
+    return b;
+#endif
+}
 
 template <class F>
 struct SegArgs {
@@ -90,31 +105,81 @@ __host__ __device__ constexpr uint32_t bitrev4(uint32_t v) {
     return ((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3);
 }
 
-// 16-point DFT in registers (decimation in frequency, constants w[j] = w_16^j): v[bitrev4(k)] = sum_a x_a w_16^(a k)
-template <class F>
-__device__ __forceinline__ void radix16(typename F::T (&v)[16], const typename F::T (&w)[8]) {
-    typedef typename F::T T;
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-        const int half = 8 >> s;
-#pragma unroll
-        for (int q = 0; q < 16; q += 2 * half) {
-#pragma unroll
-            for (int i = 0; i < half; i++) {
-                const T u = v[q + i], t = v[q + i + half];
-                v[q + i] = F::add(u, t);
-                T dlt = F::sub(u, t);
-                if (i != 0) dlt = F::mul(dlt, w[i << s]);
-                v[q + i + half] = dlt;
-            }
-        }
+// 16-point DFT in registers (decimation in frequency, constants w[j] = w_16^j): v[bitrev4(k)] = sum_a x_a w_16^(a k).
+// DIR = +1 / -1: the transform is known to be the forward / inverse one over Goldilocks, where w_16 = 2^12
+// (f64/mod.rs:248-264: w_64 = 8), so w_16^j for j = 1, 2 is a left shift, for j = 6, 7 a negated right shift
+// (2^72 = -2^-24, 2^84 = -2^-12), and the inverse constants are w_16^-j = -2^(96 - 12 j); the negation is folded into the
+// preceding subtraction.  j = 3, 4, 5 (2^36, 2^48, 2^60) cost as much shifted as multiplied and use the table.
+// DIR = 0: generic (constants from the table only).
+template <class F, int DIR, int J>
+__device__ __forceinline__ typename F::T radix16_twiddle(typename F::T u, typename F::T t, const typename F::T (&w)[8]) {
+    if constexpr (DIR == 0 || F::FIELD_ID != 1 || (J >= 3 && J <= 5)) {
+        return F::mul(F::sub(u, t), w[J]);
+    } else if constexpr (DIR > 0) {
+        if constexpr (J == 1) return F::template mul_pow2<12>(F::sub(u, t));
+        if constexpr (J == 2) return F::template mul_pow2<24>(F::sub(u, t));
+        if constexpr (J == 6) return F::template div_pow2<24>(F::sub(t, u));
+        if constexpr (J == 7) return F::template div_pow2<12>(F::sub(t, u));
+    } else {
+        if constexpr (J == 1) return F::template div_pow2<12>(F::sub(u, t));
+        if constexpr (J == 2) return F::template div_pow2<24>(F::sub(u, t));
+        if constexpr (J == 6) return F::template mul_pow2<24>(F::sub(t, u));
+        if constexpr (J == 7) return F::template mul_pow2<12>(F::sub(t, u));
     }
+    return F::zero();
+}
+
+template <class F, int DIR, int S, int Q, int I>
+__device__ __forceinline__ void radix16_bfly(typename F::T (&v)[16], const typename F::T (&w)[8]) {
+    constexpr int half = 8 >> S;
+    const typename F::T u = v[Q + I], t = v[Q + I + half];
+    v[Q + I] = F::add(u, t);
+    if constexpr (I == 0)
+        v[Q + I + half] = F::sub(u, t);
+    else
+        v[Q + I + half] = radix16_twiddle<F, DIR, (I << S)>(u, t, w);
+}
+
+template <class F, int DIR, int S, int Q>
+__device__ __forceinline__ void radix16_group(typename F::T (&v)[16], const typename F::T (&w)[8]) {
+    constexpr int half = 8 >> S;
+    radix16_bfly<F, DIR, S, Q, 0>(v, w);
+    if constexpr (half > 1) radix16_bfly<F, DIR, S, Q, 1>(v, w);
+    if constexpr (half > 2) {
+        radix16_bfly<F, DIR, S, Q, 2>(v, w);
+        radix16_bfly<F, DIR, S, Q, 3>(v, w);
+    }
+    if constexpr (half > 4) {
+        radix16_bfly<F, DIR, S, Q, 4>(v, w);
+        radix16_bfly<F, DIR, S, Q, 5>(v, w);
+        radix16_bfly<F, DIR, S, Q, 6>(v, w);
+        radix16_bfly<F, DIR, S, Q, 7>(v, w);
+    }
+}
+
+template <class F, int DIR>
+__device__ __forceinline__ void radix16(typename F::T (&v)[16], const typename F::T (&w)[8]) {
+    radix16_group<F, DIR, 0, 0>(v, w);
+    radix16_group<F, DIR, 1, 0>(v, w);
+    radix16_group<F, DIR, 1, 8>(v, w);
+    radix16_group<F, DIR, 2, 0>(v, w);
+    radix16_group<F, DIR, 2, 4>(v, w);
+    radix16_group<F, DIR, 2, 8>(v, w);
+    radix16_group<F, DIR, 2, 12>(v, w);
+    radix16_group<F, DIR, 3, 0>(v, w);
+    radix16_group<F, DIR, 3, 2>(v, w);
+    radix16_group<F, DIR, 3, 4>(v, w);
+    radix16_group<F, DIR, 3, 6>(v, w);
+    radix16_group<F, DIR, 3, 8>(v, w);
+    radix16_group<F, DIR, 3, 10>(v, w);
+    radix16_group<F, DIR, 3, 12>(v, w);
+    radix16_group<F, DIR, 3, 14>(v, w);
 }
 
 // In-place transform of x[D][S] in LDS; twd[e] = w_D^e.  Rounds: radix-16 (one lane per work item, 16 values in
 // registers) while >= 4 bits remain, then radix-4 / radix-2 (two lanes per item).  Natural order in,
 // seg_digit_reverse order out.
-template <class F>
+template <class F, int DIR = 0>
 __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::T *twd, uint32_t logD) {
     typedef typename F::T T;
     typedef Pair<T> P2;
@@ -139,7 +204,7 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
                 T v[16];
 #pragma unroll
                 for (int a = 0; a < 16; a++) v[a] = x[base + a * st];
-                radix16<F>(v, w16);
+                radix16<F, DIR>(v, w16);
                 if (jp != 0) {
                     const uint32_t e = jp << tshift;
 #pragma unroll
@@ -224,8 +289,8 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
 
 // ---------------------------------------------------------------------------------------------------------------
 // Strided pass.  grid.x = n_cosets * n_seg * O * I ; work-group = (coset c, segment g, outer o, inner i)
-// EVAL only tags the instantiation (interpolation = 0 / coset evaluation = 1) so that profilers list the two uses
-// under different kernel names, like k_seg_last<F, OUT>.
+// EVAL = 0: interpolation (inverse transform), 1: coset evaluation (forward transform); like k_seg_last<F, OUT> the two
+// uses appear under different kernel names in profiles, and the direction selects the shift twiddles of radix16.
 template <class F, int EVAL, bool PACKED = false>
 __global__ void __launch_bounds__(512) k_seg_strided(SegArgs<F> a) {
     typedef typename F::T T;
@@ -238,7 +303,7 @@ __global__ void __launch_bounds__(512) k_seg_strided(SegArgs<F> a) {
     T *twd = x + (size_t)D * S;
     T *aux = twd + D;  // coset factors of the input rows, later the inter-pass twiddles of the output rows
 
-    uint64_t bid = blockIdx.x;
+    uint64_t bid = xcd_group_index(blockIdx.x, gridDim.x);  // neighbouring i on one XCD
     const uint64_t i = bid % a.I;
     bid /= a.I;
     const uint64_t o = bid % a.O;
@@ -267,34 +332,73 @@ __global__ void __launch_bounds__(512) k_seg_strided(SegArgs<F> a) {
         pre.lo += (uint64_t)(a.coset0 + c) * a.pre_lo_stride;
         pre.hi += (uint64_t)(a.coset0 + c) * a.pre_hi_stride;
     }
+    const uint32_t nitems = D * HP;
+    const uint64_t row0 = o * D * a.I + i;  // row index of d = 0; rows of this group are I apart
+    // The first LOAD_BATCH row pieces of every thread (the whole tile up to D = 2^10) are requested before the tables
+    // are built, so that their latency runs under the table arithmetic.  The rows are I apart: every load is its own
+    // 64-byte gather, the load phase lives on memory-level parallelism.
+    constexpr uint32_t LB = SegCfg<F>::LOAD_BATCH;
+    const uint32_t step = blockDim.x;
+    const bool from_regs = !(PACKED && a.pre_on);
+    P2 v0[LB];
+    if (from_regs) {
+#pragma unroll
+        for (uint32_t u = 0; u < LB; u++) {
+            const uint32_t wk = threadIdx.x + u * step;
+            if (wk < nitems)
+#ifdef WF_EXP_SKIP_LOAD
+                v0[u] = *reinterpret_cast<const P2 *>(src + 2 * (wk & (HP - 1)));
+#else
+                v0[u] = *reinterpret_cast<const P2 *>(src + (row0 + (uint64_t)(wk >> hp_shift) * a.I) * S + 2 * (wk & (HP - 1)));
+#endif
+        }
+    }
     for (uint32_t e = threadIdx.x; e < D; e += blockDim.x) {
         twd[e] = a.digit_tw[e];
         if (!PACKED && a.pre_on) aux[e] = pre.get((uint64_t)e * a.I);  // h_c^(d*I); h_c^i goes into the output table
     }
     __syncthreads();
 
-    const uint32_t nitems = D * HP;
-    const uint64_t row0 = o * D * a.I + i;  // row index of d = 0; rows of this group are I apart
-    for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
-        const uint32_t lp = wk & (HP - 1), d = wk >> hp_shift;
-        P2 v;
-        if (PACKED && a.pre_on) {  // replicate the polynomial's lanes into every coset group of the row
+    if (PACKED && a.pre_on) {  // replicate the polynomial's lanes into every coset group of the row
+        for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
+            const uint32_t lp = wk & (HP - 1), d = wk >> hp_shift;
+            P2 v;
             const uint32_t lgm = (1u << a.lg_log) - 1, cola = lane_a & lgm, colb = lane_b & lgm;
             const T *srow = src + (row0 + (uint64_t)d * a.I) * S;
             v.a = act_a ? F::mul(srow[cola], pre_a.get((uint64_t)d * a.I)) : F::zero();
             v.b = act_b ? F::mul(srow[colb], pre_b.get((uint64_t)d * a.I)) : F::zero();
-        } else {
-            v = *reinterpret_cast<const P2 *>(src + (row0 + (uint64_t)d * a.I) * S + 2 * lp);
-            if (a.pre_on) {
-                const T f = aux[d];
-                v.a = F::mul(v.a, f);
-                v.b = F::mul(v.b, f);
+            *reinterpret_cast<P2 *>(x + d * S + 2 * lp) = v;
+        }
+    } else {
+        for (uint32_t wk0 = threadIdx.x; wk0 < nitems; wk0 += LB * step) {
+            P2 v[LB];
+#pragma unroll
+            for (uint32_t u = 0; u < LB; u++) {
+                const uint32_t wk = wk0 + u * step;
+                if (wk0 == threadIdx.x)
+                    v[u] = v0[u];
+                else if (wk < nitems)
+                    v[u] = *reinterpret_cast<const P2 *>(src + (row0 + (uint64_t)(wk >> hp_shift) * a.I) * S + 2 * (wk & (HP - 1)));
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < LB; u++) {
+                const uint32_t wk = wk0 + u * step;
+                if (wk < nitems) {
+                    const uint32_t lp = wk & (HP - 1), d = wk >> hp_shift;
+                    if (a.pre_on) {
+                        const T f = aux[d];
+                        v[u].a = F::mul(v[u].a, f);
+                        v[u].b = F::mul(v[u].b, f);
+                    }
+                    *reinterpret_cast<P2 *>(x + d * S + 2 * lp) = v[u];
+                }
             }
         }
-        *reinterpret_cast<P2 *>(x + d * S + 2 * lp) = v;
     }
     __syncthreads();
-    seg_lds_ntt<F>(x, twd, a.logD);
+#ifndef WF_EXP_SKIP_NTT  // tuning experiment: memory phases only (scripts/exp_variants.sh)
+    seg_lds_ntt<F, EVAL ? 1 : -1>(x, twd, a.logD);
+#endif
 
     // output factors: start * (w_N^(i * N/(D*I)))^k, start = h_c^i (evaluation) or the 1/n scale (interpolation)
     {
@@ -331,6 +435,9 @@ __global__ void __launch_bounds__(512) k_seg_strided(SegArgs<F> a) {
             v.a = F::mul(v.a, start_a);
             v.b = F::mul(v.b, start_b);
         }
+#ifdef WF_EXP_SKIP_STORE
+        if (*reinterpret_cast<const uint32_t *>(&v.a) == a.logN + 77777u)
+#endif
         *reinterpret_cast<P2 *>(dst_lane + (uint64_t)k * k_stride) = v;
     }
 }
@@ -349,11 +456,12 @@ __global__ void __launch_bounds__(512) k_seg_last(SegArgs<F> a) {
     T *twd = x + (size_t)D * S;
     T *aux = twd + D;
 
-    uint64_t bid = blockIdx.x;
+    // coset fastest: with SEG_OUT_ROWS the cosets of one row block write the 64-byte pieces of the same rows
+    uint64_t bid = xcd_group_index(blockIdx.x, gridDim.x);
+    const uint32_t c = (uint32_t)(bid % a.n_cosets);
+    bid /= a.n_cosets;
     const uint64_t o = bid % a.O;
-    bid /= a.O;
-    const uint32_t g = (uint32_t)(bid % a.n_seg);
-    const uint32_t c = (uint32_t)(bid / a.n_seg);
+    const uint32_t g = (uint32_t)(bid / a.O);
     const uint64_t seg_elems = ((uint64_t)1 << a.logN) * S;
     const T *src = a.src + (a.src_shared ? (uint64_t)g : (uint64_t)c * a.n_seg + g) * seg_elems + o * D * S;
 
@@ -385,32 +493,66 @@ __global__ void __launch_bounds__(512) k_seg_last(SegArgs<F> a) {
         pre.lo += (uint64_t)(a.coset0 + c) * a.pre_lo_stride;
         pre.hi += (uint64_t)(a.coset0 + c) * a.pre_hi_stride;
     }
+    const uint32_t nitems = D * HP;
+    constexpr uint32_t LB = SegCfg<F>::LOAD_BATCH;  // requested before the tables are built (see k_seg_strided)
+    const uint32_t step = blockDim.x;
+    const bool from_regs = !(PACKED && a.pre_on);
+    P2 v0[LB];
+    if (from_regs) {
+#pragma unroll
+        for (uint32_t u = 0; u < LB; u++) {
+            const uint32_t wk = threadIdx.x + u * step;
+#ifdef WF_EXP_SKIP_LOAD
+            if (wk < nitems) v0[u] = *reinterpret_cast<const P2 *>(a.src + 2 * (uint64_t)(wk & 63));
+#else
+            if (wk < nitems) v0[u] = *reinterpret_cast<const P2 *>(src + 2 * (uint64_t)wk);
+#endif
+        }
+    }
     for (uint32_t e = threadIdx.x; e < D; e += blockDim.x) {
         twd[e] = a.digit_tw[e];
         if (!PACKED && a.pre_on) aux[e] = pre.get(e);  // single-pass evaluation: row index = coefficient index
     }
     __syncthreads();
-    const uint32_t nitems = D * HP;
-    for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
-        P2 v;
-        if (PACKED && a.pre_on) {  // single pass: replicate the polynomial row into the coset groups, scaled per lane
+    if (PACKED && a.pre_on) {  // single pass: replicate the polynomial row into the coset groups, scaled per lane
+        for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
+            P2 v;
             const uint32_t d = wk >> hp_shift;
             const uint32_t lgm = (1u << a.lg_log) - 1, cola = lane_a & lgm, colb = lane_b & lgm;
             const T *srow = src + (uint64_t)d * S;
             v.a = act_a ? F::mul(srow[cola], pre_a.get(d)) : F::zero();
             v.b = act_b ? F::mul(srow[colb], pre_b.get(d)) : F::zero();
-        } else {
-            v = *reinterpret_cast<const P2 *>(src + 2 * (uint64_t)wk);
-            if (a.pre_on) {
-                const T f = aux[wk >> hp_shift];
-                v.a = F::mul(v.a, f);
-                v.b = F::mul(v.b, f);
+            *reinterpret_cast<P2 *>(x + 2 * wk) = v;
+        }
+    } else {
+        for (uint32_t wk0 = threadIdx.x; wk0 < nitems; wk0 += LB * step) {
+            P2 v[LB];
+#pragma unroll
+            for (uint32_t u = 0; u < LB; u++) {
+                const uint32_t wk = wk0 + u * step;
+                if (wk0 == threadIdx.x)
+                    v[u] = v0[u];
+                else if (wk < nitems)
+                    v[u] = *reinterpret_cast<const P2 *>(src + 2 * (uint64_t)wk);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < LB; u++) {
+                const uint32_t wk = wk0 + u * step;
+                if (wk < nitems) {
+                    if (a.pre_on) {
+                        const T f = aux[wk >> hp_shift];
+                        v[u].a = F::mul(v[u].a, f);
+                        v[u].b = F::mul(v[u].b, f);
+                    }
+                    *reinterpret_cast<P2 *>(x + 2 * wk) = v[u];
+                }
             }
         }
-        *reinterpret_cast<P2 *>(x + 2 * wk) = v;
     }
     __syncthreads();
-    seg_lds_ntt<F>(x, twd, a.logD);
+#ifndef WF_EXP_SKIP_NTT
+    seg_lds_ntt<F, OUT == SEG_OUT_ROWS ? 1 : -1>(x, twd, a.logD);
+#endif
 
     // Store.  Work item = (row position pos, lane pair); this thread's positions are pos0 + j * pstride, j = 0, 1, ..
     // (pstride is a power of two > pos0), so its output indices are rev(pos0) | rev(j * pstride): the per-thread
@@ -466,6 +608,9 @@ __global__ void __launch_bounds__(512) k_seg_last(SegArgs<F> a) {
             const P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
             const uint64_t off = k * k_stride;
             if (pair_store) {
+#ifdef WF_EXP_SKIP_STORE
+                if (*reinterpret_cast<const uint32_t *>(&v.a) == a.logN + 77777u)
+#endif
                 *reinterpret_cast<P2 *>(pa + off) = v;
             } else {
                 if (pa) pa[off] = v.a;

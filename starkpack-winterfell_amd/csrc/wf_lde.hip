@@ -52,6 +52,7 @@ struct TableSet {  // device-resident Pow2L tables
 
 struct wf_ctx {
     int device = 0;
+    int num_cus = 256;  // compute units of the device: sizes the persistent grids of the segment kernels
     hipStream_t stream = nullptr;
     // key: (field, logN, kind, aux, offset lo, offset hi); kind 0 = forward root, 1 = inverse root,
     // 2 = coset bases (aux = log blowup), 3 = output series for interpolate_with_offset
@@ -790,6 +791,8 @@ int wf_ctx_create(int device, wf_ctx **out) {
     HIP_TRY(hipSetDevice(device));
     wf_ctx *c = new wf_ctx();
     c->device = device;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->num_cus = cus;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;

@@ -59,6 +59,26 @@ int main(int argc, char **argv) {
         const u128 d = a >= b ? a - b : a + (P - b);
         if (w(F128::sub_limbs(n(a), n(b))) != d) bad++;
     }
+    // Goldilocks shift twiddles (F64::mul_pow2 / div_pow2) against the general product by the same constant
+    {
+        using wf::F64;
+        const u128 P64 = F64::P;
+        auto chk = [&](uint64_t x) {
+            const uint64_t e12 = (uint64_t)(((u128)x << 12) % P64), e24 = (uint64_t)(((u128)x << 24) % P64);
+            const uint64_t e32 = (uint64_t)(((u128)x << 32) % P64);
+            if (F64::mul_pow2<12>(x) != e12 || F64::mul_pow2<24>(x) != e24 || F64::mul_pow2<32>(x) != e32) bad++;
+            const uint64_t d12 = F64::div_pow2<12>(x), d24 = F64::div_pow2<24>(x), d32 = F64::div_pow2<32>(x);
+            if ((uint64_t)(((u128)d12 << 12) % P64) != x || d12 >= F64::P) bad++;
+            if ((uint64_t)(((u128)d24 << 24) % P64) != x || d24 >= F64::P) bad++;
+            if ((uint64_t)(((u128)d32 << 32) % P64) != x || d32 >= F64::P) bad++;
+        };
+        const uint64_t edge[] = {0, 1, 2, 0xFFF, 0x1000, 0xFFFFFF, 0x1000000, 0xFFFFFFFFull, 0x100000000ull,
+                                 0xFFFFFFFF00000000ull, 0xFFFFFFFEFFFFFFFFull, 0xFFFFFFFF00000000ull - 1, F64::P - 1,
+                                 F64::P - 2, F64::P - 0x1000, 0xFFFFF00000000000ull, 0x000FFFFFFFFFFFFFull,
+                                 0xFFF0000000000001ull % F64::P, 0x8000000000000000ull, 0x7FFFFFFFFFFFFFFFull};
+        for (uint64_t e : edge) chk(e % F64::P);
+        for (long it = 0; it < iters; it++) chk(rnd() % F64::P);
+    }
     printf("checked %ld triples, bad=%ld\n", iters, bad);
     if (bad == 0) printf("ALL OK\n");
     return bad != 0;
