@@ -15,3 +15,4 @@ build_variant skip_load "-DWF_EXP_SKIP_LOAD"
 build_variant skip_mem "-DWF_EXP_SKIP_LOAD -DWF_EXP_SKIP_STORE"
 build_variant skip_ntt_store "-DWF_EXP_SKIP_NTT -DWF_EXP_SKIP_STORE"
 build_variant skip_ntt_load "-DWF_EXP_SKIP_NTT -DWF_EXP_SKIP_LOAD"
+build_variant nt_store "-DWF_EXP_NT_STORE"

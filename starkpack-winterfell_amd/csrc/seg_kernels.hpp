@@ -35,6 +35,20 @@ struct alignas(16) Pair {
     T a, b;
 };
 
+// 16- or 32-byte store of a lane pair; WF_EXP_NT_STORE: as non-temporal stores (tuning experiment)
+template <class T>
+__device__ __forceinline__ void store_pair(T *dst, const Pair<T> &v) {
+#ifdef WF_EXP_NT_STORE
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 *s = reinterpret_cast<const u32x4 *>(&v);
+    u32x4 *d = reinterpret_cast<u32x4 *>(dst);
+#pragma unroll
+    for (unsigned q = 0; q < sizeof(Pair<T>) / 16; q++) __builtin_nontemporal_store(s[q], d + q);
+#else
+    *reinterpret_cast<Pair<T> *>(dst) = v;
+#endif
+}
+
 enum : int { SEG_OUT_SEG = 0, SEG_OUT_ROWS = 1 };
 
 // Work-groups are dispatched to the 8 XCDs round-robin (blockIdx % 8), each XCD with its own L2.  This maps blockIdx
@@ -292,7 +306,7 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
 // EVAL = 0: interpolation (inverse transform), 1: coset evaluation (forward transform); like k_seg_last<F, OUT> the two
 // uses appear under different kernel names in profiles, and the direction selects the shift twiddles of radix16.
 template <class F, int EVAL, bool PACKED = false>
-__global__ void __launch_bounds__(512) k_seg_strided(SegArgs<F> a) {
+__global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
     typedef typename F::T T;
     typedef Pair<T> P2;
     constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;
@@ -438,14 +452,14 @@ __global__ void __launch_bounds__(512) k_seg_strided(SegArgs<F> a) {
 #ifdef WF_EXP_SKIP_STORE
         if (*reinterpret_cast<const uint32_t *>(&v.a) == a.logN + 77777u)
 #endif
-        *reinterpret_cast<P2 *>(dst_lane + (uint64_t)k * k_stride) = v;
+        store_pair(dst_lane + (uint64_t)k * k_stride, v);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Last pass.  grid.x = n_cosets * n_seg * O ; work-group = (coset c, segment g, row block o) of D contiguous rows.
 template <class F, int OUT, bool PACKED = false>
-__global__ void __launch_bounds__(512) k_seg_last(SegArgs<F> a) {
+__global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
     typedef typename F::T T;
     typedef Pair<T> P2;
     constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;
@@ -571,7 +585,7 @@ __global__ void __launch_bounds__(512) k_seg_last(SegArgs<F> a) {
                 v.a = F::mul(v.a, a.scale);
                 v.b = F::mul(v.b, a.scale);
             }
-            *reinterpret_cast<P2 *>(dst + k * S) = v;
+            store_pair(dst + k * S, v);
         }
     } else {
         // destination of each lane for k = 0: dst + trace * trace_elems + (coset) * row_width + column
@@ -611,7 +625,7 @@ __global__ void __launch_bounds__(512) k_seg_last(SegArgs<F> a) {
 #ifdef WF_EXP_SKIP_STORE
                 if (*reinterpret_cast<const uint32_t *>(&v.a) == a.logN + 77777u)
 #endif
-                *reinterpret_cast<P2 *>(pa + off) = v;
+                store_pair(pa + off, v);
             } else {
                 if (pa) pa[off] = v.a;
                 if (pb) pb[off] = v.b;

@@ -240,13 +240,27 @@ struct Plan {
     uint32_t dig[4];
 };
 
-// digits of at most `max_digit` bits (what one work-group can hold in LDS: 11 for f64, 10 for f128), balanced
-static Plan make_plan(uint32_t L, uint32_t max_digit) {
+// digits of at most `max_digit` bits (what one work-group can hold in LDS: 11 for f64, 10 for f128), balanced.
+// `avoid_full`: a plan of two maximal digits would run both passes with a single work-group per CU (the tile fills
+// the LDS), which measures ~10 % slower than three passes over smaller tiles (2^22 f64, 2^20 f128).
+static Plan make_plan(uint32_t L, uint32_t max_digit, bool avoid_full = false) {
     Plan p;
     p.n_pass = L <= 10 ? 1 : (int)((L + max_digit - 1) / max_digit);
+    if (avoid_full && p.n_pass == 2 && L == 2 * max_digit) p.n_pass = 3;
     uint32_t base = L / p.n_pass, rem = L % p.n_pass;
     for (int i = 0; i < p.n_pass; i++) p.dig[i] = base + (i < (int)rem ? 1 : 0);
     return p;
+}
+
+// the plan of the segment kernels (run_seg_transform and the sizing of its work buffer must agree on it)
+template <class F>
+static Plan seg_plan(uint32_t logN) {
+    uint32_t max_digit = F::BYTES == 8 ? 11 : 10;
+    if (const char *e = getenv("WF_EXP_MAX_DIGIT")) {  // tuning experiment: force more, smaller passes
+        const uint32_t v = (uint32_t)atoi(e);
+        if (v >= 4 && v < max_digit && (logN + v - 1) / v <= 4) max_digit = v;  // Plan holds 4 digits
+    }
+    return make_plan(logN, max_digit, true);
 }
 
 template <class F>
@@ -382,7 +396,10 @@ static int seg_launch_dims(uint32_t logD, uint32_t &threads, size_t &lds) {
     const size_t D = (size_t)1 << logD;
     lds = (D * SegCfg<F>::S + 2 * D) * sizeof(typename F::T);
     if (lds > 160 * 1024) return fail(WF_ERR_ARG, "internal: pass needs %zu bytes of LDS", lds);
-    threads = logD >= 9 ? 512 : 256;
+    // one work item of the widest round per thread (radix-16 on 8 lanes for f64, radix-4 on lane pairs for f128: D/2
+    // items either way), so that no wave idles through the transform rounds; a 2^11-row f64 tile fills the LDS of a CU
+    // on its own and brings its 16 waves along
+    threads = (uint32_t)std::min<size_t>(1024, std::max<size_t>(64, D / 2));
     if (lds > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void *)k_seg_strided<F, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_TRY(hipFuncSetAttribute((const void *)k_seg_strided<F, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -419,7 +436,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
     TableSet *tw;
     int rc = root_tables<F>(ctx, d.logN, inverse, &tw);
     if (rc) return rc;
-    const Plan plan = make_plan(d.logN, F::BYTES == 8 ? 11 : 10);
+    const Plan plan = seg_plan<F>(d.logN);
     const uint64_t N = (uint64_t)1 << d.logN;
 
     SegArgs<F> a;
@@ -670,7 +687,7 @@ static int path_buffers(wf_ctx *ctx, const wf_params *p, PathBufs<F> &b) {
     b.total_base_cols = p->n_cols * p->ext_degree * p->n_traces;
     b.n_seg = (b.total_base_cols + S - 1) / S;
     const size_t seg_vals = (size_t)b.n_seg * S << p->log2_trace_len;
-    const size_t work_vals = make_plan(p->log2_trace_len, F::BYTES == 8 ? 11 : 10).n_pass > 1 ? seg_vals << p->log2_blowup : 0;
+    const size_t work_vals = seg_plan<F>(p->log2_trace_len).n_pass > 1 ? seg_vals << p->log2_blowup : 0;
     int rc = ensure(ctx->scratch, (2 * seg_vals + work_vals) * sizeof(T));
     if (rc) return rc;
     b.segA = (T *)ctx->scratch.p;

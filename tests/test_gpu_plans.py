@@ -1,0 +1,25 @@
+"""GPU: the parity suites again under forced pass plans.  By default a transform of 2^L rows takes 1 pass (L <= 10) or
+2 (3 only from 2^22 f64 / 2^20 f128 on), so the 3- and 4-pass code paths of the segment kernels would only ever see the
+largest inputs.  WF_EXP_MAX_DIGIT (a tuning switch of the library, read by its planner) caps the digit size, which sends
+the small and medium shapes of the parity and golden suites through many-pass plans; results must stay bit-exact."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("max_digit", [5, 7])
+def test_parity_under_forced_plans(capi, max_digit):
+    capi.load()
+    env = dict(os.environ)
+    env["WF_EXP_MAX_DIGIT"] = str(max_digit)
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                          os.path.join(ROOT, "tests", "test_gpu_coset_shard.py"),
+                          os.path.join(ROOT, "tests", "test_gpu_parity.py"),
+                          os.path.join(ROOT, "tests", "test_gpu_golden.py")],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
