@@ -367,6 +367,25 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
 #endif
         }
     }
+    // output factors of this tile: start * (w_N^(i * N/(D*I)))^k, start = h_c^i (evaluation) or the 1/n scale
+    // (interpolation).  Their table reads are issued here, next to the tile's rows, and the (at most two) values per
+    // thread wait in registers until the input factors in `aux` have been consumed.
+    T fo[2];
+    {
+        const uint32_t tw_shift = a.logN - a.logD - (63 - __builtin_clzll(a.I));
+        T start = a.scale_on ? a.scale : F::one();
+        if (!PACKED && a.pre_on) start = pre.get(i);
+        const bool trivial = !a.scale_on && (PACKED || !a.pre_on);
+#pragma unroll
+        for (uint32_t q = 0; q < 2; q++) {
+            const uint32_t k = threadIdx.x + q * blockDim.x;  // blockDim >= D / 2
+            if (k < D) {
+                T f = a.tw.get(((uint64_t)k * i) << tw_shift);
+                if (!trivial) f = F::mul(f, start);
+                fo[q] = f;
+            }
+        }
+    }
     for (uint32_t e = threadIdx.x; e < D; e += blockDim.x) {
         twd[e] = a.digit_tw[e];
         if (!PACKED && a.pre_on) aux[e] = pre.get((uint64_t)e * a.I);  // h_c^(d*I); h_c^i goes into the output table
@@ -410,24 +429,18 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
         }
     }
     __syncthreads();
+    // the input factors are consumed: `aux` now takes the output factors (visible after the transform's barriers)
+#pragma unroll
+    for (uint32_t q = 0; q < 2; q++) {
+        const uint32_t k = threadIdx.x + q * blockDim.x;
+        if (k < D) aux[k] = fo[q];
+    }
 #ifndef WF_EXP_SKIP_NTT  // tuning experiment: memory phases only (scripts/exp_variants.sh)
     seg_lds_ntt<F, EVAL ? 1 : -1>(x, twd, a.logD);
+#else
+    __syncthreads();
 #endif
 
-    // output factors: start * (w_N^(i * N/(D*I)))^k, start = h_c^i (evaluation) or the 1/n scale (interpolation)
-    {
-        const uint32_t tw_shift = a.logN - a.logD - (63 - __builtin_clzll(a.I));
-        T start = a.scale_on ? a.scale : F::one();
-        if (!PACKED && a.pre_on) start = pre.get(i);
-        const bool trivial = !a.scale_on && (PACKED || !a.pre_on);
-        for (uint32_t k = threadIdx.x; k < D; k += blockDim.x) {
-            const uint64_t e = ((uint64_t)k * i) << tw_shift;
-            T f = a.tw.get(e);
-            if (!trivial) f = F::mul(f, start);
-            aux[k] = f;
-        }
-    }
-    __syncthreads();
     T start_a = F::one(), start_b = F::one();
     if (PACKED && a.pre_on) {  // h_c^i of each lane's coset (the table above carries only the twiddle)
         start_a = pre_a.get(i);
