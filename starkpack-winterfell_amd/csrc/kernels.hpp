@@ -32,6 +32,11 @@ struct Pow2L {
         if (h) a = F::mul(a, hi[h]);
         return a;
     }
+    // branch-free form for prologues that want all their table reads in flight at once: g^e = a * b (hi[0] = 1)
+    __device__ __forceinline__ void fetch(uint64_t e, typename F::T &a, typename F::T &b) const {
+        a = lo[e & mask];
+        b = hi[e >> s];
+    }
 };
 
 enum : uint32_t { SCALE_NONE = 0, SCALE_CONST = 1, SCALE_SERIES = 2 };

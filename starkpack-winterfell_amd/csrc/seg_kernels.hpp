@@ -354,6 +354,24 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
     constexpr uint32_t LB = SegCfg<F>::LOAD_BATCH;
     const uint32_t step = blockDim.x;
     const bool from_regs = !(PACKED && a.pre_on);
+    // ---- prologue: every global read of the tile's setup is issued before the first one is used -- the operands of the
+    // output factors start * (w_N^(i * N/(D*I)))^k (start = h_c^i for an evaluation, 1/n for an interpolation), the digit
+    // twiddles, the operands of the input factors h_c^(d*I), then the tile's first LOAD_BATCH row pieces per thread (all
+    // of them up to D = 2^10).  Branch-free with clamped indices (blockDim >= D/2: at most two table entries per
+    // thread); the output factors wait in registers until the input factors in `aux` have been consumed.
+    const uint32_t tw_shift = a.logN - a.logD - (63 - __builtin_clzll(a.I));
+    const bool scale_in = !PACKED && a.pre_on;
+    const Pow2L<F> pin = scale_in ? pre : a.tw;  // without input scaling the reads go to the root table and are dropped
+    uint32_t kq[2];
+    T fo_a[2], fo_b[2], tw_q[2], fi_a[2], fi_b[2];
+#pragma unroll
+    for (uint32_t q = 0; q < 2; q++) {
+        const uint32_t k = threadIdx.x + q * blockDim.x;
+        kq[q] = k < D ? k : D - 1;
+        a.tw.fetch(((uint64_t)kq[q] * i) << tw_shift, fo_a[q], fo_b[q]);
+        tw_q[q] = a.digit_tw[kq[q]];
+        pin.fetch((uint64_t)kq[q] * a.I, fi_a[q], fi_b[q]);
+    }
     P2 v0[LB];
     if (from_regs) {
 #pragma unroll
@@ -367,28 +385,21 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
 #endif
         }
     }
-    // output factors of this tile: start * (w_N^(i * N/(D*I)))^k, start = h_c^i (evaluation) or the 1/n scale
-    // (interpolation).  Their table reads are issued here, next to the tile's rows, and the (at most two) values per
-    // thread wait in registers until the input factors in `aux` have been consumed.
     T fo[2];
     {
-        const uint32_t tw_shift = a.logN - a.logD - (63 - __builtin_clzll(a.I));
         T start = a.scale_on ? a.scale : F::one();
-        if (!PACKED && a.pre_on) start = pre.get(i);
-        const bool trivial = !a.scale_on && (PACKED || !a.pre_on);
+        if (scale_in) start = pre.get(i);
+        const bool trivial = !a.scale_on && !scale_in;
 #pragma unroll
         for (uint32_t q = 0; q < 2; q++) {
-            const uint32_t k = threadIdx.x + q * blockDim.x;  // blockDim >= D / 2
-            if (k < D) {
-                T f = a.tw.get(((uint64_t)k * i) << tw_shift);
-                if (!trivial) f = F::mul(f, start);
-                fo[q] = f;
+            T f = F::mul(fo_a[q], fo_b[q]);
+            if (!trivial) f = F::mul(f, start);
+            fo[q] = f;
+            if (threadIdx.x + q * blockDim.x < D) {
+                twd[kq[q]] = tw_q[q];
+                if (scale_in) aux[kq[q]] = F::mul(fi_a[q], fi_b[q]);  // h_c^(d*I); h_c^i goes into the output factors
             }
         }
-    }
-    for (uint32_t e = threadIdx.x; e < D; e += blockDim.x) {
-        twd[e] = a.digit_tw[e];
-        if (!PACKED && a.pre_on) aux[e] = pre.get((uint64_t)e * a.I);  // h_c^(d*I); h_c^i goes into the output table
     }
     __syncthreads();
 
@@ -521,9 +532,22 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
         pre.hi += (uint64_t)(a.coset0 + c) * a.pre_hi_stride;
     }
     const uint32_t nitems = D * HP;
-    constexpr uint32_t LB = SegCfg<F>::LOAD_BATCH;  // requested before the tables are built (see k_seg_strided)
+    // prologue as in k_seg_strided: the digit twiddles, the operands of the input factors (single-pass evaluation only)
+    // and the tile's rows are all requested before the first of them is used
+    constexpr uint32_t LB = SegCfg<F>::LOAD_BATCH;
     const uint32_t step = blockDim.x;
     const bool from_regs = !(PACKED && a.pre_on);
+    const bool scale_in = !PACKED && a.pre_on;
+    const Pow2L<F> pin = scale_in ? pre : a.tw;
+    uint32_t kq[2];
+    T tw_q[2], fi_a[2], fi_b[2];
+#pragma unroll
+    for (uint32_t q = 0; q < 2; q++) {
+        const uint32_t k = threadIdx.x + q * blockDim.x;  // blockDim >= D / 2
+        kq[q] = k < D ? k : D - 1;
+        tw_q[q] = a.digit_tw[kq[q]];
+        pin.fetch(kq[q], fi_a[q], fi_b[q]);  // single-pass evaluation: row index = coefficient index
+    }
     P2 v0[LB];
     if (from_regs) {
 #pragma unroll
@@ -536,9 +560,12 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
 #endif
         }
     }
-    for (uint32_t e = threadIdx.x; e < D; e += blockDim.x) {
-        twd[e] = a.digit_tw[e];
-        if (!PACKED && a.pre_on) aux[e] = pre.get(e);  // single-pass evaluation: row index = coefficient index
+#pragma unroll
+    for (uint32_t q = 0; q < 2; q++) {
+        if (threadIdx.x + q * blockDim.x < D) {
+            twd[kq[q]] = tw_q[q];
+            if (scale_in) aux[kq[q]] = F::mul(fi_a[q], fi_b[q]);
+        }
     }
     __syncthreads();
     if (PACKED && a.pre_on) {  // single pass: replicate the polynomial row into the coset groups, scaled per lane
