@@ -95,6 +95,11 @@ struct SegArgs {
     uint32_t cpr_log, lg_log;
     uint64_t row_width;
     uint64_t trace_lde_elems;
+    // fused leaf hashing (last pass, SEG_OUT_ROWS, one segment, one trace, not PACKED): the tile's rows are complete
+    // rows of the matrix and at most 64 bytes long, so leaf k * rows_per_k + coset is hashed here, from LDS, and the LDE
+    // is not read back by k_hash_rows (RowMatrix::commit_to_rows, row_matrix.rs:183-203)
+    uint32_t *leaves;          // nullptr: no fused hashing
+    uint32_t hash_epr;         // elements of a row that are hashed (elements_per_row)
 };
 
 // LDS position -> output index of seg_lds_ntt: radix-16 digits while >= 4 bits remain, then radix-4, then radix-2
@@ -614,9 +619,10 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
     // the lane (column, trace, destination base) is hoisted out of the loop.
     const uint32_t out_shift = a.logN - a.logD;
     const uint32_t pstride = blockDim.x >> hp_shift, pos0 = threadIdx.x >> hp_shift;
-    const uint32_t k0 = seg_digit_reverse<F>(pos0, a.logD);
-    if (pos0 >= D) return;  // more threads than work items (tiny transforms)
+    const uint32_t k0 = seg_digit_reverse<F>(pos0 < D ? pos0 : 0, a.logD);
+    const bool has_rows = pos0 < D;  // more threads than work items in tiny transforms
     if (OUT == SEG_OUT_SEG) {
+        if (!has_rows) return;
         T *dst = a.dst + ((uint64_t)c * a.n_seg + g) * seg_elems + lane_a;
         for (uint32_t pj = 0; pj < D; pj += pstride) {
             const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, a.logD)) << out_shift);
@@ -656,8 +662,8 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
                 pb = a.dst + (uint64_t)t1 * a.trace_lde_elems + (uint64_t)c * a.row_width + c1;
             }
         }
-        if (!pa && !pb) return;
-        for (uint32_t pj = 0; pj < D; pj += pstride) {
+        if (!has_rows) pa = pb = nullptr;
+        for (uint32_t pj = 0; (pa || pb) && pj < D; pj += pstride) {
             const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, a.logD)) << out_shift);
             const P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
             const uint64_t off = k * k_stride;
@@ -670,6 +676,29 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
                 if (pa) pa[off] = v.a;
                 if (pb) pb[off] = v.b;
             }
+        }
+    }
+
+    // Fused leaf hashing, after the row stores have been issued (they drain while the lanes hash): one lane per row
+    // position (blockDim >= D/2: at most two rows per thread); the S lanes of a row are its whole 64 bytes (unused lanes
+    // are zero), canonical bytes as in hash_elements (blake/mod.rs:46-59).
+    if (OUT == SEG_OUT_ROWS && !PACKED && a.leaves) {
+        constexpr uint32_t WPE = F::BYTES / 4;
+        for (uint32_t pos = threadIdx.x; pos < D; pos += blockDim.x) {
+            T ev[S];
+            uint4 *evq = reinterpret_cast<uint4 *>(ev);
+            const uint4 *q = reinterpret_cast<const uint4 *>(x + (size_t)pos * S);
+#pragma unroll
+            for (uint32_t w = 0; w < 4; w++) evq[w] = q[w];
+            uint32_t m[16], out[8];
+#pragma unroll
+            for (uint32_t e = 0; e < S; e++) elem_words<F>(ev[e], &m[e * WPE]);
+            b3::set_iv(out);
+            b3::compress(out, m, 0, 0, a.hash_epr * F::BYTES, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT);
+            const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << (a.logN - a.logD));
+            uint4 *dl = reinterpret_cast<uint4 *>(a.leaves + (k * a.rows_per_k + c) * 8);
+            dl[0] = make_uint4(out[0], out[1], out[2], out[3]);
+            dl[1] = make_uint4(out[4], out[5], out[6], out[7]);
         }
     }
 }

@@ -424,6 +424,9 @@ struct SegDesc {
     T *out;
     uint32_t logN, n_seg, n_cosets;
     bool rows_out;
+    void *leaves = nullptr;     // rows_out: hash the leaves in the last pass when the shape allows (sets *fused)
+    uint32_t hash_epr = 0;
+    bool *fused = nullptr;
     const TableSet *pre;
     uint32_t base_cols, total_base_cols, coset0;
     uint64_t row_width, trace_lde_elems;
@@ -531,6 +534,12 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         a.pre_on = (single && d.rows_out) ? 1 : 0;
         a.scale_on = (single && !d.rows_out) ? 1 : 0;
         a.scale = inv_n;
+        // leaf hashing rides on the last pass when a tile row is a whole matrix row of one trace (<= 64 bytes)
+        const bool fuse = d.rows_out && d.leaves && !packed && d.n_seg == 1 && d.total_base_cols == d.base_cols &&
+                          getenv("WF_EXP_NO_FUSED_HASH") == nullptr;
+        a.leaves = fuse ? (uint32_t *)d.leaves : nullptr;
+        a.hash_epr = d.hash_epr;
+        if (d.fused) *d.fused = fuse;
         uint32_t threads;
         size_t lds;
         rc = seg_launch_dims<F>(a.logD, threads, lds);
@@ -730,13 +739,19 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
     d.total_base_cols = b.total_base_cols;
     d.row_width = row_width;
     d.trace_lde_elems = Nrows * row_width;
+    bool hashed = false;  // leaves produced by the last evaluation pass itself (one segment, one trace)
+    d.leaves = d_leaves;
+    d.hash_epr = base_cols;
+    d.fused = &hashed;
     rc = run_seg_transform<F>(ctx, st, d);
     if (rc) return rc;
 
     if (d_leaves) {
-        prof_mark(ctx, st, "hash_rows");
-        rc = run_hash_rows<F>(ctx, st, d_lde, Nrows * row_width, Nrows, (uint32_t)row_width, base_cols, p->n_traces, d_leaves);
-        if (rc) return rc;
+        if (!hashed) {
+            prof_mark(ctx, st, "hash_rows");
+            rc = run_hash_rows<F>(ctx, st, d_lde, Nrows * row_width, Nrows, (uint32_t)row_width, base_cols, p->n_traces, d_leaves);
+            if (rc) return rc;
+        }
         if (d_nodes) {
             prof_mark(ctx, st, "merkle");
             rc = run_merkle(st, d_leaves, Nrows, d_nodes);
