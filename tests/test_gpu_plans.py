@@ -12,11 +12,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("max_digit", [5, 7])
-def test_parity_under_forced_plans(capi, max_digit):
+@pytest.mark.parametrize("switch", ["WF_EXP_MAX_DIGIT=5", "WF_EXP_MAX_DIGIT=7", "WF_EXP_NO_FUSED_HASH=1"])
+def test_parity_under_forced_plans(capi, switch):
+    """WF_EXP_NO_FUSED_HASH: one-segment, one-trace matrices normally get their leaves from the last evaluation pass;
+    with the switch they go through k_hash_rows like every other shape -- both routes must give the same bytes."""
     capi.load()
     env = dict(os.environ)
-    env["WF_EXP_MAX_DIGIT"] = str(max_digit)
+    name, value = switch.split("=")
+    env[name] = value
     out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                           os.path.join(ROOT, "tests", "test_gpu_coset_shard.py"),
                           os.path.join(ROOT, "tests", "test_gpu_parity.py"),
