@@ -198,8 +198,12 @@ __device__ __forceinline__ void radix16(typename F::T (&v)[16], const typename F
 // In-place transform of x[D][S] in LDS; twd[e] = w_D^e.  Rounds: radix-16 (one lane per work item, 16 values in
 // registers) while >= 4 bits remain, then radix-4 / radix-2 (two lanes per item).  Natural order in,
 // seg_digit_reverse order out.
+// `first` != nullptr: the first radix-16 round takes its 16 inputs from there instead of LDS -- the pass kernels load
+// them straight from global memory (work item wk = threadIdx.x: lane wk % S of rows a * D/16 + wk / S, a = 0..15;
+// needs logD >= 4, RADIX16 and blockDim >= D/2), which saves the tile's trip through LDS before the first round.
 template <class F, int DIR = 0>
-__device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::T *twd, uint32_t logD) {
+__device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::T *twd, uint32_t logD,
+                                            const typename F::T *first = nullptr) {
     typedef typename F::T T;
     typedef Pair<T> P2;
     constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;
@@ -221,8 +225,13 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
                 const uint32_t jp = u & (m - 1), p = u >> mlog;
                 const uint32_t base = (((p << cur) + jp) * S) + l;
                 T v[16];
+                if (first && cur == logD) {  // uniform
 #pragma unroll
-                for (int a = 0; a < 16; a++) v[a] = x[base + a * st];
+                    for (int a = 0; a < 16; a++) v[a] = first[a];
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 16; a++) v[a] = x[base + a * st];
+                }
                 radix16<F, DIR>(v, w16);
                 if (jp != 0) {
                     const uint32_t e = jp << tshift;
@@ -377,8 +386,24 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
         tw_q[q] = a.digit_tw[kq[q]];
         pin.fetch((uint64_t)kq[q] * a.I, fi_a[q], fi_b[q]);
     }
+    // `direct`: the 16 inputs of this thread's first radix-16 work item come straight from global memory into registers
+    // (lane threadIdx % S of rows a * D/16 + threadIdx / S), the tile makes no trip through LDS before the first round
+    const bool direct = SegCfg<F>::RADIX16 && a.logD >= 4 && from_regs;
+    const uint32_t m16 = D >> 4, l16 = threadIdx.x & (S - 1), j16 = threadIdx.x / S;
+    const bool has16 = threadIdx.x < m16 * S;
+    T vr[16];
     P2 v0[LB];
-    if (from_regs) {
+    if (direct) {
+        if (has16) {
+#pragma unroll
+            for (uint32_t q = 0; q < 16; q++)
+#ifdef WF_EXP_SKIP_LOAD
+                vr[q] = src[l16];
+#else
+                vr[q] = src[(row0 + (uint64_t)(q * m16 + j16) * a.I) * S + l16];
+#endif
+        }
+    } else if (from_regs) {
 #pragma unroll
         for (uint32_t u = 0; u < LB; u++) {
             const uint32_t wk = threadIdx.x + u * step;
@@ -408,7 +433,12 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
     }
     __syncthreads();
 
-    if (PACKED && a.pre_on) {  // replicate the polynomial's lanes into every coset group of the row
+    if (direct) {
+        if (scale_in && has16) {
+#pragma unroll
+            for (uint32_t q = 0; q < 16; q++) vr[q] = F::mul(vr[q], aux[q * m16 + j16]);
+        }
+    } else if (PACKED && a.pre_on) {  // replicate the polynomial's lanes into every coset group of the row
         for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
             const uint32_t lp = wk & (HP - 1), d = wk >> hp_shift;
             P2 v;
@@ -444,16 +474,20 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
             }
         }
     }
-    __syncthreads();
-    // the input factors are consumed: `aux` now takes the output factors (visible after the transform's barriers)
+    if (!direct || scale_in) __syncthreads();  // LDS tile written / input factors consumed (uniform condition)
+    // `aux` now takes the output factors (visible after the transform's barriers)
 #pragma unroll
     for (uint32_t q = 0; q < 2; q++) {
         const uint32_t k = threadIdx.x + q * blockDim.x;
         if (k < D) aux[k] = fo[q];
     }
 #ifndef WF_EXP_SKIP_NTT  // tuning experiment: memory phases only (scripts/exp_variants.sh)
-    seg_lds_ntt<F, EVAL ? 1 : -1>(x, twd, a.logD);
+    seg_lds_ntt<F, EVAL ? 1 : -1>(x, twd, a.logD, direct ? vr : nullptr);
 #else
+    if (direct && has16) {
+#pragma unroll
+        for (uint32_t q = 0; q < 16; q++) x[(q * m16 + j16) * S + l16] = vr[q];
+    }
     __syncthreads();
 #endif
 
@@ -553,6 +587,8 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
         tw_q[q] = a.digit_tw[kq[q]];
         pin.fetch(kq[q], fi_a[q], fi_b[q]);  // single-pass evaluation: row index = coefficient index
     }
+    // (no direct first round here, unlike k_seg_strided: the tile is one contiguous 64 KiB run, which 16-byte-per-lane
+    // loads staged through LDS stream faster than sixteen 8-byte loads per thread -- measured 0.61 -> 0.69 ms with it)
     P2 v0[LB];
     if (from_regs) {
 #pragma unroll
