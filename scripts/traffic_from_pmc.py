@@ -8,7 +8,9 @@ tallies 128-byte requests at 64 bytes, so it is doubled for kernels whose wave-i
 bytes (last passes, hashing, Merkle levels, layout changes); the strided passes gather isolated 64-byte rows
 (64-byte requests, counted exactly) and are not doubled, and neither is k_merkle_level2 (128 bytes per lane at a
 128-byte lane stride: its raw counter already equals the 340 MiB of children it must read).  Calibration:
-evaluate.last_pass must read the 512 MiB intermediate exactly once (raw counter: 256 MiB)."""
+evaluate.last_pass must read the 512 MiB intermediate exactly once (raw counter: 256 MiB).
+When the leaves are hashed inside the last evaluation pass (one segment, one trace) there is no k_hash_rows launch: its
+entry is zero and the evaluate entry carries the 256 MiB of leaf writes."""
 import collections
 import csv
 import json
@@ -36,7 +38,7 @@ def per_kernel(path, counter):
 def main():
     fetch, fcalls = per_kernel(sys.argv[1], "FETCH_SIZE")
     write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
-    steps = fcalls[next(k for k in fcalls if "k_hash_rows" in k)]  # one hash launch per commitment
+    steps = fcalls[next(k for k in fcalls if "k_cols_to_seg" in k)]  # one launch per commitment
     out = {"_note": "HBM bytes per commitment (cfg 2) from rocprofv3 PMC; see scripts/traffic_from_pmc.py for the "
                     "gfx950 corrections", "_round": sys.argv[3], "_steps_profiled": steps}
     for name, pats in LOGICAL:
