@@ -184,10 +184,11 @@ def test_error_codes(ctx, capi):
 
 
 @pytest.mark.parametrize("field,logR,logB,n_cols", [
-    (F64, 21, 1, 2),    # digits [11, 10]
-    (F64, 22, 1, 1),    # digits [11, 11]: a whole 160 KiB of LDS per work-group
+    (F64, 21, 1, 2),    # digits [11, 10]: a 2^11-row tile is a whole 160 KiB of LDS, 1024 threads per work-group
+    (F64, 22, 1, 1),    # segment kernels: three passes [8, 7, 7] instead of two full tiles; column kernels: [11, 11]
     (F64, 23, 1, 1),    # three passes [8, 8, 7]
-    (F128, 21, 1, 1),   # f128 digits are capped at 10 bits: three passes [7, 7, 7]
+    (F128, 20, 1, 1),   # f128 digits are capped at 10 bits; [10, 10] is replaced by three passes [7, 7, 6]
+    (F128, 21, 1, 1),   # three passes [7, 7, 7]
 ])
 def test_large_transform_plans(ctx, orc, capi, field, logR, logB, n_cols):
     rng = np.random.default_rng(logR)
