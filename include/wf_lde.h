@@ -206,6 +206,50 @@ int wf_fri_apply_drp_dev(wf_ctx *ctx, uint32_t field, uint32_t ext_degree, const
                          uint32_t folding, const uint8_t domain_offset[16], const void *alpha, void *d_out,
                          void *stream);
 
+/* Resident form of the whole commit phase: FriProver (fri/src/prover/mod.rs:98-230) with the evaluations, every layer's
+ * transposed matrix and every layer's tree kept in HBM.  The channel stays on the host: each layer is two calls with the
+ * Fiat-Shamir step in between --
+ *     for _ in 0..wf_fri_num_layers(..):   commit_layer -> root;  channel.commit_fri_layer(root);
+ *                                          alpha = channel.draw_fri_alpha();  fold(alpha)
+ *     set_remainder -> coefficients + their hash_elements commitment                       (prover/mod.rs:172-216)
+ * and the query phase (build_proof / query_layer, prover/mod.rs:232-300) reads each layer through the same
+ * wf_commitment queries as a trace commitment: positions folded with wf_fri_fold_positions, then
+ * wf_commitment_read_rows (the [E; N] evaluations of a position) and wf_commitment_prove_batch. */
+typedef struct wf_fri_prover wf_fri_prover;
+/* FriOptions::new + FriProver::new (fri/src/options.rs:26-44): folding in {2,4,8,16}, blowup a power of two;
+ * domain_offset is FriOptions::domain_offset (the field's GENERATOR in the reference, options.rs:46-55). */
+int wf_fri_prover_create(wf_ctx *ctx, uint32_t field, uint32_t ext_degree, uint32_t folding, uint32_t blowup,
+                         uint32_t remainder_max_degree, const uint8_t domain_offset[16], wf_fri_prover **out);
+void wf_fri_prover_destroy(wf_fri_prover *pr);
+/* FriOptions::num_fri_layers (fri/src/options.rs:85-93). */
+size_t wf_fri_num_layers(uint32_t folding, uint32_t blowup, uint32_t remainder_max_degree, size_t domain_size);
+/* Start of build_layers: the evaluations of the first layer (n elements of E, host memory; _dev: device memory, copied
+ * on `stream`).  WF_ERR_ARG while layers of an earlier proof are still held ("a prior proof generation request has not
+ * been completed yet", prover/mod.rs:173-176) -- call wf_fri_prover_reset first. */
+int wf_fri_prover_begin(wf_fri_prover *pr, const void *evals, size_t n);
+int wf_fri_prover_begin_dev(wf_fri_prover *pr, const void *d_evals, size_t n, void *stream);
+/* First half of build_layer (prover/mod.rs:191-203): transpose, hash_values, MerkleTree::new; root_out = the layer's
+ * root for channel.commit_fri_layer. */
+int wf_fri_prover_commit_layer(wf_fri_prover *pr, uint8_t root_out[32]);
+/* Second half (prover/mod.rs:205-214): apply_drp with the alpha the channel drew (one element of E, host memory); the
+ * committed layer joins the prover's layers, the folded evaluations become the current ones. */
+int wf_fri_prover_fold(wf_fri_prover *pr, const void *alpha);
+/* set_remainder (prover/mod.rs:218-227): interpolate_poly_with_offset of the current evaluations, the first
+ * len / blowup coefficients are the remainder polynomial: remainder_out receives *len_out (<= capacity) elements of E,
+ * commitment_out their hash_elements digest (what goes to channel.commit_fri_layer). */
+int wf_fri_prover_set_remainder(wf_fri_prover *pr, void *remainder_out, size_t capacity, size_t *len_out,
+                                uint8_t commitment_out[32]);
+/* Layers built so far and layer i as a resident commitment (rows = positions of the folded domain, one row = the
+ * folding * ext_degree base elements of [E; N]; owned by the prover: do not destroy). */
+size_t wf_fri_prover_num_layers(const wf_fri_prover *pr);
+int wf_fri_prover_layer(const wf_fri_prover *pr, size_t i, const wf_commitment **out);
+/* FriProver::reset (prover/mod.rs:150-154): drops the layers (build_proof does this at its end). */
+int wf_fri_prover_reset(wf_fri_prover *pr);
+/* folding::fold_positions (fri/src/folding/mod.rs:158-175): position % (source_domain_size / folding), first
+ * occurrences kept in order; out holds at most n entries. */
+int wf_fri_fold_positions(const uint64_t *positions, size_t n, size_t source_domain_size, uint32_t folding,
+                          uint64_t *out, size_t *n_out);
+
 /* ---- out-of-domain evaluation ----------------------------------------------------------------------- */
 
 /* ColMatrix::evaluate_columns_at (prover/src/matrix/col_matrix.rs:249-254): every column (n coefficients of

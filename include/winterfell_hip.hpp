@@ -407,4 +407,114 @@ inline std::pair<std::unique_ptr<TraceCommitment<E>>, std::vector<ColMatrix<E>>>
     return {std::make_unique<TraceCommitment<E>>(h, traces.size(), cols * E::EXTENSION_DEGREE), std::move(trace_polys)};
 }
 
+// ------------------------------------------------------------------------------------------------- FRI prover
+struct FriOptions {  // fri/src/options.rs:16-93
+    size_t blowup_factor, folding_factor, remainder_max_degree;
+    size_t num_fri_layers(size_t domain_size) const {
+        return wf_fri_num_layers((uint32_t)folding_factor, (uint32_t)blowup_factor, (uint32_t)remainder_max_degree, domain_size);
+    }
+};
+
+struct FriProofLayer {  // fri/src/proof.rs: the [E; N] evaluations of the queried positions + their batch proof
+    std::vector<uint64_t> positions;           // folded positions this layer was queried at
+    std::vector<std::vector<uint64_t>> values; // per position: folding * ext_degree base elements (raw words)
+    BatchMerkleProof proof;
+};
+
+// FriProver (fri/src/prover/mod.rs:98-300) with evaluations, layers and trees resident in HBM.  `Channel` provides
+// commit_fri_layer(const Digest&) and draw_fri_alpha() -> E, like the reference's ProverChannel.
+template <class E>
+class FriProver {
+  public:
+    FriProver(wf_ctx *ctx, FriOptions options, unsigned __int128 domain_offset) : options_(options) {
+        uint8_t off[16];
+        std::memcpy(off, &domain_offset, 16);
+        wf_check(wf_fri_prover_create(ctx, E::FIELD, E::EXTENSION_DEGREE, (uint32_t)options.folding_factor,
+                                      (uint32_t)options.blowup_factor, (uint32_t)options.remainder_max_degree, off, &h_));
+    }
+    ~FriProver() { wf_fri_prover_destroy(h_); }
+    FriProver(const FriProver &) = delete;
+    FriProver &operator=(const FriProver &) = delete;
+
+    size_t num_layers() const { return wf_fri_prover_num_layers(h_); }
+    const std::vector<E> &remainder() const { return remainder_; }
+    void reset() {  // prover/mod.rs:150-154
+        wf_check(wf_fri_prover_reset(h_));
+        remainder_.clear();
+    }
+
+    // build_layers (prover/mod.rs:172-189) + set_remainder (:218-227)
+    template <class Channel>
+    void build_layers(Channel &channel, const std::vector<E> &evaluations) {
+        wf_check(wf_fri_prover_begin(h_, evaluations.data(), evaluations.size()));
+        domain_size_ = evaluations.size();
+        const size_t layers = options_.num_fri_layers(evaluations.size());
+        size_t size = evaluations.size();
+        for (size_t i = 0; i < layers; i++) {
+            Digest root;
+            wf_check(wf_fri_prover_commit_layer(h_, root.data()));
+            channel.commit_fri_layer(root);
+            const E alpha = channel.draw_fri_alpha();
+            wf_check(wf_fri_prover_fold(h_, &alpha));
+            size /= options_.folding_factor;
+        }
+        remainder_.resize(size / options_.blowup_factor);
+        size_t len = 0;
+        Digest commitment;
+        wf_check(wf_fri_prover_set_remainder(h_, remainder_.data(), remainder_.size(), &len, commitment.data()));
+        remainder_.resize(len);
+        channel.commit_fri_layer(commitment);
+    }
+
+    // build_proof (prover/mod.rs:244-282): every layer queried at the folded positions; resets the prover like the reference
+    std::pair<std::vector<FriProofLayer>, std::vector<E>> build_proof(const std::vector<size_t> &positions) {
+        if (remainder_.empty()) throw std::logic_error("FRI layers have not been built yet");
+        std::vector<FriProofLayer> layers;
+        std::vector<uint64_t> pos(positions.begin(), positions.end());
+        size_t domain = domain_size_;
+        for (size_t i = 0; i < num_layers(); i++) {
+            std::vector<uint64_t> folded(pos.size());
+            size_t m = 0;
+            wf_check(wf_fri_fold_positions(pos.data(), pos.size(), domain, (uint32_t)options_.folding_factor, folded.data(), &m));
+            folded.resize(m);
+            const wf_commitment *layer = nullptr;
+            wf_check(wf_fri_prover_layer(h_, i, &layer));
+            uint64_t n_rows = 0, row_elems = 0;
+            uint32_t depth = 0;
+            wf_check(wf_commitment_info(layer, &n_rows, &row_elems, &depth));
+            const size_t words = row_elems * (sizeof(typename E::BaseField) / 8);
+            std::vector<uint64_t> flat(m * words);
+            wf_check(wf_commitment_read_rows(layer, folded.data(), m, flat.data()));
+            FriProofLayer pl;
+            pl.positions = folded;
+            for (size_t j = 0; j < m; j++) pl.values.emplace_back(flat.begin() + j * words, flat.begin() + (j + 1) * words);
+            pl.proof.leaves.resize(m);
+            std::vector<Digest> nodes(m * (depth + 1));
+            std::vector<uint32_t> counts(m);
+            size_t n_vec = 0, n_nodes = 0;
+            uint32_t d = 0;
+            wf_check(wf_commitment_prove_batch(layer, folded.data(), m, pl.proof.leaves[0].data(), nodes[0].data(), nodes.size(),
+                                               counts.data(), &n_vec, &n_nodes, &d));
+            size_t k = 0;
+            for (size_t v = 0; v < n_vec; v++) {
+                pl.proof.nodes.emplace_back(nodes.begin() + k, nodes.begin() + k + counts[v]);
+                k += counts[v];
+            }
+            pl.proof.depth = (uint8_t)d;
+            layers.push_back(std::move(pl));
+            pos = folded;
+            domain /= options_.folding_factor;
+        }
+        std::vector<E> remainder = remainder_;
+        reset();
+        return {std::move(layers), std::move(remainder)};
+    }
+
+  private:
+    FriOptions options_;
+    wf_fri_prover *h_ = nullptr;
+    size_t domain_size_ = 0;
+    std::vector<E> remainder_;
+};
+
 }  // namespace winterfell

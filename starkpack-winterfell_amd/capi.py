@@ -23,6 +23,9 @@ SYMBOLS = [
     "wf_trace_commit_shard_dev", "wf_merkle_build_dev", "wf_trace_commit_resident", "wf_constraint_commit_resident", "wf_commitment_destroy", "wf_commitment_root",
     "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_prove", "wf_commitment_prove_batch",
     "wf_evaluate_columns_at", "wf_commitment_evaluate_polys_at", "wf_fri_layer_commit", "wf_fri_apply_drp", "wf_fri_layer_commit_dev", "wf_fri_apply_drp_dev",
+    "wf_fri_prover_create", "wf_fri_prover_destroy", "wf_fri_num_layers", "wf_fri_prover_begin", "wf_fri_prover_begin_dev",
+    "wf_fri_prover_commit_layer", "wf_fri_prover_fold", "wf_fri_prover_set_remainder", "wf_fri_prover_num_layers",
+    "wf_fri_prover_layer", "wf_fri_prover_reset", "wf_fri_fold_positions",
     "wf_fft_evaluate_poly", "wf_fft_evaluate_poly_with_offset", "wf_fft_interpolate_poly",
     "wf_fft_interpolate_poly_with_offset", "wf_evaluate_polys_over", "wf_hash_rows", "wf_merkle_build",
 ]
@@ -129,6 +132,21 @@ def load():
         L.wf_fri_apply_drp.argtypes = [vp, u32, u32, vp, sz, u32, vp, vp, vp]
         L.wf_fri_layer_commit_dev.argtypes = [vp, u32, u32, vp, sz, u32, vp, vp, vp, vp]
         L.wf_fri_apply_drp_dev.argtypes = [vp, u32, u32, vp, sz, u32, vp, vp, vp, vp]
+        L.wf_fri_prover_create.argtypes = [vp, u32, u32, u32, u32, u32, vp, C.POINTER(vp)]
+        L.wf_fri_prover_destroy.argtypes = [vp]
+        L.wf_fri_prover_destroy.restype = None
+        L.wf_fri_num_layers.argtypes = [u32, u32, u32, sz]
+        L.wf_fri_num_layers.restype = sz
+        L.wf_fri_prover_begin.argtypes = [vp, vp, sz]
+        L.wf_fri_prover_begin_dev.argtypes = [vp, vp, sz, vp]
+        L.wf_fri_prover_commit_layer.argtypes = [vp, vp]
+        L.wf_fri_prover_fold.argtypes = [vp, vp]
+        L.wf_fri_prover_set_remainder.argtypes = [vp, vp, sz, C.POINTER(sz), vp]
+        L.wf_fri_prover_num_layers.argtypes = [vp]
+        L.wf_fri_prover_num_layers.restype = sz
+        L.wf_fri_prover_layer.argtypes = [vp, sz, C.POINTER(vp)]
+        L.wf_fri_prover_reset.argtypes = [vp]
+        L.wf_fri_fold_positions.argtypes = [vp, sz, sz, u32, vp, C.POINTER(sz)]
         L.wf_fft_evaluate_poly.argtypes = [vp, u32, u32, vp, sz]
         L.wf_fft_interpolate_poly.argtypes = [vp, u32, u32, vp, sz]
         L.wf_fft_interpolate_poly_with_offset.argtypes = [vp, u32, u32, vp, sz, vp]
@@ -358,16 +376,18 @@ class Context:
 class Commitment:
     """wf_commitment wrapper: LDE + tree resident in HBM; rows and Merkle proofs are read from there."""
 
-    def __init__(self, handle, field):
+    def __init__(self, handle, field, owned=True):
         self._h = handle
         self.field = field
+        self._owned = owned  # layers of a FriProver belong to the prover
         n_rows, row_elems, depth = C.c_uint64(), C.c_uint64(), C.c_uint32()
         _check(load().wf_commitment_info(self._h, C.byref(n_rows), C.byref(row_elems), C.byref(depth)))
         self.n_rows, self.row_elems, self.depth = n_rows.value, row_elems.value, depth.value
 
     def close(self):
         if self._h:
-            load().wf_commitment_destroy(self._h)
+            if self._owned:
+                load().wf_commitment_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -416,3 +436,73 @@ class Commitment:
             out.append([bytes(nodes[k + j]) for j in range(int(counts[i]))])
             k += int(counts[i])
         return [bytes(x) for x in leaves[:n]], out, depth.value
+
+
+def fri_num_layers(folding: int, blowup: int, remainder_max_degree: int, domain_size: int) -> int:
+    return int(load().wf_fri_num_layers(folding, blowup, remainder_max_degree, domain_size))
+
+
+def fri_fold_positions(positions, source_domain_size: int, folding: int) -> np.ndarray:
+    pos = np.ascontiguousarray(positions, dtype=np.uint64)
+    out = np.empty(max(1, len(pos)), dtype=np.uint64)
+    n_out = C.c_size_t()
+    _check(load().wf_fri_fold_positions(_p(pos), len(pos), source_domain_size, folding, _p(out), C.byref(n_out)))
+    return out[:n_out.value].copy()
+
+
+class FriProver:
+    """wf_fri_prover wrapper: the commit phase of FriProver (fri/src/prover/mod.rs) with everything resident in HBM."""
+
+    def __init__(self, ctx: "Context", field, ext, folding, blowup, remainder_max_degree, offset: int):
+        self.field, self.ext, self.folding, self.blowup = field, ext, folding, blowup
+        self._h = C.c_void_p()
+        _check(load().wf_fri_prover_create(ctx._h, field, ext, folding, blowup, remainder_max_degree, _off16(offset),
+                                           C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            load().wf_fri_prover_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def begin(self, evals: np.ndarray):
+        a = np.ascontiguousarray(evals, dtype=np.uint64)
+        n = a.size // (self.ext * ELEM_WORDS[self.field])
+        _check(load().wf_fri_prover_begin(self._h, _p(a), n))
+
+    def begin_dev(self, d_ptr: int, n: int, stream: int = 0):
+        _check(load().wf_fri_prover_begin_dev(self._h, d_ptr, n, stream))
+
+    def commit_layer(self) -> bytes:
+        out = (C.c_uint8 * 32)()
+        _check(load().wf_fri_prover_commit_layer(self._h, out))
+        return bytes(out)
+
+    def fold(self, alpha: np.ndarray):
+        al = np.ascontiguousarray(alpha, dtype=np.uint64)
+        _check(load().wf_fri_prover_fold(self._h, _p(al)))
+
+    def set_remainder(self, capacity: int):
+        w = ELEM_WORDS[self.field]
+        out = np.empty((capacity, self.ext, w) if w > 1 else (capacity, self.ext), dtype=np.uint64)
+        n = C.c_size_t()
+        digest = (C.c_uint8 * 32)()
+        _check(load().wf_fri_prover_set_remainder(self._h, _p(out), capacity, C.byref(n), digest))
+        return out[:n.value].copy(), bytes(digest)
+
+    def num_layers(self) -> int:
+        return int(load().wf_fri_prover_num_layers(self._h))
+
+    def layer(self, i: int) -> Commitment:
+        h = C.c_void_p()
+        _check(load().wf_fri_prover_layer(self._h, i, C.byref(h)))
+        return Commitment(h, self.field, owned=False)
+
+    def reset(self):
+        _check(load().wf_fri_prover_reset(self._h))
+

@@ -1457,6 +1457,7 @@ extern "C" {
 
 int wf_commitment_evaluate_polys_at(const wf_commitment *c, const void *z, uint32_t z_ext_degree, void *out) {
     if (!c || !z || !out) return fail(WF_ERR_ARG, "null argument");
+    if (!c->polys) return fail(WF_ERR_ARG, "this commitment holds no polynomials (FRI layer)");
     wf_ctx *ctx = c->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t n_cols = (size_t)c->p.n_cols * c->p.n_traces, n = (size_t)1 << c->p.log2_trace_len;
@@ -1667,3 +1668,226 @@ int wf_merkle_build(wf_ctx *ctx, const uint8_t *leaves, size_t n_leaves, uint8_t
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------- resident FRI prover
+struct wf_fri_prover {
+    wf_ctx *ctx = nullptr;
+    uint32_t field = 0, ext = 0, folding = 0, blowup = 0, remainder_max_degree = 0;
+    uint8_t offset[16] = {0};
+    void *evals = nullptr;  // evaluations of the current layer (device)
+    size_t n = 0;
+    wf_commitment *pending = nullptr;  // committed, not yet folded
+    std::vector<wf_commitment *> layers;
+};
+
+static void fri_prover_clear(wf_fri_prover *pr) {
+    (void)hipSetDevice(pr->ctx->device);
+    (void)hipStreamSynchronize(pr->ctx->stream);
+    if (pr->evals) (void)hipFree(pr->evals);
+    pr->evals = nullptr;
+    pr->n = 0;
+    free_commitment(pr->pending);
+    pr->pending = nullptr;
+    for (wf_commitment *c : pr->layers) free_commitment(c);
+    pr->layers.clear();
+}
+
+extern "C" {
+
+size_t wf_fri_num_layers(uint32_t folding, uint32_t blowup, uint32_t remainder_max_degree, size_t domain_size) {
+    if (folding < 2) return 0;
+    size_t result = 0;
+    const size_t max_remainder_size = ((size_t)remainder_max_degree + 1) * blowup;  // fri/src/options.rs:87
+    while (domain_size > max_remainder_size) {
+        domain_size /= folding;
+        result++;
+    }
+    return result;
+}
+
+int wf_fri_fold_positions(const uint64_t *positions, size_t n, size_t source_domain_size, uint32_t folding, uint64_t *out,
+                          size_t *n_out) {
+    if (!positions || !out || !n_out) return fail(WF_ERR_ARG, "null argument");
+    if (folding == 0 || source_domain_size < folding) return fail(WF_ERR_ARG, "invalid domain size / folding factor");
+    const size_t target = source_domain_size / folding;
+    size_t m = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t pos = positions[i] % target;
+        bool seen = false;
+        for (size_t j = 0; j < m && !seen; j++) seen = out[j] == pos;
+        if (!seen) out[m++] = pos;
+    }
+    *n_out = m;
+    return 0;
+}
+
+int wf_fri_prover_create(wf_ctx *ctx, uint32_t field, uint32_t ext, uint32_t folding, uint32_t blowup,
+                         uint32_t remainder_max_degree, const uint8_t domain_offset[16], wf_fri_prover **out) {
+    if (!out) return fail(WF_ERR_ARG, "out is null");
+    uint32_t l;
+    int rc = check_fri_args(ctx, field, ext, 2 * (size_t)16, folding, &l);  // field / extension / folding factor
+    if (rc) return rc;
+    if (blowup < 1 || (blowup & (blowup - 1))) return fail(WF_ERR_BLOWUP, "blowup factor must be a power of two");
+    if (!domain_offset) return fail(WF_ERR_ARG, "domain offset is null");
+    u128 off;
+    memcpy(&off, domain_offset, 16);
+    const u128 mod = field == WF_FIELD_F64 ? (u128)F64::P : F128::P();
+    if (off == 0 || off >= mod) return fail(WF_ERR_OFFSET, "domain offset must be a non-zero field element");
+    wf_fri_prover *pr = new wf_fri_prover();
+    pr->ctx = ctx;
+    pr->field = field;
+    pr->ext = ext;
+    pr->folding = folding;
+    pr->blowup = blowup;
+    pr->remainder_max_degree = remainder_max_degree;
+    memcpy(pr->offset, domain_offset, 16);
+    *out = pr;
+    return 0;
+}
+
+void wf_fri_prover_destroy(wf_fri_prover *pr) {
+    if (!pr) return;
+    fri_prover_clear(pr);
+    delete pr;
+}
+
+int wf_fri_prover_reset(wf_fri_prover *pr) {
+    if (!pr) return fail(WF_ERR_ARG, "prover is null");
+    fri_prover_clear(pr);
+    return 0;
+}
+
+static int fri_prover_begin(wf_fri_prover *pr, const void *src, size_t n, bool on_device, hipStream_t st) {
+    if (!pr || !src) return fail(WF_ERR_ARG, "null argument");
+    if (!pr->layers.empty() || pr->pending || pr->evals)
+        return fail(WF_ERR_ARG, "a prior proof generation request has not been completed yet");  // prover/mod.rs:173-176
+    if (n < 2 || (n & (n - 1))) return fail(WF_ERR_TRACE_LENGTH, "number of evaluations must be a power of two");
+    uint32_t l = 0;
+    while (((size_t)1 << l) < n) l++;
+    if (l > (pr->field == WF_FIELD_F64 ? F64::TWO_ADICITY : F128::TWO_ADICITY))
+        return fail(WF_ERR_DOMAIN, "no multiplicative subgroup of size 2^%u in this field", l);
+    HIP_TRY(hipSetDevice(pr->ctx->device));
+    const size_t bytes = n * pr->ext * wf_elem_bytes(pr->field);
+    HIP_TRY(hipMalloc(&pr->evals, bytes));
+    HIP_TRY(hipMemcpyAsync(pr->evals, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    pr->n = n;
+    return 0;
+}
+
+int wf_fri_prover_begin(wf_fri_prover *pr, const void *evals, size_t n) {
+    return fri_prover_begin(pr, evals, n, false, pr ? pr->ctx->stream : nullptr);
+}
+
+int wf_fri_prover_begin_dev(wf_fri_prover *pr, const void *d_evals, size_t n, void *stream) {
+    return fri_prover_begin(pr, d_evals, n, true, stream ? (hipStream_t)stream : (pr ? pr->ctx->stream : nullptr));
+}
+
+int wf_fri_prover_commit_layer(wf_fri_prover *pr, uint8_t root_out[32]) {
+    if (!pr || !root_out) return fail(WF_ERR_ARG, "null argument");
+    if (!pr->evals) return fail(WF_ERR_ARG, "no evaluations: call wf_fri_prover_begin first");
+    if (pr->pending) return fail(WF_ERR_ARG, "the committed layer has not been folded yet");
+    uint32_t l;
+    int rc = check_fri_args(pr->ctx, pr->field, pr->ext, pr->n, pr->folding, &l);
+    if (rc) return rc;
+    wf_ctx *ctx = pr->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t eb = wf_elem_bytes(pr->field), rows = pr->n / pr->folding;
+    wf_commitment *c = new wf_commitment();
+    memset(c, 0, sizeof(*c));
+    c->ctx = ctx;
+    c->p.field = pr->field;
+    c->p.ext_degree = pr->ext;
+    c->p.n_cols = pr->folding;
+    c->p.n_traces = 1;
+    c->p.digest_bytes = 32;
+    memcpy(c->p.domain_offset, pr->offset, 16);
+    c->n_rows = rows;
+    c->row_width = c->epr = c->row_elems = (uint64_t)pr->folding * pr->ext;
+    for (uint64_t t = rows; t > 1; t >>= 1) c->depth++;
+    c->p.log2_trace_len = c->depth;
+    hipError_t e = hipMalloc(&c->lde, pr->n * pr->ext * eb);
+    if (e == hipSuccess) e = hipMalloc(&c->leaves, rows * 32);
+    if (e == hipSuccess) e = hipMalloc(&c->nodes, rows * 32);
+    if (e != hipSuccess) {
+        free_commitment(c);
+        return fail(WF_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    hipStream_t st = ctx->stream;
+    rc = pr->field == WF_FIELD_F64
+             ? fri_layer_commit_dev<F64>(ctx, st, pr->ext, pr->evals, pr->n, pr->folding, c->lde, c->leaves, c->nodes)
+             : fri_layer_commit_dev<F128>(ctx, st, pr->ext, pr->evals, pr->n, pr->folding, c->lde, c->leaves, c->nodes);
+    if (rc == 0 && hipMemcpyAsync(c->root, (const char *)c->nodes + 32, 32, hipMemcpyDeviceToHost, st) != hipSuccess)
+        rc = fail(WF_ERR_HIP, "copying the layer root failed");
+    if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = fail(WF_ERR_HIP, "stream synchronisation failed");
+    if (rc) {
+        free_commitment(c);
+        return rc;
+    }
+    memcpy(root_out, c->root, 32);
+    pr->pending = c;
+    return 0;
+}
+
+int wf_fri_prover_fold(wf_fri_prover *pr, const void *alpha) {
+    if (!pr || !alpha) return fail(WF_ERR_ARG, "null argument");
+    if (!pr->pending) return fail(WF_ERR_ARG, "no committed layer to fold: call wf_fri_prover_commit_layer first");
+    wf_ctx *ctx = pr->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t rows = pr->n / pr->folding;
+    void *next = nullptr;
+    HIP_TRY(hipMalloc(&next, rows * pr->ext * wf_elem_bytes(pr->field)));
+    hipStream_t st = ctx->stream;
+    int rc = pr->field == WF_FIELD_F64
+                 ? fri_apply_drp_dev<F64>(ctx, st, pr->ext, pr->pending->lde, rows, pr->folding, pr->offset, alpha, next)
+                 : fri_apply_drp_dev<F128>(ctx, st, pr->ext, pr->pending->lde, rows, pr->folding, pr->offset, alpha, next);
+    if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = fail(WF_ERR_HIP, "stream synchronisation failed");
+    if (rc) {
+        (void)hipFree(next);
+        return rc;
+    }
+    (void)hipFree(pr->evals);
+    pr->evals = next;
+    pr->n = rows;
+    pr->layers.push_back(pr->pending);
+    pr->pending = nullptr;
+    return 0;
+}
+
+int wf_fri_prover_set_remainder(wf_fri_prover *pr, void *remainder_out, size_t capacity, size_t *len_out,
+                                uint8_t commitment_out[32]) {
+    if (!pr || !remainder_out || !len_out || !commitment_out) return fail(WF_ERR_ARG, "null argument");
+    if (!pr->evals) return fail(WF_ERR_ARG, "no evaluations: call wf_fri_prover_begin first");
+    if (pr->pending) return fail(WF_ERR_ARG, "the committed layer has not been folded yet");
+    const size_t len = pr->n / pr->blowup;
+    if (len == 0) return fail(WF_ERR_BLOWUP, "fewer evaluations (%zu) than the blowup factor (%u)", pr->n, pr->blowup);
+    if (len > capacity) return fail(WF_ERR_ARG, "remainder has %zu coefficients, buffer holds %zu", len, capacity);
+    wf_ctx *ctx = pr->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t eb = wf_elem_bytes(pr->field), bytes = pr->n * pr->ext * eb;
+    std::vector<unsigned char> host(bytes);
+    HIP_TRY(hipMemcpy(host.data(), pr->evals, bytes, hipMemcpyDeviceToHost));
+    // the remainder layer is tiny ((remainder_max_degree + 1) * blowup evaluations): through the host-buffer entry points
+    int rc = wf_fft_interpolate_poly_with_offset(ctx, pr->field, pr->ext, host.data(), pr->n, pr->offset);
+    if (rc) return rc;
+    memcpy(remainder_out, host.data(), len * pr->ext * eb);
+    rc = wf_hash_rows(ctx, pr->field, remainder_out, 1, len * pr->ext, commitment_out);  // hash_elements(&remainder_poly)
+    if (rc) return rc;
+    *len_out = len;
+    (void)hipFree(pr->evals);
+    pr->evals = nullptr;
+    pr->n = 0;
+    return 0;
+}
+
+size_t wf_fri_prover_num_layers(const wf_fri_prover *pr) { return pr ? pr->layers.size() : 0; }
+
+int wf_fri_prover_layer(const wf_fri_prover *pr, size_t i, const wf_commitment **out) {
+    if (!pr || !out) return fail(WF_ERR_ARG, "null argument");
+    if (i >= pr->layers.size()) return fail(WF_ERR_ARG, "layer %zu does not exist (%zu layers)", i, pr->layers.size());
+    *out = pr->layers[i];
+    return 0;
+}
+
+}  // extern "C"
+

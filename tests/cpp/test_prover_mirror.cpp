@@ -5,6 +5,7 @@
 // Build + run: tests/test_gpu_cpp_mirror.py (needs a GPU).
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../../include/winterfell_hip.hpp"
@@ -239,7 +240,94 @@ static void resident_commitment_query() {
     std::printf("resident_commitment_query ok\n");
 }
 
+// fri/src/prover/tests.rs:22-69 (fri_prove_verify): evaluations of a polynomial with coefficients 0..trace_length-1 over
+// the LDE domain, folding factor 4, max remainder degree 7 -- here the commit phase and the query phase of the resident
+// FriProver against the oracle's layer-by-layer restatement.  The channel derives alpha from the layer root.
+struct TestChannel {
+    std::vector<Digest> layer_commitments;
+    void commit_fri_layer(const Digest &d) { layer_commitments.push_back(d); }
+    F64Element draw_fri_alpha() {
+        Digest seed;
+        orc_merge_with_int(layer_commitments.back().data(), layer_commitments.size(), seed.data());
+        uint64_t v;
+        std::memcpy(&v, seed.data(), 8);
+        return F64Element{orc_f64_new(v >> 2)};
+    }
+};
+
+static void fri_prover_resident() {
+    const size_t trace_length = 1 << 8, blowup = 8, folding = 4, max_rem = 7, n = trace_length * blowup;
+    std::vector<uint64_t> tw(n / 2);
+    EXPECT(orc_f64_get_twiddles(tw.data(), n, 0) == 0);
+    std::vector<F64Element> evaluations(n, F64Element{0});
+    for (size_t i = 0; i < trace_length; i++) evaluations[i].inner = orc_f64_new(i);  // build_evaluations
+    orc_f64_evaluate_poly(reinterpret_cast<uint64_t *>(evaluations.data()), n, 1, tw.data());
+
+    Prover prover(0);
+    FriOptions options{blowup, folding, max_rem};
+    FriProver<F64Element> fri(prover.context(), options, 7);
+    TestChannel channel;
+    fri.build_layers(channel, evaluations);
+    EXPECT(fri.num_layers() == options.num_fri_layers(n) && fri.num_layers() == 3);
+    EXPECT(channel.layer_commitments.size() == fri.num_layers() + 1);
+
+    // oracle: the same chain on the host
+    std::vector<uint64_t> cur(n);
+    for (size_t i = 0; i < n; i++) cur[i] = evaluations[i].inner;
+    TestChannel want;
+    size_t size = n;
+    uint8_t off[16] = {7};
+    std::vector<std::vector<uint64_t>> transposed;
+    std::vector<std::vector<Digest>> trees;
+    for (size_t l = 0; l < 3; l++) {
+        std::vector<uint64_t> tr(size);
+        orc_transpose_slice(ORC_FIELD_F64, cur.data(), size, 1, folding, tr.data());
+        const size_t rows = size / folding;
+        std::vector<Digest> leaves(rows), nodes(rows);
+        for (size_t i = 0; i < rows; i++) orc_hash_elements(ORC_FIELD_F64, &tr[i * folding], folding, leaves[i].data());
+        EXPECT(orc_build_merkle_nodes(leaves[0].data(), rows, nodes[0].data(), 1) == 0);
+        EXPECT(nodes[1] == channel.layer_commitments[l]);
+        want.commit_fri_layer(nodes[1]);
+        const F64Element alpha = want.draw_fri_alpha();
+        std::vector<uint64_t> next(rows);
+        orc_apply_drp(ORC_FIELD_F64, tr.data(), rows, 1, folding, off, &alpha.inner, next.data(), 1);
+        transposed.push_back(tr);
+        trees.push_back(nodes);
+        cur = next;
+        size = rows;
+    }
+    std::vector<uint64_t> itw(size / 2);
+    EXPECT(orc_f64_get_twiddles(itw.data(), size, 1) == 0);
+    orc_f64_interpolate_poly_with_offset(cur.data(), size, 1, itw.data(), orc_f64_new(7));
+    EXPECT(fri.remainder().size() == size / blowup);
+    for (size_t i = 0; i < size / blowup; i++) EXPECT(fri.remainder()[i].inner == cur[i]);
+    Digest rc;
+    orc_hash_elements(ORC_FIELD_F64, cur.data(), size / blowup, rc.data());
+    EXPECT(rc == channel.layer_commitments.back());
+
+    // query phase (build_proof): values of every layer at the folded positions + verifiable batch proofs' leaves
+    auto [layers, remainder] = fri.build_proof({5, 77, 1029, 2000, 1500, 77 + 512});
+    EXPECT(layers.size() == 3 && remainder.size() == size / blowup && fri.num_layers() == 0);
+    size_t domain = n;
+    for (size_t l = 0; l < 3; l++) {
+        const size_t target = domain / folding;
+        for (size_t j = 0; j < layers[l].positions.size(); j++) {
+            const uint64_t pos = layers[l].positions[j];
+            EXPECT(pos < target);
+            for (size_t k = 0; k < folding; k++) EXPECT(layers[l].values[j][k] == transposed[l][pos * folding + k]);
+            Digest h;
+            orc_hash_elements(ORC_FIELD_F64, layers[l].values[j].data(), folding, h.data());
+            EXPECT(h == layers[l].proof.leaves[j]);
+        }
+        EXPECT(layers[l].proof.depth == ilog2_exact(target, "layer size"));
+        domain = target;
+    }
+    EXPECT(layers[0].positions.size() == 4);  // 1029 folds onto 5 and 77 + 512 onto 77 in the 512-row layer
+    std::printf("fri_prover_resident ok\n");
+}
+
 int main() {
+    fri_prover_resident();
     extend_and_commit_trace_table();
     resident_commitment_query();
     starkpack_two_traces_f64();
