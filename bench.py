@@ -26,6 +26,10 @@ sys.path.insert(0, ROOT)
 
 LOG_R, LOG_B, N_COLS = 20, 3, 8
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+# integer-VALU rates of the path's two instruction sequences in isolation on one MI355X (scripts/microbench.hip; the
+# better of the boxes measured this round, profiles/r01_microbench.txt): Goldilocks butterflies, BLAKE3 compressions
+ALU_BFLY_PER_S = 1.59e12
+ALU_COMPRESS_PER_S = 57.0e9
 
 
 def work_model(log_r=LOG_R, log_b=LOG_B, c=N_COLS, e=8):
@@ -43,7 +47,8 @@ def work_model(log_r=LOG_R, log_b=LOG_B, c=N_COLS, e=8):
     muls = butterflies + c * R + beta * c * R
     field_ops = 3 * butterflies + c * R + beta * c * R
     compressions = N * ((c * e + 63) // 64) + (N - 1)
-    return dict(bytes_per_kernel=bytes_k, b_alg=b_alg, field_ops=field_ops, modmuls=muls, compressions=compressions)
+    return dict(bytes_per_kernel=bytes_k, b_alg=b_alg, field_ops=field_ops, modmuls=muls, compressions=compressions,
+                butterflies=butterflies)
 
 
 def rand_f64_dev(torch, n, seed, device):
@@ -232,6 +237,12 @@ def main():
                                    + (", the roots of all steps all-gathered over RCCL once per run" if world > 1 else ""),
                        "log2_trace_len": LOG_R, "n_cols": N_COLS, "blowup": 1 << LOG_B, "n_traces": 1},
             "commits_per_s": commits / elapsed,
+            # the path is integer-VALU bound: time of its butterflies and BLAKE3 compressions at the rates the same
+            # instruction sequences reach in isolation (scripts/microbench.hip, profiles/r01_microbench.txt) vs the step
+            "alu": {"butterflies": model["butterflies"], "blake3_compressions": model["compressions"],
+                    "microbench_butterflies_per_s": ALU_BFLY_PER_S, "microbench_compressions_per_s": ALU_COMPRESS_PER_S,
+                    "ideal_ms": (model["butterflies"] / ALU_BFLY_PER_S + model["compressions"] / ALU_COMPRESS_PER_S) * 1e3,
+                    "frac": (model["butterflies"] / ALU_BFLY_PER_S + model["compressions"] / ALU_COMPRESS_PER_S) * 1e3 / ms_per_step},
             "path": {"b_alg_bytes": model["b_alg"], "hbm_frac": model["b_alg"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "field_ops": model["field_ops"], "blake3_compressions": model["compressions"]},
             "roofline": {"bound": "hbm", "kernel": dom + (" (leaf hashing fused into its last pass)" if fused_hash and dom == "evaluate" else ""),
