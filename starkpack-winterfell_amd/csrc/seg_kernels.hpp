@@ -100,6 +100,7 @@ struct SegArgs {
     // is not read back by k_hash_rows (RowMatrix::commit_to_rows, row_matrix.rs:183-203)
     uint32_t *leaves;          // nullptr: no fused hashing
     uint32_t hash_epr;         // elements of a row that are hashed (elements_per_row)
+    uint32_t *tile_counters;         // k_seg_last_hash: 8 zeroed counters, one per XCD (dynamic tile assignment)
 };
 
 // LDS position -> output index of seg_lds_ntt: radix-16 digits while >= 4 bits remain, then radix-4, then radix-2
@@ -738,6 +739,167 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Last pass of a multi-pass evaluation of ONE segment of ONE trace with fused leaf hashing (the bench workload), as a
+// PERSISTENT kernel: the grid is one resident set of work-groups, each takes tiles from a per-XCD ticket counter until
+// they run out (every work-group reaches that exit); the rows of its next tile are requested right after the row stores
+// of the current one and arrive while the lanes hash the leaves -- the only stretch of the tile loop that has 32 VGPRs
+// to spare (the transform itself needs ~80 of the 128 that two resident work-groups per CU allow).  Same tiles,
+// arithmetic and outputs as k_seg_last<F, ROWS>; a static tile walk (t += gridDim) measured 10 % slower than the
+// one-tile-per-work-group kernel, the dynamic one 5 % faster.
+__device__ __forceinline__ uint32_t opaque_tid() {
+    // everything derived from the thread index is recomputed inside every iteration of the tile loop from this opaque
+    // copy: otherwise the compiler hoists dozens of loop-invariant addresses out of the loop and holds them in VGPRs
+    uint32_t t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
+template <class F>
+__global__ void __launch_bounds__(1024) k_seg_last_hash(SegArgs<F> a) {
+    typedef typename F::T T;
+    typedef Pair<T> P2;
+    constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;
+    constexpr uint32_t hp_shift = HP == 4 ? 2 : 1;
+    constexpr uint32_t WPE = F::BYTES / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const uint32_t D = 1u << a.logD;
+    T *x = reinterpret_cast<T *>(smem_raw);
+    T *twd = x + (size_t)D * S;
+    const uint64_t total = (uint64_t)a.n_cosets * a.O;  // n_seg == 1
+    const uint64_t seg_elems = ((uint64_t)1 << a.logN) * S;
+    const uint32_t step = blockDim.x;
+    const uint32_t out_shift = a.logN - a.logD;
+    const uint64_t k_stride = (uint64_t)a.rows_per_k * a.row_width;
+
+    for (uint32_t e = threadIdx.x; e < D; e += step) twd[e] = a.digit_tw[e];
+
+    auto tile_src = [&](uint64_t t, uint32_t &c, uint64_t &rev_o) -> const T * {
+        uint64_t bid = xcd_group_index(t, total);  // coset fastest, 8 consecutive tiles on one XCD
+        c = (uint32_t)(bid % a.n_cosets);
+        const uint64_t o = bid / a.n_cosets;
+        rev_o = 0;
+        uint32_t bits = 0;
+        for (uint32_t q = 0; q < a.n_prev; q++) bits += a.prev_log[q];
+        uint32_t hi = bits, sh = 0;
+        for (uint32_t q = 0; q < a.n_prev; q++) {
+            hi -= a.prev_log[q];
+            rev_o |= ((o >> hi) & (((uint64_t)1 << a.prev_log[q]) - 1)) << sh;
+            sh += a.prev_log[q];
+        }
+        return a.src + (uint64_t)c * seg_elems + o * D * S;
+    };
+
+    // Tiles are handed out dynamically, per XCD (work-groups are dispatched to XCD blockIdx % 8): tile = 8 * ticket + xcd,
+    // so that the tile order within an XCD -- 8 consecutive tiles = the cosets of one row block -- is kept and a slow
+    // work-group does not hold back a fixed share of the tiles.  total is a multiple of 8 (8 cosets or more).
+    uint32_t *ticket_sh = reinterpret_cast<uint32_t *>(twd + D);  // two words behind the twiddles (dynamic LDS)
+    const uint32_t xcd = blockIdx.x & 7;
+    const uint64_t per_xcd = total >> 3;
+    auto next_ticket = [&](uint32_t slot) -> uint64_t {  // uniform result; includes a barrier
+        if (threadIdx.x == 0) ticket_sh[slot] = atomicAdd(a.tile_counters + xcd, 1u);
+        __syncthreads();
+        return ticket_sh[slot];
+    };
+    uint64_t ticket = next_ticket(0);
+    if (ticket >= per_xcd) return;
+    uint64_t t = ticket * 8 + xcd;
+    uint32_t c;
+    uint64_t rev_o;
+    const T *src = tile_src(t, c, rev_o);
+    // blockDim == D / 2 (the launcher guarantees it): the tile is one contiguous run of 4 * D 16-byte chunks (a row is 64
+    // bytes for either field), eight per thread, copied to the same offsets of `x`.  Eight native vector registers
+    // rather than an array or a struct: carried around the tile loop those would live in scratch memory.
+    uint4 q0, q1, q2, q3, q4, q5, q6, q7;
+#define WF_TILE_LOAD(SRC, TID)                                      \
+    do {                                                            \
+        const uint4 *s_ = reinterpret_cast<const uint4 *>(SRC) + (TID); \
+        q0 = s_[0];                                                 \
+        q1 = s_[step];                                              \
+        q2 = s_[2 * step];                                          \
+        q3 = s_[3 * step];                                          \
+        q4 = s_[4 * step];                                          \
+        q5 = s_[5 * step];                                          \
+        q6 = s_[6 * step];                                          \
+        q7 = s_[7 * step];                                          \
+    } while (0)
+    WF_TILE_LOAD(src, threadIdx.x);
+
+    while (true) {
+        {
+            uint4 *d_ = reinterpret_cast<uint4 *>(x) + opaque_tid();
+            d_[0] = q0;
+            d_[step] = q1;
+            d_[2 * step] = q2;
+            d_[3 * step] = q3;
+            d_[4 * step] = q4;
+            d_[5 * step] = q5;
+            d_[6 * step] = q6;
+            d_[7 * step] = q7;
+        }
+        __syncthreads();
+        seg_lds_ntt<F, 1>(x, twd, a.logD);
+
+        // row stores: lane pair (2l, 2l+1) of row position pos -> 16-byte piece of LDE row k * rows_per_k + c
+        {
+            const uint32_t tid = opaque_tid();
+            const uint32_t pstride = step >> hp_shift, pos0 = tid >> hp_shift, lane_a = 2 * (tid & (HP - 1));
+            if (pos0 < D && lane_a < a.base_cols) {
+                const uint32_t k0 = seg_digit_reverse<F>(pos0, a.logD);
+                T *pa = a.dst + (uint64_t)c * a.row_width + lane_a;
+                const bool pair = lane_a + 1 < a.base_cols;
+                for (uint32_t pj = 0; pj < D; pj += pstride) {
+                    const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, a.logD)) << out_shift);
+                    const P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
+                    if (pair)
+                        store_pair(pa + k * k_stride, v);
+                    else
+                        pa[k * k_stride] = v.a;
+                }
+            }
+        }
+
+        // the next tile's rows start their way into registers; they land while the leaves are hashed
+        ticket = next_ticket(1);  // (barrier: every lane has read its rows of `x` for the stores above)
+        const uint64_t tn = ticket * 8 + xcd;
+        const bool more = ticket < per_xcd;
+        uint32_t cn = c;
+        uint64_t rev_on = rev_o;
+        if (more) {
+            src = tile_src(tn, cn, rev_on);
+            WF_TILE_LOAD(src, opaque_tid());
+        }
+
+        // leaves: one lane per row position (blockDim >= D/2: at most two rows per thread), see k_seg_last
+        {
+            const uint32_t tid = opaque_tid();
+            for (uint32_t pos = tid; pos < D; pos += step) {
+                T ev[S];
+                uint4 *evq = reinterpret_cast<uint4 *>(ev);
+                const uint4 *q = reinterpret_cast<const uint4 *>(x + (size_t)pos * S);
+#pragma unroll
+                for (uint32_t w = 0; w < 4; w++) evq[w] = q[w];
+                uint32_t m[16], out[8];
+#pragma unroll
+                for (uint32_t e = 0; e < S; e++) elem_words<F>(ev[e], &m[e * WPE]);
+                b3::set_iv(out);
+                b3::compress(out, m, 0, 0, a.hash_epr * F::BYTES, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT);
+                const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << out_shift);
+                uint4 *dl = reinterpret_cast<uint4 *>(a.leaves + (k * a.rows_per_k + c) * 8);
+                dl[0] = make_uint4(out[0], out[1], out[2], out[3]);
+                dl[1] = make_uint4(out[4], out[5], out[6], out[7]);
+            }
+        }
+        if (!more) break;
+        __syncthreads();  // x is rewritten by the next tile
+        t = tn;
+        c = cn;
+        rev_o = rev_on;
+    }
+}
+
+#undef WF_TILE_LOAD
 
 // ---------------------------------------------------------------------------------------------------------------
 // Layout changes between the caller's columns ([col][row][ext coordinate]) and segments.

@@ -52,7 +52,7 @@ struct TableSet {  // device-resident Pow2L tables
 
 struct wf_ctx {
     int device = 0;
-    int num_cus = 256;  // compute units of the device: sizes the persistent grids of the segment kernels
+    int num_cus = 256;  // compute units of the device: sizes the persistent grid of k_seg_last_hash
     hipStream_t stream = nullptr;
     // key: (field, logN, kind, aux, offset lo, offset hi); kind 0 = forward root, 1 = inverse root,
     // 2 = coset bases (aux = log blowup), 3 = output series for interpolate_with_offset
@@ -66,6 +66,7 @@ struct wf_ctx {
     DevBuf scratch;   // evaluation intermediate [cosets][columns][R]
     DevBuf io[5];     // staging for the host-buffer API: trace, polys, lde, leaves, nodes
     DevBuf hash_tmp;  // chunk chaining values of rows longer than one BLAKE3 chunk
+    DevBuf tickets;   // per-XCD tile counters of the persistent last pass
 };
 
 // logical kernel of a mark: the text before the first '.', with the layout changes counted as interpolation
@@ -547,7 +548,19 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         const uint64_t grid = (uint64_t)n_groups * d.n_seg * a.O;
         if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
         prof_mark(ctx, st, tag_l);
-        if (d.rows_out && packed)
+        // fused hashing in a multi-pass plan: the persistent form of the last pass (one resident set of work-groups)
+        const bool persistent = fuse && !single && threads * 2 == (1u << a.logD) && grid % 8 == 0 && getenv("WF_EXP_NO_PERSISTENT") == nullptr;
+        if (persistent) {
+            if (lds > 64 * 1024)
+                HIP_TRY(hipFuncSetAttribute((const void *)k_seg_last_hash<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            const size_t lds_p = lds - ((size_t)1 << a.logD) * sizeof(T) + 16;  // no `aux` table; two ticket words
+            const uint64_t resident = (uint64_t)ctx->num_cus * std::max<size_t>(1, (160 * 1024) / lds_p);
+            int rcq = ensure(ctx->tickets, 64);
+            if (rcq) return rcq;
+            HIP_TRY(hipMemsetAsync(ctx->tickets.p, 0, 32, st));
+            a.tile_counters = (uint32_t *)ctx->tickets.p;
+            hipLaunchKernelGGL((k_seg_last_hash<F>), dim3((uint32_t)std::min<uint64_t>(grid, resident)), dim3(threads), lds_p, st, a);
+        } else if (d.rows_out && packed)
             hipLaunchKernelGGL((k_seg_last<F, SEG_OUT_ROWS, true>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
         else if (d.rows_out)
             hipLaunchKernelGGL((k_seg_last<F, SEG_OUT_ROWS>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
@@ -846,6 +859,7 @@ void wf_ctx_destroy(wf_ctx *ctx) {
     for (auto &b : ctx->io)
         if (b.p) (void)hipFree(b.p);
     if (ctx->hash_tmp.p) (void)hipFree(ctx->hash_tmp.p);
+    if (ctx->tickets.p) (void)hipFree(ctx->tickets.p);
     for (auto e : ctx->prof_ev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
