@@ -9,7 +9,11 @@
 //
 // Transform structure (same as kernels.hpp): N = 2^L split into digit passes; a strided pass handles the rows
 // (o, d, i), d = 0..D-1, of one inner position i; the last pass handles D contiguous rows and scatters to natural
-// order.  Inside LDS: radix-4 rounds on x[D][S], two lanes per thread (16-byte LDS accesses for f64).
+// order.  Inside LDS (x[D][S]): radix-16 rounds with the 16 values of one lane in registers (f64), then radix-4 /
+// radix-2 rounds on two lanes per thread (16-byte LDS accesses for f64); f128 uses the radix-4 / radix-2 rounds only.
+// Work-groups have D/2 threads (one work item of the widest round each).  DESIGN.md §4 describes the kernels, §9 the
+// variants that were measured and dropped; the WF_EXP_* macros switch parts off for time attribution
+// (scripts/exp_variants.sh) and are never defined in the product build.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -100,7 +104,7 @@ struct SegArgs {
     // is not read back by k_hash_rows (RowMatrix::commit_to_rows, row_matrix.rs:183-203)
     uint32_t *leaves;          // nullptr: no fused hashing
     uint32_t hash_epr;         // elements of a row that are hashed (elements_per_row)
-    uint32_t *tile_counters;         // k_seg_last_hash: 8 zeroed counters, one per XCD (dynamic tile assignment)
+    uint32_t *tile_counters;   // k_seg_last_hash: 8 zeroed counters, one per XCD (dynamic tile assignment)
 };
 
 // LDS position -> output index of seg_lds_ntt: radix-16 digits while >= 4 bits remain, then radix-4, then radix-2
