@@ -634,14 +634,21 @@ static int run_merkle(hipStream_t st, const void *leaves, uint64_t n_leaves, voi
         const uint64_t n_par = n_children >> 1;
         const uint32_t threads = 256;
         const uint64_t grid = (n_par + threads - 1) / threads;
-        if (n_par >= (1u << 16)) {  // two levels that still fill the chip: one lane per grandparent
+        // levels of >= 2^18 parents: two per launch; below that the LDS subtree kernel folds 9 levels per launch (one
+        // launch less than switching at 2^16, 5 us at 2^23 leaves).  WF_EXP_MERKLE_L2_MIN: tuning switch
+        static const uint32_t l2_min = [] {
+            const char *e = getenv("WF_EXP_MERKLE_L2_MIN");
+            const int v = e ? atoi(e) : 18;
+            return (uint32_t)(v >= 10 && v <= 30 ? v : 18);
+        }();
+        if (n_par >= ((uint64_t)1 << l2_min)) {  // two levels that still fill the chip: one lane per grandparent
             const uint64_t n_grand = n_par >> 1;
             const uint64_t blocks2 = std::min<uint64_t>((n_grand + threads - 1) / threads, 256 * 8);  // grid-stride
             hipLaunchKernelGGL(k_merkle_level2, dim3((uint32_t)blocks2), dim3(threads), 0, st,
                                children, (uint32_t *)nodes + n_par * 8, (uint32_t *)nodes + n_grand * 8, n_grand);
             HIP_TRY(hipGetLastError());
             n_children = n_grand;
-        } else if (n_par >= (1u << 15)) {  // a level that still fills the chip: one lane per node, one level per launch
+        } else if (n_par >= (1u << 15) && l2_min == 16) {  // a level that still fills the chip: one lane per node
             hipLaunchKernelGGL(k_merkle_level, dim3((uint32_t)grid), dim3(threads), 0, st, children,
                                (uint32_t *)nodes + n_par * 8, n_par);
             HIP_TRY(hipGetLastError());
