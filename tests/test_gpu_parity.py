@@ -88,6 +88,11 @@ CASES = [
     (F64, 1, 8, 1, 255, 1),    # MAX_TRACE_WIDTH columns (air/src/air/trace_info.rs:37): 32 segments, 2040-byte rows
     (F64, 1, 11, 7, 2, 1),     # blowup 128 on a two-pass transform, narrow matrix (coset-packed lanes)
     (F128, 2, 4, 1, 127, 2),   # 508 base columns per row x 2 traces: 16 KiB rows, 16 BLAKE3 chunks each
+    # one segment, one trace, two passes: leaves come from the persistent fused last pass (k_seg_last_hash)
+    (F128, 1, 12, 2, 3, 1),    # f128: 48-byte leaves out of 64-byte tile rows, LDE rows padded to 8 elements
+    (F64, 1, 12, 7, 8, 1),     # blowup 128: 128 cosets per row block
+    (F64, 1, 11, 1, 7, 1),     # blowup 2: two cosets
+    (F64, 3, 11, 3, 2, 1),     # cubic extension: 6 base columns
 ]
 
 
