@@ -1,5 +1,5 @@
 """Experiment: is the device-buffer form capturable into a HIP graph (via torch.cuda.CUDAGraph) and what does replay save?"""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import starkpack_winterfell_amd.capi as capi
