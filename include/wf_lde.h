@@ -228,6 +228,11 @@ size_t wf_fri_num_layers(uint32_t folding, uint32_t blowup, uint32_t remainder_m
  * been completed yet", prover/mod.rs:173-176) -- call wf_fri_prover_reset first. */
 int wf_fri_prover_begin(wf_fri_prover *pr, const void *evals, size_t n);
 int wf_fri_prover_begin_dev(wf_fri_prover *pr, const void *d_evals, size_t n, void *stream);
+/* The same start from the DEEP composition polynomial itself (SURVEY.md §8f-2 feeding §8f-1 without a round trip):
+ * DeepCompositionPoly::evaluate (prover/src/composer/mod.rs:198-205) = evaluate_poly_with_offset of its n coefficients
+ * (elements of E, host memory) over the LDE domain of n * lde_blowup points with the prover's domain offset; the
+ * evaluations are produced in HBM and become the first layer (prover/src/lib.rs: fri_prover.build_layers(.., evaluations)). */
+int wf_fri_prover_begin_poly(wf_fri_prover *pr, const void *poly, size_t n, size_t lde_blowup);
 /* First half of build_layer (prover/mod.rs:191-203): transpose, hash_values, MerkleTree::new; root_out = the layer's
  * root for channel.commit_fri_layer. */
 int wf_fri_prover_commit_layer(wf_fri_prover *pr, uint8_t root_out[32]);

@@ -23,7 +23,7 @@ SYMBOLS = [
     "wf_trace_commit_shard_dev", "wf_merkle_build_dev", "wf_trace_commit_resident", "wf_constraint_commit_resident", "wf_commitment_destroy", "wf_commitment_root",
     "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_prove", "wf_commitment_prove_batch",
     "wf_evaluate_columns_at", "wf_commitment_evaluate_polys_at", "wf_fri_layer_commit", "wf_fri_apply_drp", "wf_fri_layer_commit_dev", "wf_fri_apply_drp_dev",
-    "wf_fri_prover_create", "wf_fri_prover_destroy", "wf_fri_num_layers", "wf_fri_prover_begin", "wf_fri_prover_begin_dev",
+    "wf_fri_prover_create", "wf_fri_prover_destroy", "wf_fri_num_layers", "wf_fri_prover_begin", "wf_fri_prover_begin_dev", "wf_fri_prover_begin_poly",
     "wf_fri_prover_commit_layer", "wf_fri_prover_fold", "wf_fri_prover_set_remainder", "wf_fri_prover_num_layers",
     "wf_fri_prover_layer", "wf_fri_prover_reset", "wf_fri_fold_positions",
     "wf_fft_evaluate_poly", "wf_fft_evaluate_poly_with_offset", "wf_fft_interpolate_poly",
@@ -139,6 +139,7 @@ def load():
         L.wf_fri_num_layers.restype = sz
         L.wf_fri_prover_begin.argtypes = [vp, vp, sz]
         L.wf_fri_prover_begin_dev.argtypes = [vp, vp, sz, vp]
+        L.wf_fri_prover_begin_poly.argtypes = [vp, vp, sz, sz]
         L.wf_fri_prover_commit_layer.argtypes = [vp, vp]
         L.wf_fri_prover_fold.argtypes = [vp, vp]
         L.wf_fri_prover_set_remainder.argtypes = [vp, vp, sz, C.POINTER(sz), vp]
@@ -474,6 +475,12 @@ class FriProver:
         a = np.ascontiguousarray(evals, dtype=np.uint64)
         n = a.size // (self.ext * ELEM_WORDS[self.field])
         _check(load().wf_fri_prover_begin(self._h, _p(a), n))
+
+    def begin_poly(self, poly: np.ndarray, lde_blowup: int):
+        """DEEP composition polynomial (coefficients) -> its LDE evaluations on the device -> first layer."""
+        a = np.ascontiguousarray(poly, dtype=np.uint64)
+        n = a.size // (self.ext * ELEM_WORDS[self.field])
+        _check(load().wf_fri_prover_begin_poly(self._h, _p(a), n, lde_blowup))
 
     def begin_dev(self, d_ptr: int, n: int, stream: int = 0):
         _check(load().wf_fri_prover_begin_dev(self._h, d_ptr, n, stream))

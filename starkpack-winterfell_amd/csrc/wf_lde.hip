@@ -1804,6 +1804,47 @@ int wf_fri_prover_begin_dev(wf_fri_prover *pr, const void *d_evals, size_t n, vo
     return fri_prover_begin(pr, d_evals, n, true, stream ? (hipStream_t)stream : (pr ? pr->ctx->stream : nullptr));
 }
 
+int wf_fri_prover_begin_poly(wf_fri_prover *pr, const void *poly, size_t n, size_t lde_blowup) {
+    if (!pr || !poly) return fail(WF_ERR_ARG, "null argument");
+    if (!pr->layers.empty() || pr->pending || pr->evals)
+        return fail(WF_ERR_ARG, "a prior proof generation request has not been completed yet");
+    if (n < 8 || (n & (n - 1))) return fail(WF_ERR_TRACE_LENGTH, "polynomial size must be a power of two >= 8");
+    if (lde_blowup < 2 || lde_blowup > 128 || (lde_blowup & (lde_blowup - 1)))
+        return fail(WF_ERR_BLOWUP, "blowup must be a power of two in [2,128]");
+    wf_ctx *ctx = pr->ctx;
+    wf_params p;
+    memset(&p, 0, sizeof(p));
+    p.field = pr->field;
+    p.ext_degree = pr->ext;
+    while (((size_t)1 << p.log2_trace_len) < n) p.log2_trace_len++;
+    while (((size_t)1 << p.log2_blowup) < lde_blowup) p.log2_blowup++;
+    p.n_cols = 1;
+    p.n_traces = 1;
+    p.digest_bytes = 32;
+    memcpy(p.domain_offset, pr->offset, 16);
+    int rc = check_params(&p, true);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t eb = wf_elem_bytes(pr->field), rows = n * lde_blowup, rw = wf_row_width(&p);
+    if ((rc = ensure(ctx->io[0], wf_column_bytes(&p)))) return rc;
+    if ((rc = ensure(ctx->io[2], wf_lde_bytes(&p)))) return rc;
+    HIP_TRY(hipMalloc(&pr->evals, rows * pr->ext * eb));
+    hipStream_t st = ctx->stream;
+    rc = hipMemcpyAsync(ctx->io[0].p, poly, wf_column_bytes(&p), hipMemcpyHostToDevice, st) == hipSuccess ? 0 : fail(WF_ERR_HIP, "upload failed");
+    // one column of E evaluated to row-major (row width 8), then its ext_degree live lanes gathered into a dense vector
+    if (rc == 0) rc = wf_constraint_commit_dev(ctx, &p, ctx->io[0].p, ctx->io[2].p, nullptr, nullptr, st);
+    if (rc == 0 && hipMemcpy2DAsync(pr->evals, pr->ext * eb, ctx->io[2].p, rw * eb, pr->ext * eb, rows, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        rc = fail(WF_ERR_HIP, "gathering the evaluations failed");
+    if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = fail(WF_ERR_HIP, "stream synchronisation failed");
+    if (rc) {
+        (void)hipFree(pr->evals);
+        pr->evals = nullptr;
+        return rc;
+    }
+    pr->n = rows;
+    return 0;
+}
+
 int wf_fri_prover_commit_layer(wf_fri_prover *pr, uint8_t root_out[32]) {
     if (!pr || !root_out) return fail(WF_ERR_ARG, "null argument");
     if (!pr->evals) return fail(WF_ERR_ARG, "no evaluations: call wf_fri_prover_begin first");

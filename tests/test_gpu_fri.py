@@ -165,4 +165,10 @@ def test_resident_fri_prover(ctx, orc, capi, field, ext, folding, blowup, max_re
     pr.reset()
     assert pr.num_layers() == 0
     pr.begin(ev)                                         # usable again after reset
+    pr.reset()
+    # begin_poly: the polynomial's coset LDE (offset, blowup) is produced on the device and committed as layer 0
+    pr.begin_poly(low.reshape(-1), blowup)
+    lde = np.ascontiguousarray(orc.evaluate_poly_with_offset(field, low.reshape(-1), trace_len, ext,
+                                                             orc.get_twiddles(field, trace_len), off_elem, blowup))
+    assert pr.commit_layer() == orc.fri_layer_commit(field, lde, n, ext, folding)["root"]
     pr.close()

@@ -48,7 +48,7 @@ def test_prove_shaped_pipeline(ctx, orc, capi):
     want_e = orc.evaluate_poly_with_offset(F64, deep, R, ext, orc.get_twiddles(F64, R), L.orc_f64_new(offset), 1 << logB)
     assert np.array_equal(deep_evals, want_e)
     fri = capi.FriProver(ctx, F64, ext, folding, 1 << logB, max_rem, offset)
-    fri.begin(deep_evals)
+    fri.begin_poly(deep, 1 << logB)                      # the evaluations never leave the device
     cur, size, want_layers = deep_evals, N, []
     for i in range(capi.fri_num_layers(folding, 1 << logB, max_rem, N)):
         want = orc.fri_layer_commit(F64, cur, size, ext, folding)
