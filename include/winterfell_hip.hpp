@@ -447,9 +447,22 @@ class FriProver {
     template <class Channel>
     void build_layers(Channel &channel, const std::vector<E> &evaluations) {
         wf_check(wf_fri_prover_begin(h_, evaluations.data(), evaluations.size()));
-        domain_size_ = evaluations.size();
-        const size_t layers = options_.num_fri_layers(evaluations.size());
-        size_t size = evaluations.size();
+        run_layers(channel, evaluations.size());
+    }
+    // the same, starting from the DEEP composition polynomial (composer/mod.rs:198-205): its evaluations over the LDE
+    // domain are produced on the GPU and never visit the host
+    template <class Channel>
+    void build_layers_from_poly(Channel &channel, const std::vector<E> &coefficients, size_t lde_blowup) {
+        wf_check(wf_fri_prover_begin_poly(h_, coefficients.data(), coefficients.size(), lde_blowup));
+        run_layers(channel, coefficients.size() * lde_blowup);
+    }
+
+  private:
+    template <class Channel>
+    void run_layers(Channel &channel, size_t n_evaluations) {
+        domain_size_ = n_evaluations;
+        const size_t layers = options_.num_fri_layers(n_evaluations);
+        size_t size = n_evaluations;
         for (size_t i = 0; i < layers; i++) {
             Digest root;
             wf_check(wf_fri_prover_commit_layer(h_, root.data()));
@@ -466,6 +479,7 @@ class FriProver {
         channel.commit_fri_layer(commitment);
     }
 
+  public:
     // build_proof (prover/mod.rs:244-282): every layer queried at the folded positions; resets the prover like the reference
     std::pair<std::vector<FriProofLayer>, std::vector<E>> build_proof(const std::vector<size_t> &positions) {
         if (remainder_.empty()) throw std::logic_error("FRI layers have not been built yet");

@@ -323,6 +323,21 @@ static void fri_prover_resident() {
         domain = target;
     }
     EXPECT(layers[0].positions.size() == 4);  // 1029 folds onto 5 and 77 + 512 onto 77 in the 512-row layer
+
+    // the DEEP-polynomial entry: coefficients in, coset LDE on the device; first layer root against the oracle
+    std::vector<F64Element> coeffs(evaluations.begin(), evaluations.begin() + trace_length);
+    for (size_t i = 0; i < trace_length; i++) coeffs[i].inner = orc_f64_new(3 * i + 1);
+    TestChannel ch2;
+    fri.build_layers_from_poly(ch2, coeffs, blowup);
+    std::vector<uint64_t> ttw(trace_length / 2), lde(n), tr0(n);
+    EXPECT(orc_f64_get_twiddles(ttw.data(), trace_length, 0) == 0);
+    orc_f64_evaluate_poly_with_offset(reinterpret_cast<const uint64_t *>(coeffs.data()), trace_length, 1, ttw.data(),
+                                      orc_f64_new(7), blowup, lde.data());
+    orc_transpose_slice(ORC_FIELD_F64, lde.data(), n, 1, folding, tr0.data());
+    std::vector<Digest> l0(n / folding), n0(n / folding);
+    for (size_t i = 0; i < n / folding; i++) orc_hash_elements(ORC_FIELD_F64, &tr0[i * folding], folding, l0[i].data());
+    EXPECT(orc_build_merkle_nodes(l0[0].data(), n / folding, n0[0].data(), 1) == 0);
+    EXPECT(n0[1] == ch2.layer_commitments[0]);
     std::printf("fri_prover_resident ok\n");
 }
 
