@@ -134,6 +134,43 @@ __global__ void __launch_bounds__(256) k_l2_compute_only(uint32_t *__restrict__ 
     }
 }
 
+// three levels per launch: lane i reads eight children (256 contiguous bytes) in two halves
+__global__ void __launch_bounds__(256) k_l3(const uint32_t *__restrict__ children, uint32_t *__restrict__ l1,
+                                            uint32_t *__restrict__ l2, uint32_t *__restrict__ l3, uint64_t n3) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t top[16];
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(children + (2 * i + half) * 32);
+            uint32_t m[16], cv[8], g[16];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                uint4 q[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) q[j] = src[4 * h + j];
+                unpack(q, m);
+                b3::merge(m, cv);
+                uint4 *dst = reinterpret_cast<uint4 *>(l1 + (4 * i + 2 * half + h) * 8);
+                dst[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+                dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+#pragma unroll
+                for (int k = 0; k < 8; k++) g[8 * h + k] = cv[k];
+            }
+            b3::merge(g, cv);
+            uint4 *dg = reinterpret_cast<uint4 *>(l2 + (2 * i + half) * 8);
+            dg[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+            dg[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+#pragma unroll
+            for (int k = 0; k < 8; k++) top[8 * half + k] = cv[k];
+        }
+        uint32_t cv[8];
+        b3::merge(top, cv);
+        uint4 *dt = reinterpret_cast<uint4 *>(l3 + i * 8);
+        dt[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+        dt[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+    }
+}
+
 template <class K>
 static float timeit(K launch, int reps) {
     hipEvent_t e0, e1;
@@ -185,6 +222,16 @@ int main() {
         ms = timeit([&] { hipLaunchKernelGGL(k_l2_compute_only, dim3(blocks), dim3(256), 0, 0, nodes2 + n_grand * 8, n_grand); }, 10);
         snprintf(nm, sizeof nm, "compute only, %u blocks", blocks);
         report(nm, ms);
+    }
+    for (uint32_t blocks : {1024u, 2048u, 4096u}) {
+        const uint64_t n3 = n_grand / 2;
+        float ms = timeit([&] { hipLaunchKernelGGL(k_l3, dim3(blocks), dim3(256), 0, 0, leaves, nodes2 + n_par * 8, nodes2 + n_grand * 8, nodes2 + n3 * 8, n3); }, 10);
+        printf("three levels per launch, %u blocks             %7.3f ms  %6.2f Gcompress/s (7 per lane)\n", blocks, ms, 7.0 * n3 / ms / 1e6);
+        // reference: two launches of the product kernel covering the same three levels
+        float ms2 = timeit([&] {
+            hipLaunchKernelGGL(k_merkle_level2, dim3(2048), dim3(256), 0, 0, leaves, nodes + n_par * 8, nodes + n_grand * 8, n_grand);
+            hipLaunchKernelGGL(k_merkle_level, dim3((uint32_t)(n3 / 256)), dim3(256), 0, 0, nodes + n_grand * 8, nodes + n3 * 8, n3); }, 10);
+        printf("   product: level2 + level for the same levels  %7.3f ms\n", ms2);
     }
     {
         float ms = timeit([&] { hipLaunchKernelGGL(k_l2_upfront<false>, dim3((uint32_t)(n_grand / 256)), dim3(256), 0, 0, leaves, nodes2 + n_par * 8, nodes2 + n_grand * 8, n_grand); }, 10);
