@@ -69,6 +69,11 @@ __device__ __forceinline__ uint64_t xcd_group_index(uint64_t b, uint64_t total) 
 #endif
 }
 
+// Tile indices are decoded with shifts where a factor is a power of two (I and O always are) and with 32-bit divisions
+// otherwise (grids are below 2^31): a 64-bit division by a run-time value costs ~80 VALU instructions on this target,
+// and the prologue of a tile is paid by every thread.
+__device__ __forceinline__ uint32_t ilog2_pow2(uint64_t v) { return 63u - (uint32_t)__builtin_clzll(v); }
+
 template <class F>
 struct SegArgs {
     typedef typename F::T T;
@@ -337,12 +342,11 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
     T *aux = twd + D;  // coset factors of the input rows, later the inter-pass twiddles of the output rows
 
     uint64_t bid = xcd_group_index(blockIdx.x, gridDim.x);  // neighbouring i on one XCD
-    const uint64_t i = bid % a.I;
-    bid /= a.I;
-    const uint64_t o = bid % a.O;
-    bid /= a.O;
-    const uint32_t g = (uint32_t)(bid % a.n_seg);
-    const uint32_t c = (uint32_t)(bid / a.n_seg);
+    const uint32_t logI = ilog2_pow2(a.I), logO = ilog2_pow2(a.O);
+    const uint64_t i = bid & (a.I - 1);
+    const uint64_t o = (bid >> logI) & (a.O - 1);
+    const uint32_t rest = (uint32_t)(bid >> (logI + logO));
+    const uint32_t c = rest / a.n_seg, g = rest - c * a.n_seg;
     const uint64_t seg_elems = ((uint64_t)1 << a.logN) * S;
     const T *src = a.src + (a.src_shared ? (uint64_t)g : (uint64_t)c * a.n_seg + g) * seg_elems;
     T *dst = a.dst + ((uint64_t)c * a.n_seg + g) * seg_elems;
@@ -366,7 +370,7 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
         pre.hi += (uint64_t)(a.coset0 + c) * a.pre_hi_stride;
     }
     const uint32_t nitems = D * HP;
-    const uint64_t row0 = o * D * a.I + i;  // row index of d = 0; rows of this group are I apart
+    const uint64_t row0 = ((o << a.logD) << logI) + i;  // row index of d = 0; rows of this group are I apart
     // The first LOAD_BATCH row pieces of every thread (the whole tile up to D = 2^10) are requested before the tables
     // are built, so that their latency runs under the table arithmetic.  The rows are I apart: every load is its own
     // 64-byte gather, the load phase lives on memory-level parallelism.
@@ -378,7 +382,7 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
     // twiddles, the operands of the input factors h_c^(d*I), then the tile's first LOAD_BATCH row pieces per thread (all
     // of them up to D = 2^10).  Branch-free with clamped indices (blockDim >= D/2: at most two table entries per
     // thread); the output factors wait in registers until the input factors in `aux` have been consumed.
-    const uint32_t tw_shift = a.logN - a.logD - (63 - __builtin_clzll(a.I));
+    const uint32_t tw_shift = a.logN - a.logD - logI;
     const bool scale_in = !PACKED && a.pre_on;
     const Pow2L<F> pin = scale_in ? pre : a.tw;  // without input scaling the reads go to the root table and are dropped
     uint32_t kq[2];
@@ -389,7 +393,7 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
         kq[q] = k < D ? k : D - 1;
         a.tw.fetch(((uint64_t)kq[q] * i) << tw_shift, fo_a[q], fo_b[q]);
         tw_q[q] = a.digit_tw[kq[q]];
-        pin.fetch((uint64_t)kq[q] * a.I, fi_a[q], fi_b[q]);
+        pin.fetch((uint64_t)kq[q] << logI, fi_a[q], fi_b[q]);
     }
     // `direct`: the 16 inputs of this thread's first radix-16 work item come straight from global memory into registers
     // (lane threadIdx % S of rows a * D/16 + threadIdx / S), the tile makes no trip through LDS before the first round
@@ -400,13 +404,18 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
     P2 v0[LB];
     if (direct) {
         if (has16) {
+            // sixteen rows m16 * I apart: one address, then a running 64-bit add per row
+            const T *pr = src + (row0 + ((uint64_t)j16 << logI)) * S + l16;
+            const uint64_t rstep = ((uint64_t)m16 << logI) * S;
 #pragma unroll
-            for (uint32_t q = 0; q < 16; q++)
+            for (uint32_t q = 0; q < 16; q++) {
 #ifdef WF_EXP_SKIP_LOAD
                 vr[q] = src[l16];
 #else
-                vr[q] = src[(row0 + (uint64_t)(q * m16 + j16) * a.I) * S + l16];
+                vr[q] = *pr;
 #endif
+                pr += rstep;
+            }
         }
     } else if (from_regs) {
 #pragma unroll
@@ -416,7 +425,7 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
 #ifdef WF_EXP_SKIP_LOAD
                 v0[u] = *reinterpret_cast<const P2 *>(src + 2 * (wk & (HP - 1)));
 #else
-                v0[u] = *reinterpret_cast<const P2 *>(src + (row0 + (uint64_t)(wk >> hp_shift) * a.I) * S + 2 * (wk & (HP - 1)));
+                v0[u] = *reinterpret_cast<const P2 *>(src + (row0 + ((uint64_t)(wk >> hp_shift) << logI)) * S + 2 * (wk & (HP - 1)));
 #endif
         }
     }
@@ -448,9 +457,9 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
             const uint32_t lp = wk & (HP - 1), d = wk >> hp_shift;
             P2 v;
             const uint32_t lgm = (1u << a.lg_log) - 1, cola = lane_a & lgm, colb = lane_b & lgm;
-            const T *srow = src + (row0 + (uint64_t)d * a.I) * S;
-            v.a = act_a ? F::mul(srow[cola], pre_a.get((uint64_t)d * a.I)) : F::zero();
-            v.b = act_b ? F::mul(srow[colb], pre_b.get((uint64_t)d * a.I)) : F::zero();
+            const T *srow = src + (row0 + ((uint64_t)d << logI)) * S;
+            v.a = act_a ? F::mul(srow[cola], pre_a.get((uint64_t)d << logI)) : F::zero();
+            v.b = act_b ? F::mul(srow[colb], pre_b.get((uint64_t)d << logI)) : F::zero();
             *reinterpret_cast<P2 *>(x + d * S + 2 * lp) = v;
         }
     } else {
@@ -462,7 +471,7 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
                 if (wk0 == threadIdx.x)
                     v[u] = v0[u];
                 else if (wk < nitems)
-                    v[u] = *reinterpret_cast<const P2 *>(src + (row0 + (uint64_t)(wk >> hp_shift) * a.I) * S + 2 * (wk & (HP - 1)));
+                    v[u] = *reinterpret_cast<const P2 *>(src + (row0 + ((uint64_t)(wk >> hp_shift) << logI)) * S + 2 * (wk & (HP - 1)));
             }
 #pragma unroll
             for (uint32_t u = 0; u < LB; u++) {
@@ -506,7 +515,7 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
     if (pos0 >= D) return;
     const uint32_t k0 = seg_digit_reverse<F>(pos0, a.logD);
     T *dst_lane = dst + row0 * S + lane_a;
-    const uint64_t k_stride = a.I * S;
+    const uint64_t k_stride = (uint64_t)S << logI;
     for (uint32_t pj = 0; pj < D; pj += pstride) {
         const uint32_t k = k0 | seg_digit_reverse<F>(pj, a.logD);
         P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
@@ -540,12 +549,13 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
 
     // coset fastest: with SEG_OUT_ROWS the cosets of one row block write the 64-byte pieces of the same rows
     uint64_t bid = xcd_group_index(blockIdx.x, gridDim.x);
-    const uint32_t c = (uint32_t)(bid % a.n_cosets);
-    bid /= a.n_cosets;
-    const uint64_t o = bid % a.O;
-    const uint32_t g = (uint32_t)(bid / a.O);
+    const uint32_t logO = ilog2_pow2(a.O);
+    const uint32_t b32 = (uint32_t)bid;  // grids are below 2^31
+    const uint32_t q32 = b32 / a.n_cosets, c = b32 - q32 * a.n_cosets;
+    const uint64_t o = q32 & (uint32_t)(a.O - 1);
+    const uint32_t g = q32 >> logO;
     const uint64_t seg_elems = ((uint64_t)1 << a.logN) * S;
-    const T *src = a.src + (a.src_shared ? (uint64_t)g : (uint64_t)c * a.n_seg + g) * seg_elems + o * D * S;
+    const T *src = a.src + (a.src_shared ? (uint64_t)g : (uint64_t)c * a.n_seg + g) * seg_elems + (o << a.logD) * S;
 
     // natural-order contribution of the earlier digits: o = (k1, k2, ..), k1 most significant -> k1 + N1*k2 + ..
     uint64_t rev_o = 0;
@@ -781,8 +791,9 @@ __global__ void __launch_bounds__(1024) k_seg_last_hash(SegArgs<F> a) {
 
     auto tile_src = [&](uint64_t t, uint32_t &c, uint64_t &rev_o) -> const T * {
         uint64_t bid = xcd_group_index(t, total);  // coset fastest, 8 consecutive tiles on one XCD
-        c = (uint32_t)(bid % a.n_cosets);
-        const uint64_t o = bid / a.n_cosets;
+        const uint32_t b32 = (uint32_t)bid, q32 = b32 / a.n_cosets;  // grids are below 2^31
+        c = b32 - q32 * a.n_cosets;
+        const uint64_t o = q32;
         rev_o = 0;
         uint32_t bits = 0;
         for (uint32_t q = 0; q < a.n_prev; q++) bits += a.prev_log[q];
@@ -792,7 +803,7 @@ __global__ void __launch_bounds__(1024) k_seg_last_hash(SegArgs<F> a) {
             rev_o |= ((o >> hi) & (((uint64_t)1 << a.prev_log[q]) - 1)) << sh;
             sh += a.prev_log[q];
         }
-        return a.src + (uint64_t)c * seg_elems + o * D * S;
+        return a.src + (uint64_t)c * seg_elems + (o << a.logD) * S;
     };
 
     // Tiles are handed out dynamically, per XCD (work-groups are dispatched to XCD blockIdx % 8): tile = 8 * ticket + xcd,
