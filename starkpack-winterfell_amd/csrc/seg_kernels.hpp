@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
     if (pos0 >= D) return;
     const uint32_t k0 = seg_digit_reverse<F>(pos0, a.logD);
     T *dst_lane = dst + row0 * S + lane_a;
-    const uint64_t k_stride = (uint64_t)S << logI;
+    const uint32_t k_shift = logI + (S == 8 ? 3 : 2);  // rows k of the output are I apart: element offset k * I * S
     for (uint32_t pj = 0; pj < D; pj += pstride) {
         const uint32_t k = k0 | seg_digit_reverse<F>(pj, a.logD);
         P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
@@ -529,7 +529,7 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
 #ifdef WF_EXP_SKIP_STORE
         if (*reinterpret_cast<const uint32_t *>(&v.a) == a.logN + 77777u)
 #endif
-        store_pair(dst_lane + (uint64_t)k * k_stride, v);
+        store_pair(dst_lane + ((uint64_t)k << k_shift), v);
     }
 }
 
@@ -686,7 +686,7 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
         }
     } else {
         // destination of each lane for k = 0: dst + trace * trace_elems + (coset) * row_width + column
-        const uint64_t k_stride = (uint64_t)a.rows_per_k * a.row_width;  // elements between consecutive k
+        const uint32_t k_stride = a.rows_per_k * (uint32_t)a.row_width;  // elements between consecutive k (< 2^19)
         T *pa = nullptr, *pb = nullptr;
         bool pair_store = false;
         if (PACKED) {
@@ -717,7 +717,7 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
         for (uint32_t pj = 0; (pa || pb) && pj < D; pj += pstride) {
             const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, a.logD)) << out_shift);
             const P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
-            const uint64_t off = k * k_stride;
+            const uint64_t off = (uint64_t)(uint32_t)k * k_stride;  // k < 2^32 rows: one 32 x 32 -> 64 multiply
             if (pair_store) {
 #ifdef WF_EXP_SKIP_STORE
                 if (*reinterpret_cast<const uint32_t *>(&v.a) == a.logN + 77777u)
@@ -747,7 +747,7 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
             b3::set_iv(out);
             b3::compress(out, m, 0, 0, a.hash_epr * F::BYTES, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT);
             const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << (a.logN - a.logD));
-            uint4 *dl = reinterpret_cast<uint4 *>(a.leaves + (k * a.rows_per_k + c) * 8);
+            uint4 *dl = reinterpret_cast<uint4 *>(a.leaves + ((uint64_t)(uint32_t)k * a.rows_per_k + c) * 8);
             dl[0] = make_uint4(out[0], out[1], out[2], out[3]);
             dl[1] = make_uint4(out[4], out[5], out[6], out[7]);
         }
@@ -785,7 +785,7 @@ __global__ void __launch_bounds__(1024) k_seg_last_hash(SegArgs<F> a) {
     const uint64_t seg_elems = ((uint64_t)1 << a.logN) * S;
     const uint32_t step = blockDim.x;
     const uint32_t out_shift = a.logN - a.logD;
-    const uint64_t k_stride = (uint64_t)a.rows_per_k * a.row_width;
+    const uint32_t k_stride = a.rows_per_k * (uint32_t)a.row_width;  // < 2^19
 
     for (uint32_t e = threadIdx.x; e < D; e += step) twd[e] = a.digit_tw[e];
 
@@ -868,9 +868,9 @@ __global__ void __launch_bounds__(1024) k_seg_last_hash(SegArgs<F> a) {
                     const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, a.logD)) << out_shift);
                     const P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
                     if (pair)
-                        store_pair(pa + k * k_stride, v);
+                        store_pair(pa + (uint64_t)(uint32_t)k * k_stride, v);
                     else
-                        pa[k * k_stride] = v.a;
+                        pa[(uint64_t)(uint32_t)k * k_stride] = v.a;
                 }
             }
         }
@@ -901,7 +901,7 @@ __global__ void __launch_bounds__(1024) k_seg_last_hash(SegArgs<F> a) {
                 b3::set_iv(out);
                 b3::compress(out, m, 0, 0, a.hash_epr * F::BYTES, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT);
                 const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << out_shift);
-                uint4 *dl = reinterpret_cast<uint4 *>(a.leaves + (k * a.rows_per_k + c) * 8);
+                uint4 *dl = reinterpret_cast<uint4 *>(a.leaves + ((uint64_t)(uint32_t)k * a.rows_per_k + c) * 8);
                 dl[0] = make_uint4(out[0], out[1], out[2], out[3]);
                 dl[1] = make_uint4(out[4], out[5], out[6], out[7]);
             }
