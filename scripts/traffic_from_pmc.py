@@ -18,7 +18,7 @@ import sys
 
 LOGICAL = [
     ("interpolate", ["k_cols_to_seg", "k_seg_strided<wf::F64, 0,", "k_seg_last<wf::F64, 0,", "k_seg_to_cols"]),
-    ("evaluate", ["k_seg_strided<wf::F64, 1,", "k_seg_last<wf::F64, 1,", "k_seg_last_hash<wf::F64>"]),
+    ("evaluate", ["k_seg_strided<wf::F64, 1,", "k_seg_last<wf::F64, 1,", "k_seg_last_hash<wf::F64,"]),
     ("hash_rows", ["k_hash_rows"]),
     ("merkle", ["k_merkle_level", "k_merkle_subtree"])  # k_merkle_level also matches k_merkle_level2,
 ]

@@ -755,12 +755,16 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Last pass of a multi-pass evaluation of ONE segment of ONE trace with fused leaf hashing (the bench workload), as a
-// PERSISTENT kernel: the grid is one resident set of work-groups, each takes tiles from a per-XCD ticket counter until
-// they run out (every work-group reaches that exit); the rows of its next tile are requested right after the row stores
-// of the current one and arrive while the lanes hash the leaves -- the only stretch of the tile loop that has 32 VGPRs
-// to spare (the transform itself needs ~80 of the 128 that two resident work-groups per CU allow).  Same tiles,
-// arithmetic and outputs as k_seg_last<F, ROWS>; a static tile walk (t += gridDim) measured 10 % slower than the
+// Last pass of a multi-pass evaluation with fused leaf hashing, as a PERSISTENT kernel, for matrices whose combined row
+// (all base columns of all traces, RowMatrix::commit_to_comb_rows, row_matrix.rs:204-238) is at most one BLAKE3 chunk:
+// n_seg <= 16 segments.  Segment g of a row IS the g-th 64-byte block of the hashed message (base columns are packed
+// into segments in concatenation order), so a work-group that walks over the n_seg tiles of one (coset, row block)
+// keeps the chaining values of its rows in registers and compresses one block per tile; the LDE is never read back.
+// The grid is one resident set of work-groups; each takes (coset, row block) tickets from a per-XCD counter until they
+// run out (every work-group reaches that exit); the rows of its next tile are requested right after the row stores of
+// the current one and arrive while the lanes hash -- the only stretch of the tile loop that has 32 VGPRs to spare (the
+// transform itself needs ~80 of the 128 that two resident work-groups per CU allow).  Same tiles, arithmetic and
+// outputs as k_seg_last<F, ROWS> + k_hash_rows; a static tile walk (t += gridDim) measured 10 % slower than the
 // one-tile-per-work-group kernel, the dynamic one 5 % faster.
 __device__ __forceinline__ uint32_t opaque_tid() {
     // everything derived from the thread index is recomputed inside every iteration of the tile loop from this opaque
@@ -770,8 +774,9 @@ __device__ __forceinline__ uint32_t opaque_tid() {
     return t;
 }
 
-template <class F>
-__global__ void __launch_bounds__(1024) k_seg_last_hash(SegArgs<F> a) {
+// MULTI = false: one segment of one trace (the bench workload) -- no chaining values to carry, one lane pair mapping.
+template <class F, bool MULTI>
+__global__ void __launch_bounds__(F::BYTES == 8 ? 1024 : 512) k_seg_last_hash(SegArgs<F> a) {  // f128 tiles: D <= 2^10
     typedef typename F::T T;
     typedef Pair<T> P2;
     constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;
@@ -781,19 +786,20 @@ __global__ void __launch_bounds__(1024) k_seg_last_hash(SegArgs<F> a) {
     const uint32_t D = 1u << a.logD;
     T *x = reinterpret_cast<T *>(smem_raw);
     T *twd = x + (size_t)D * S;
-    const uint64_t total = (uint64_t)a.n_cosets * a.O;  // n_seg == 1
+    const uint64_t total = (uint64_t)a.n_cosets * a.O;  // tickets: (coset, row block)
     const uint64_t seg_elems = ((uint64_t)1 << a.logN) * S;
     const uint32_t step = blockDim.x;
     const uint32_t out_shift = a.logN - a.logD;
     const uint32_t k_stride = a.rows_per_k * (uint32_t)a.row_width;  // < 2^19
+    const uint32_t hash_bytes = a.hash_epr * F::BYTES;             // <= 1024: one chunk
 
     for (uint32_t e = threadIdx.x; e < D; e += step) twd[e] = a.digit_tw[e];
 
-    auto tile_src = [&](uint64_t t, uint32_t &c, uint64_t &rev_o) -> const T * {
-        uint64_t bid = xcd_group_index(t, total);  // coset fastest, 8 consecutive tiles on one XCD
+    auto decode = [&](uint64_t t, uint32_t &c, uint64_t &o, uint64_t &rev_o) {
+        uint64_t bid = xcd_group_index(t, total);  // coset fastest, 8 consecutive tickets on one XCD
         const uint32_t b32 = (uint32_t)bid, q32 = b32 / a.n_cosets;  // grids are below 2^31
         c = b32 - q32 * a.n_cosets;
-        const uint64_t o = q32;
+        o = q32;
         rev_o = 0;
         uint32_t bits = 0;
         for (uint32_t q = 0; q < a.n_prev; q++) bits += a.prev_log[q];
@@ -803,12 +809,14 @@ __global__ void __launch_bounds__(1024) k_seg_last_hash(SegArgs<F> a) {
             rev_o |= ((o >> hi) & (((uint64_t)1 << a.prev_log[q]) - 1)) << sh;
             sh += a.prev_log[q];
         }
-        return a.src + (uint64_t)c * seg_elems + (o << a.logD) * S;
+    };
+    auto tile_src = [&](uint32_t c, uint64_t o, uint32_t g) -> const T * {
+        return a.src + ((uint64_t)c * a.n_seg + g) * seg_elems + (o << a.logD) * S;
     };
 
-    // Tiles are handed out dynamically, per XCD (work-groups are dispatched to XCD blockIdx % 8): tile = 8 * ticket + xcd,
-    // so that the tile order within an XCD -- 8 consecutive tiles = the cosets of one row block -- is kept and a slow
-    // work-group does not hold back a fixed share of the tiles.  total is a multiple of 8 (8 cosets or more).
+    // Tickets are handed out dynamically, per XCD (work-groups are dispatched to XCD blockIdx % 8): ticket index =
+    // 8 * n + xcd, so that the order within an XCD -- 8 consecutive tickets = the cosets of one row block -- is kept and
+    // a slow work-group does not hold back a fixed share of the work.  total is a multiple of 8.
     uint32_t *ticket_sh = reinterpret_cast<uint32_t *>(twd + D);  // two words behind the twiddles (dynamic LDS)
     const uint32_t xcd = blockIdx.x & 7;
     const uint64_t per_xcd = total >> 3;
@@ -819,14 +827,15 @@ __global__ void __launch_bounds__(1024) k_seg_last_hash(SegArgs<F> a) {
     };
     uint64_t ticket = next_ticket(0);
     if (ticket >= per_xcd) return;
-    uint64_t t = ticket * 8 + xcd;
-    uint32_t c;
-    uint64_t rev_o;
-    const T *src = tile_src(t, c, rev_o);
+    uint32_t c, g = 0;  // g stays 0 without MULTI
+    uint64_t o, rev_o;
+    decode(ticket * 8 + xcd, c, o, rev_o);
+    const T *src = tile_src(c, o, 0);
     // blockDim == D / 2 (the launcher guarantees it): the tile is one contiguous run of 4 * D 16-byte chunks (a row is 64
-    // bytes for either field), eight per thread, copied to the same offsets of `x`.  Eight native vector registers
-    // rather than an array or a struct: carried around the tile loop those would live in scratch memory.
+    // bytes for either field), eight per thread, copied to the same offsets of `x`.  Native vector registers rather
+    // than arrays or structs for everything carried around the tile loop: those would live in scratch memory.
     uint4 q0, q1, q2, q3, q4, q5, q6, q7;
+    uint4 cva0 = make_uint4(0, 0, 0, 0), cva1 = cva0, cvb0 = cva0, cvb1 = cva0;  // chaining values of this lane's two rows
 #define WF_TILE_LOAD(SRC, TID)                                      \
     do {                                                            \
         const uint4 *s_ = reinterpret_cast<const uint4 *>(SRC) + (TID); \
@@ -856,60 +865,105 @@ __global__ void __launch_bounds__(1024) k_seg_last_hash(SegArgs<F> a) {
         __syncthreads();
         seg_lds_ntt<F, 1>(x, twd, a.logD);
 
-        // row stores: lane pair (2l, 2l+1) of row position pos -> 16-byte piece of LDE row k * rows_per_k + c
+        // row stores: lane pair (2l, 2l+1) of row position pos -> its place in LDE row k * rows_per_k + c of its trace
         {
             const uint32_t tid = opaque_tid();
             const uint32_t pstride = step >> hp_shift, pos0 = tid >> hp_shift, lane_a = 2 * (tid & (HP - 1));
-            if (pos0 < D && lane_a < a.base_cols) {
+            const uint32_t B = g * S + lane_a;  // global base column of lane a
+            T *pa = nullptr, *pb = nullptr;
+            bool pair = false;
+            if (!MULTI) {
+                if (pos0 < D && lane_a < a.base_cols) {
+                    pa = a.dst + (uint64_t)c * a.row_width + lane_a;
+                    pair = lane_a + 1 < a.base_cols;
+                }
+            } else if (pos0 < D && B < a.total_base_cols) {
+                const uint32_t t0 = B / a.base_cols, c0 = B - t0 * a.base_cols;
+                pa = a.dst + (uint64_t)t0 * a.trace_lde_elems + (uint64_t)c * a.row_width + c0;
+                pair = c0 + 1 < a.base_cols && (c0 & 1) == 0;  // both lanes in one trace, 16-byte aligned
+                if (B + 1 < a.total_base_cols) {
+                    const uint32_t t1 = (B + 1) / a.base_cols, c1 = (B + 1) - t1 * a.base_cols;
+                    pb = a.dst + (uint64_t)t1 * a.trace_lde_elems + (uint64_t)c * a.row_width + c1;
+                }
+            }
+            if (pa) {
                 const uint32_t k0 = seg_digit_reverse<F>(pos0, a.logD);
-                T *pa = a.dst + (uint64_t)c * a.row_width + lane_a;
-                const bool pair = lane_a + 1 < a.base_cols;
                 for (uint32_t pj = 0; pj < D; pj += pstride) {
                     const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, a.logD)) << out_shift);
                     const P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
-                    if (pair)
-                        store_pair(pa + (uint64_t)(uint32_t)k * k_stride, v);
-                    else
-                        pa[(uint64_t)(uint32_t)k * k_stride] = v.a;
+                    const uint64_t off = (uint64_t)(uint32_t)k * k_stride;
+                    if (pair) {
+                        store_pair(pa + off, v);
+                    } else {
+                        pa[off] = v.a;
+                        if (pb) pb[off] = v.b;
+                    }
                 }
             }
         }
 
-        // the next tile's rows start their way into registers; they land while the leaves are hashed
-        ticket = next_ticket(1);  // (barrier: every lane has read its rows of `x` for the stores above)
-        const uint64_t tn = ticket * 8 + xcd;
-        const bool more = ticket < per_xcd;
-        uint32_t cn = c;
-        uint64_t rev_on = rev_o;
+        // the next tile -- the next segment of this row block, or the first one of a new ticket -- starts its way into
+        // registers; it lands while the leaves are hashed
+        bool more = true;
+        uint32_t cn = c, gn = g + 1;
+        uint64_t on = o, rev_on = rev_o;
+        if (!MULTI || gn == a.n_seg) {
+            gn = 0;
+            ticket = next_ticket(1);
+            more = ticket < per_xcd;
+            if (more) decode(ticket * 8 + xcd, cn, on, rev_on);
+        }
         if (more) {
-            src = tile_src(tn, cn, rev_on);
+            src = tile_src(cn, on, gn);
             WF_TILE_LOAD(src, opaque_tid());
         }
 
-        // leaves: one lane per row position (blockDim >= D/2: at most two rows per thread), see k_seg_last
+        // block g of the rows' messages: one lane per row position, two rows per lane (tid and tid + D/2); the S lanes
+        // of a tile row are its 64 message bytes (lanes past the last column are zero), canonical as in hash_elements
         {
             const uint32_t tid = opaque_tid();
-            for (uint32_t pos = tid; pos < D; pos += step) {
+            const bool last = !MULTI || g + 1 == a.n_seg;
+            const uint32_t flags = (g == 0 ? (uint32_t)b3::CHUNK_START : 0u) | (last ? (uint32_t)(b3::CHUNK_END | b3::ROOT) : 0u);
+            const uint32_t blen = last ? hash_bytes - 64u * g : 64u;
+#pragma unroll 1  // one compression in flight: interleaving the two rows measured slower (and doubles the code)
+            for (uint32_t r = 0; r < 2; r++) {
+                const uint32_t pos = tid + r * step;
                 T ev[S];
                 uint4 *evq = reinterpret_cast<uint4 *>(ev);
                 const uint4 *q = reinterpret_cast<const uint4 *>(x + (size_t)pos * S);
 #pragma unroll
                 for (uint32_t w = 0; w < 4; w++) evq[w] = q[w];
-                uint32_t m[16], out[8];
+                uint32_t m[16], cv[8];
 #pragma unroll
                 for (uint32_t e = 0; e < S; e++) elem_words<F>(ev[e], &m[e * WPE]);
-                b3::set_iv(out);
-                b3::compress(out, m, 0, 0, a.hash_epr * F::BYTES, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT);
-                const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << out_shift);
-                uint4 *dl = reinterpret_cast<uint4 *>(a.leaves + ((uint64_t)(uint32_t)k * a.rows_per_k + c) * 8);
-                dl[0] = make_uint4(out[0], out[1], out[2], out[3]);
-                dl[1] = make_uint4(out[4], out[5], out[6], out[7]);
+                if (!MULTI || g == 0) {
+                    b3::set_iv(cv);
+                } else {
+                    const uint4 lo = r == 0 ? cva0 : cvb0, hi = r == 0 ? cva1 : cvb1;
+                    cv[0] = lo.x; cv[1] = lo.y; cv[2] = lo.z; cv[3] = lo.w;
+                    cv[4] = hi.x; cv[5] = hi.y; cv[6] = hi.z; cv[7] = hi.w;
+                }
+                b3::compress(cv, m, 0, 0, blen, flags);
+                const uint4 lo = make_uint4(cv[0], cv[1], cv[2], cv[3]), hi = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+                if (last) {
+                    const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << out_shift);
+                    uint4 *dl = reinterpret_cast<uint4 *>(a.leaves + ((uint64_t)(uint32_t)k * a.rows_per_k + c) * 8);
+                    dl[0] = lo;
+                    dl[1] = hi;
+                } else if (r == 0) {
+                    cva0 = lo;
+                    cva1 = hi;
+                } else {
+                    cvb0 = lo;
+                    cvb1 = hi;
+                }
             }
         }
         if (!more) break;
         __syncthreads();  // x is rewritten by the next tile
-        t = tn;
         c = cn;
+        g = MULTI ? gn : 0;
+        o = on;
         rev_o = rev_on;
     }
 }

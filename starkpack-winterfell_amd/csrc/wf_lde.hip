@@ -535,31 +535,42 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         a.pre_on = (single && d.rows_out) ? 1 : 0;
         a.scale_on = (single && !d.rows_out) ? 1 : 0;
         a.scale = inv_n;
-        // leaf hashing rides on the last pass when a tile row is a whole matrix row of one trace (<= 64 bytes)
-        const bool fuse = d.rows_out && d.leaves && !packed && d.n_seg == 1 && d.total_base_cols == d.base_cols &&
-                          getenv("WF_EXP_NO_FUSED_HASH") == nullptr;
-        a.leaves = fuse ? (uint32_t *)d.leaves : nullptr;
-        a.hash_epr = d.hash_epr;
-        if (d.fused) *d.fused = fuse;
+        // Leaf hashing rides on the last pass
+        //  - in the persistent kernel k_seg_last_hash when the combined row of all traces is at most one BLAKE3 chunk
+        //    (<= 16 segments) and the plan has several passes,
+        //  - else in k_seg_last itself when a tile row is a whole matrix row of one trace (one segment),
+        //  - else not at all: k_hash_rows reads the LDE back.
         uint32_t threads;
         size_t lds;
         rc = seg_launch_dims<F>(a.logD, threads, lds);
         if (rc) return rc;
         const uint64_t grid = (uint64_t)n_groups * d.n_seg * a.O;
         if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
+        const bool may_fuse = d.rows_out && d.leaves && !packed && getenv("WF_EXP_NO_FUSED_HASH") == nullptr;
+        const uint64_t tickets = (uint64_t)d.n_cosets * a.O;
+        const bool persistent = may_fuse && !single && d.n_seg <= 16 && threads * 2 == (1u << a.logD) && tickets % 8 == 0 &&
+                                getenv("WF_EXP_NO_PERSISTENT") == nullptr;
+        const bool fuse = persistent || (may_fuse && d.n_seg == 1 && d.total_base_cols == d.base_cols);
+        a.leaves = fuse ? (uint32_t *)d.leaves : nullptr;
+        a.hash_epr = d.hash_epr;
+        if (d.fused) *d.fused = fuse;
         prof_mark(ctx, st, tag_l);
-        // fused hashing in a multi-pass plan: the persistent form of the last pass (one resident set of work-groups)
-        const bool persistent = fuse && !single && threads * 2 == (1u << a.logD) && grid % 8 == 0 && getenv("WF_EXP_NO_PERSISTENT") == nullptr;
         if (persistent) {
-            if (lds > 64 * 1024)
-                HIP_TRY(hipFuncSetAttribute((const void *)k_seg_last_hash<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            const bool multi = d.n_seg > 1 || d.total_base_cols != d.base_cols;
+            if (lds > 64 * 1024) {
+                HIP_TRY(hipFuncSetAttribute((const void *)k_seg_last_hash<F, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIP_TRY(hipFuncSetAttribute((const void *)k_seg_last_hash<F, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            }
             const size_t lds_p = lds - ((size_t)1 << a.logD) * sizeof(T) + 16;  // no `aux` table; two ticket words
             const uint64_t resident = (uint64_t)ctx->num_cus * std::max<size_t>(1, (160 * 1024) / lds_p);
             int rcq = ensure(ctx->tickets, 64);
             if (rcq) return rcq;
             HIP_TRY(hipMemsetAsync(ctx->tickets.p, 0, 32, st));
             a.tile_counters = (uint32_t *)ctx->tickets.p;
-            hipLaunchKernelGGL((k_seg_last_hash<F>), dim3((uint32_t)std::min<uint64_t>(grid, resident)), dim3(threads), lds_p, st, a);
+            if (multi)
+                hipLaunchKernelGGL((k_seg_last_hash<F, true>), dim3((uint32_t)std::min<uint64_t>(tickets, resident)), dim3(threads), lds_p, st, a);
+            else
+                hipLaunchKernelGGL((k_seg_last_hash<F, false>), dim3((uint32_t)std::min<uint64_t>(tickets, resident)), dim3(threads), lds_p, st, a);
         } else if (d.rows_out && packed)
             hipLaunchKernelGGL((k_seg_last<F, SEG_OUT_ROWS, true>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
         else if (d.rows_out)
@@ -761,7 +772,7 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
     d.trace_lde_elems = Nrows * row_width;
     bool hashed = false;  // leaves produced by the last evaluation pass itself (one segment, one trace)
     d.leaves = d_leaves;
-    d.hash_epr = base_cols;
+    d.hash_epr = b.total_base_cols;  // the combined row of all traces (= base_cols for one trace)
     d.fused = &hashed;
     rc = run_seg_transform<F>(ctx, st, d);
     if (rc) return rc;
