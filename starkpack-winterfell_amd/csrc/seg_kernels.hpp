@@ -53,6 +53,26 @@ __device__ __forceinline__ void store_pair(T *dst, const Pair<T> &v) {
 #endif
 }
 
+// A lane pair rebuilt from the 16-byte vector registers it was loaded into.  Tile data that waits in registers between
+// its (early) global load and its use is kept in native vector registers: arrays of Pair<> in the same role stay in
+// scratch memory in some instantiations (the PACKED ones), which doubles the tile's memory traffic.
+template <class F>
+__device__ __forceinline__ Pair<typename F::T> pair_from(const uint4 &qa, const uint4 &qb);
+template <>
+__device__ __forceinline__ Pair<uint64_t> pair_from<F64>(const uint4 &qa, const uint4 &) {
+    Pair<uint64_t> v;
+    v.a = ((uint64_t)qa.y << 32) | qa.x;
+    v.b = ((uint64_t)qa.w << 32) | qa.z;
+    return v;
+}
+template <>
+__device__ __forceinline__ Pair<U128> pair_from<F128>(const uint4 &qa, const uint4 &qb) {
+    Pair<U128> v;
+    v.a = U128{((uint64_t)qa.y << 32) | qa.x, ((uint64_t)qa.w << 32) | qa.z};
+    v.b = U128{((uint64_t)qb.y << 32) | qb.x, ((uint64_t)qb.w << 32) | qb.z};
+    return v;
+}
+
 enum : int { SEG_OUT_SEG = 0, SEG_OUT_ROWS = 1 };
 
 // Work-groups are dispatched to the 8 XCDs round-robin (blockIdx % 8), each XCD with its own L2.  This maps blockIdx
@@ -374,7 +394,6 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
     // The first LOAD_BATCH row pieces of every thread (the whole tile up to D = 2^10) are requested before the tables
     // are built, so that their latency runs under the table arithmetic.  The rows are I apart: every load is its own
     // 64-byte gather, the load phase lives on memory-level parallelism.
-    constexpr uint32_t LB = SegCfg<F>::LOAD_BATCH;
     const uint32_t step = blockDim.x;
     const bool from_regs = !(PACKED && a.pre_on);
     // ---- prologue: every global read of the tile's setup is issued before the first one is used -- the operands of the
@@ -397,11 +416,13 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
     }
     // `direct`: the 16 inputs of this thread's first radix-16 work item come straight from global memory into registers
     // (lane threadIdx % S of rows a * D/16 + threadIdx / S), the tile makes no trip through LDS before the first round
-    const bool direct = SegCfg<F>::RADIX16 && a.logD >= 4 && from_regs;
+    // (not in the PACKED instantiations: there the 16-value array ends up in scratch memory)
+    const bool direct = !PACKED && SegCfg<F>::RADIX16 && a.logD >= 4 && from_regs;
     const uint32_t m16 = D >> 4, l16 = threadIdx.x & (S - 1), j16 = threadIdx.x / S;
     const bool has16 = threadIdx.x < m16 * S;
     T vr[16];
-    P2 v0[LB];
+    uint4 r0, r1, r2, r3, r4, r5, r6, r7;  // the non-direct route: lane pairs in vector registers (see pair_from)
+    r0 = r1 = r2 = r3 = r4 = r5 = r6 = r7 = make_uint4(0, 0, 0, 0);
     if (direct) {
         if (has16) {
             // sixteen rows m16 * I apart: one address, then a running 64-bit add per row
@@ -418,16 +439,38 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
             }
         }
     } else if (from_regs) {
-#pragma unroll
-        for (uint32_t u = 0; u < LB; u++) {
-            const uint32_t wk = threadIdx.x + u * step;
-            if (wk < nitems)
 #ifdef WF_EXP_SKIP_LOAD
-                v0[u] = *reinterpret_cast<const P2 *>(src + 2 * (wk & (HP - 1)));
+#define WF_ITEM_PTR(WK) reinterpret_cast<const uint4 *>(src + 2 * ((WK) & (HP - 1)))
 #else
-                v0[u] = *reinterpret_cast<const P2 *>(src + (row0 + ((uint64_t)(wk >> hp_shift) << logI)) * S + 2 * (wk & (HP - 1)));
+#define WF_ITEM_PTR(WK) \
+    reinterpret_cast<const uint4 *>(src + (row0 + ((uint64_t)((WK) >> hp_shift) << logI)) * S + 2 * ((WK) & (HP - 1)))
 #endif
+#define WF_LOAD_ITEM(U, RA, RB)                            \
+    do {                                                   \
+        const uint32_t wk_ = threadIdx.x + (U) * step;     \
+        if (wk_ < nitems) {                                \
+            const uint4 *p_ = WF_ITEM_PTR(wk_);            \
+            RA = p_[0];                                    \
+            if (F::BYTES == 16) RB = p_[1];                \
+        }                                                  \
+    } while (0)
+        if (F::BYTES == 8) {
+            WF_LOAD_ITEM(0, r0, r0);
+            WF_LOAD_ITEM(1, r1, r1);
+            WF_LOAD_ITEM(2, r2, r2);
+            WF_LOAD_ITEM(3, r3, r3);
+            WF_LOAD_ITEM(4, r4, r4);
+            WF_LOAD_ITEM(5, r5, r5);
+            WF_LOAD_ITEM(6, r6, r6);
+            WF_LOAD_ITEM(7, r7, r7);
+        } else {
+            WF_LOAD_ITEM(0, r0, r1);
+            WF_LOAD_ITEM(1, r2, r3);
+            WF_LOAD_ITEM(2, r4, r5);
+            WF_LOAD_ITEM(3, r6, r7);
         }
+#undef WF_LOAD_ITEM
+#undef WF_ITEM_PTR
     }
     T fo[2];
     {
@@ -463,30 +506,36 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
             *reinterpret_cast<P2 *>(x + d * S + 2 * lp) = v;
         }
     } else {
-        for (uint32_t wk0 = threadIdx.x; wk0 < nitems; wk0 += LB * step) {
-            P2 v[LB];
-#pragma unroll
-            for (uint32_t u = 0; u < LB; u++) {
-                const uint32_t wk = wk0 + u * step;
-                if (wk0 == threadIdx.x)
-                    v[u] = v0[u];
-                else if (wk < nitems)
-                    v[u] = *reinterpret_cast<const P2 *>(src + (row0 + ((uint64_t)(wk >> hp_shift) << logI)) * S + 2 * (wk & (HP - 1)));
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < LB; u++) {
-                const uint32_t wk = wk0 + u * step;
-                if (wk < nitems) {
-                    const uint32_t lp = wk & (HP - 1), d = wk >> hp_shift;
-                    if (a.pre_on) {
-                        const T f = aux[d];
-                        v[u].a = F::mul(v[u].a, f);
-                        v[u].b = F::mul(v[u].b, f);
-                    }
-                    *reinterpret_cast<P2 *>(x + d * S + 2 * lp) = v[u];
-                }
-            }
+#define WF_FILL_ITEM(U, RA, RB)                                          \
+    do {                                                                 \
+        const uint32_t wk_ = threadIdx.x + (U) * step;                   \
+        if (wk_ < nitems) {                                              \
+            const uint32_t lp_ = wk_ & (HP - 1), d_ = wk_ >> hp_shift;   \
+            P2 v_ = pair_from<F>(RA, RB);                                \
+            if (a.pre_on) {                                              \
+                const T f_ = aux[d_];                                    \
+                v_.a = F::mul(v_.a, f_);                                 \
+                v_.b = F::mul(v_.b, f_);                                 \
+            }                                                            \
+            *reinterpret_cast<P2 *>(x + d_ * S + 2 * lp_) = v_;          \
+        }                                                                \
+    } while (0)
+        if (F::BYTES == 8) {
+            WF_FILL_ITEM(0, r0, r0);
+            WF_FILL_ITEM(1, r1, r1);
+            WF_FILL_ITEM(2, r2, r2);
+            WF_FILL_ITEM(3, r3, r3);
+            WF_FILL_ITEM(4, r4, r4);
+            WF_FILL_ITEM(5, r5, r5);
+            WF_FILL_ITEM(6, r6, r6);
+            WF_FILL_ITEM(7, r7, r7);
+        } else {
+            WF_FILL_ITEM(0, r0, r1);
+            WF_FILL_ITEM(1, r2, r3);
+            WF_FILL_ITEM(2, r4, r5);
+            WF_FILL_ITEM(3, r6, r7);
         }
+#undef WF_FILL_ITEM
     }
     if (!direct || scale_in) __syncthreads();  // LDS tile written / input factors consumed (uniform condition)
     // `aux` now takes the output factors (visible after the transform's barriers)
@@ -588,7 +637,6 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
     const uint32_t nitems = D * HP;
     // prologue as in k_seg_strided: the digit twiddles, the operands of the input factors (single-pass evaluation only)
     // and the tile's rows are all requested before the first of them is used
-    constexpr uint32_t LB = SegCfg<F>::LOAD_BATCH;
     const uint32_t step = blockDim.x;
     const bool from_regs = !(PACKED && a.pre_on);
     const bool scale_in = !PACKED && a.pre_on;
@@ -604,18 +652,42 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
     }
     // (no direct first round here, unlike k_seg_strided: the tile is one contiguous 64 KiB run, which 16-byte-per-lane
     // loads staged through LDS stream faster than sixteen 8-byte loads per thread -- measured 0.61 -> 0.69 ms with it)
-    P2 v0[LB];
-    if (from_regs) {
-#pragma unroll
-        for (uint32_t u = 0; u < LB; u++) {
-            const uint32_t wk = threadIdx.x + u * step;
+    // blockDim >= D/2: a tile is at most LOAD_BATCH lane pairs per thread, eight 16-byte registers either way
+    uint4 r0, r1, r2, r3, r4, r5, r6, r7;
+    r0 = r1 = r2 = r3 = r4 = r5 = r6 = r7 = make_uint4(0, 0, 0, 0);
 #ifdef WF_EXP_SKIP_LOAD
-            if (wk < nitems) v0[u] = *reinterpret_cast<const P2 *>(a.src + 2 * (uint64_t)(wk & 63));
+#define WF_ITEM_PTR(WK) reinterpret_cast<const uint4 *>(a.src + 2 * (uint64_t)((WK) & 63))
 #else
-            if (wk < nitems) v0[u] = *reinterpret_cast<const P2 *>(src + 2 * (uint64_t)wk);
+#define WF_ITEM_PTR(WK) reinterpret_cast<const uint4 *>(src + 2 * (uint64_t)(WK))
 #endif
+#define WF_LOAD_ITEM(U, RA, RB)                            \
+    do {                                                   \
+        const uint32_t wk_ = threadIdx.x + (U) * step;     \
+        if (wk_ < nitems) {                                \
+            const uint4 *p_ = WF_ITEM_PTR(wk_);            \
+            RA = p_[0];                                    \
+            if (F::BYTES == 16) RB = p_[1];                \
+        }                                                  \
+    } while (0)
+    if (from_regs) {
+        if (F::BYTES == 8) {
+            WF_LOAD_ITEM(0, r0, r0);
+            WF_LOAD_ITEM(1, r1, r1);
+            WF_LOAD_ITEM(2, r2, r2);
+            WF_LOAD_ITEM(3, r3, r3);
+            WF_LOAD_ITEM(4, r4, r4);
+            WF_LOAD_ITEM(5, r5, r5);
+            WF_LOAD_ITEM(6, r6, r6);
+            WF_LOAD_ITEM(7, r7, r7);
+        } else {
+            WF_LOAD_ITEM(0, r0, r1);
+            WF_LOAD_ITEM(1, r2, r3);
+            WF_LOAD_ITEM(2, r4, r5);
+            WF_LOAD_ITEM(3, r6, r7);
         }
     }
+#undef WF_LOAD_ITEM
+#undef WF_ITEM_PTR
 #pragma unroll
     for (uint32_t q = 0; q < 2; q++) {
         if (threadIdx.x + q * blockDim.x < D) {
@@ -635,29 +707,35 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
             *reinterpret_cast<P2 *>(x + 2 * wk) = v;
         }
     } else {
-        for (uint32_t wk0 = threadIdx.x; wk0 < nitems; wk0 += LB * step) {
-            P2 v[LB];
-#pragma unroll
-            for (uint32_t u = 0; u < LB; u++) {
-                const uint32_t wk = wk0 + u * step;
-                if (wk0 == threadIdx.x)
-                    v[u] = v0[u];
-                else if (wk < nitems)
-                    v[u] = *reinterpret_cast<const P2 *>(src + 2 * (uint64_t)wk);
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < LB; u++) {
-                const uint32_t wk = wk0 + u * step;
-                if (wk < nitems) {
-                    if (a.pre_on) {
-                        const T f = aux[wk >> hp_shift];
-                        v[u].a = F::mul(v[u].a, f);
-                        v[u].b = F::mul(v[u].b, f);
-                    }
-                    *reinterpret_cast<P2 *>(x + 2 * wk) = v[u];
-                }
-            }
+#define WF_FILL_ITEM(U, RA, RB)                                \
+    do {                                                       \
+        const uint32_t wk_ = threadIdx.x + (U) * step;         \
+        if (wk_ < nitems) {                                    \
+            P2 v_ = pair_from<F>(RA, RB);                      \
+            if (a.pre_on) {                                    \
+                const T f_ = aux[wk_ >> hp_shift];             \
+                v_.a = F::mul(v_.a, f_);                       \
+                v_.b = F::mul(v_.b, f_);                       \
+            }                                                  \
+            *reinterpret_cast<P2 *>(x + 2 * wk_) = v_;         \
+        }                                                      \
+    } while (0)
+        if (F::BYTES == 8) {
+            WF_FILL_ITEM(0, r0, r0);
+            WF_FILL_ITEM(1, r1, r1);
+            WF_FILL_ITEM(2, r2, r2);
+            WF_FILL_ITEM(3, r3, r3);
+            WF_FILL_ITEM(4, r4, r4);
+            WF_FILL_ITEM(5, r5, r5);
+            WF_FILL_ITEM(6, r6, r6);
+            WF_FILL_ITEM(7, r7, r7);
+        } else {
+            WF_FILL_ITEM(0, r0, r1);
+            WF_FILL_ITEM(1, r2, r3);
+            WF_FILL_ITEM(2, r4, r5);
+            WF_FILL_ITEM(3, r6, r7);
         }
+#undef WF_FILL_ITEM
     }
     __syncthreads();
 #ifndef WF_EXP_SKIP_NTT
@@ -701,6 +779,8 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
                 pb = a.dst + (uint64_t)t1 * a.trace_lde_elems +
                      (((uint64_t)c << a.cpr_log) + (lane_b >> a.lg_log)) * a.row_width + (col - t1 * a.base_cols);
             }
+            // both lanes in the same coset and trace, neighbouring columns at an even offset: one 16-byte store
+            pair_store = pa && pb && pb == pa + 1 && ((pa - a.dst) & 1) == 0;
         } else {
             const uint32_t B = g * S + lane_a;  // global base column of lane a
             if (B < a.total_base_cols) {
