@@ -306,7 +306,9 @@ __global__ void __launch_bounds__(256) k_hash_rows(HashArgs<F> a) {
         const uint32_t epr = a.epr;
         auto load = [&](uint64_t bi, uint32_t(&m)[16]) {
             const uint32_t e0 = (uint32_t)bi * EPB;
-            if (e0 + EPB <= epr) {  // whole 64-byte block: rows are 64-byte aligned, four 16-byte loads
+            // whole 64-byte block inside the stored row (rows are 64-byte aligned, lanes past `epr` are zero by the
+            // padding rule, exactly the zero padding BLAKE3 wants): four 16-byte loads
+            if (e0 + EPB <= a.row_width) {
                 const uint4 *q = reinterpret_cast<const uint4 *>(row + e0);
                 T ev[EPB];
                 uint4 *dstv = reinterpret_cast<uint4 *>(ev);
