@@ -501,8 +501,11 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
             P2 v;
             const uint32_t lgm = (1u << a.lg_log) - 1, cola = lane_a & lgm, colb = lane_b & lgm;
             const T *srow = src + (row0 + ((uint64_t)d << logI)) * S;
-            v.a = act_a ? F::mul(srow[cola], pre_a.get((uint64_t)d << logI)) : F::zero();
-            v.b = act_b ? F::mul(srow[colb], pre_b.get((uint64_t)d << logI)) : F::zero();
+            // the two lanes of a pair share their coset (and so the factor) unless a coset is a single lane wide
+            const T fa = pre_a.get((uint64_t)d << logI);
+            const T fb = a.lg_log ? fa : pre_b.get((uint64_t)d << logI);
+            v.a = act_a ? F::mul(srow[cola], fa) : F::zero();
+            v.b = act_b ? F::mul(srow[colb], fb) : F::zero();
             *reinterpret_cast<P2 *>(x + d * S + 2 * lp) = v;
         }
     } else {
@@ -702,8 +705,10 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
             const uint32_t d = wk >> hp_shift;
             const uint32_t lgm = (1u << a.lg_log) - 1, cola = lane_a & lgm, colb = lane_b & lgm;
             const T *srow = src + (uint64_t)d * S;
-            v.a = act_a ? F::mul(srow[cola], pre_a.get(d)) : F::zero();
-            v.b = act_b ? F::mul(srow[colb], pre_b.get(d)) : F::zero();
+            const T fa = pre_a.get(d);
+            const T fb = a.lg_log ? fa : pre_b.get(d);  // lanes of a pair share their coset unless it is one lane wide
+            v.a = act_a ? F::mul(srow[cola], fa) : F::zero();
+            v.b = act_b ? F::mul(srow[colb], fb) : F::zero();
             *reinterpret_cast<P2 *>(x + 2 * wk) = v;
         }
     } else {
