@@ -117,6 +117,10 @@ struct SegArgs {
     // SEG_OUT_ROWS
     uint32_t base_cols;        // base columns per trace
     uint32_t total_base_cols;  // over all traces
+    // columns the last pass stores per trace / in total: base_cols / total_base_cols, or row_width for a single trace whose
+    // segments cover the padded row exactly -- the zero padding lanes (segments.rs:65-72) are then written with the data
+    // (whole 64-byte pieces) and the caller does not have to clear the matrix first
+    uint32_t store_cols, total_store_cols;
     uint32_t coset0;           // first coset computed by this call (coset sharding across GPUs); 0 otherwise
     uint32_t rows_per_k;       // cosets held by the output matrix: row = k * rows_per_k + local coset (= blowup unless sharded)
     // coset-packed lanes (narrow matrices: total_base_cols <= S/2): a row holds 2^cpr_log cosets x 2^lg_log lanes;
@@ -788,13 +792,13 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
             pair_store = pa && pb && pb == pa + 1 && ((pa - a.dst) & 1) == 0;
         } else {
             const uint32_t B = g * S + lane_a;  // global base column of lane a
-            if (B < a.total_base_cols) {
-                const uint32_t t0 = B / a.base_cols, c0 = B - t0 * a.base_cols;
+            if (B < a.total_store_cols) {
+                const uint32_t t0 = B / a.store_cols, c0 = B - t0 * a.store_cols;
                 pa = a.dst + (uint64_t)t0 * a.trace_lde_elems + (uint64_t)c * a.row_width + c0;
-                pair_store = c0 + 1 < a.base_cols && (c0 & 1) == 0;  // both lanes in one trace, 16-byte aligned
+                pair_store = c0 + 1 < a.store_cols && (c0 & 1) == 0;  // both lanes in one trace, 16-byte aligned
             }
-            if (B + 1 < a.total_base_cols) {
-                const uint32_t t1 = (B + 1) / a.base_cols, c1 = (B + 1) - t1 * a.base_cols;
+            if (B + 1 < a.total_store_cols) {
+                const uint32_t t1 = (B + 1) / a.store_cols, c1 = (B + 1) - t1 * a.store_cols;
                 pb = a.dst + (uint64_t)t1 * a.trace_lde_elems + (uint64_t)c * a.row_width + c1;
             }
         }
@@ -958,16 +962,16 @@ __global__ void __launch_bounds__(F::BYTES == 8 ? 1024 : 512) k_seg_last_hash(Se
             T *pa = nullptr, *pb = nullptr;
             bool pair = false;
             if (!MULTI) {
-                if (pos0 < D && lane_a < a.base_cols) {
+                if (pos0 < D && lane_a < a.store_cols) {
                     pa = a.dst + (uint64_t)c * a.row_width + lane_a;
-                    pair = lane_a + 1 < a.base_cols;
+                    pair = lane_a + 1 < a.store_cols;
                 }
-            } else if (pos0 < D && B < a.total_base_cols) {
-                const uint32_t t0 = B / a.base_cols, c0 = B - t0 * a.base_cols;
+            } else if (pos0 < D && B < a.total_store_cols) {
+                const uint32_t t0 = B / a.store_cols, c0 = B - t0 * a.store_cols;
                 pa = a.dst + (uint64_t)t0 * a.trace_lde_elems + (uint64_t)c * a.row_width + c0;
-                pair = c0 + 1 < a.base_cols && (c0 & 1) == 0;  // both lanes in one trace, 16-byte aligned
-                if (B + 1 < a.total_base_cols) {
-                    const uint32_t t1 = (B + 1) / a.base_cols, c1 = (B + 1) - t1 * a.base_cols;
+                pair = c0 + 1 < a.store_cols && (c0 & 1) == 0;  // both lanes in one trace, 16-byte aligned
+                if (B + 1 < a.total_store_cols) {
+                    const uint32_t t1 = (B + 1) / a.store_cols, c1 = (B + 1) - t1 * a.store_cols;
                     pb = a.dst + (uint64_t)t1 * a.trace_lde_elems + (uint64_t)c * a.row_width + c1;
                 }
             }

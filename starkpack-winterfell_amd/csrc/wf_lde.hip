@@ -429,6 +429,7 @@ struct SegDesc {
     uint32_t hash_epr = 0;
     bool *fused = nullptr;
     const TableSet *pre;
+    bool pad_in_kernel = false;  // rows_out: the last pass also writes the zero padding lanes of the rows
     uint32_t base_cols, total_base_cols, coset0;
     uint64_t row_width, trace_lde_elems;
 };
@@ -456,6 +457,8 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
     }
     a.base_cols = d.base_cols;
     a.total_base_cols = d.total_base_cols;
+    a.store_cols = d.pad_in_kernel ? (uint32_t)d.row_width : d.base_cols;
+    a.total_store_cols = d.pad_in_kernel ? (uint32_t)d.row_width : d.total_base_cols;
     a.coset0 = d.coset0;
     a.rows_per_k = d.n_cosets;
     a.row_width = d.row_width;
@@ -752,7 +755,11 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
     TableSet *cos;
     int rc = coset_tables<F>(ctx, logR, logB, off, olo, ohi, &cos);
     if (rc) return rc;
-    if (row_width != base_cols)  // zero the padding lanes (segments.rs:65-72)
+    // Zero padding lanes (segments.rs:65-72): a single trace whose segments cover the padded row exactly (always for f64)
+    // and that is not coset-packed gets them from the last evaluation pass; everything else is cleared up front.
+    const bool pad_in_kernel = row_width != base_cols && p->n_traces == 1 && (uint64_t)b.n_seg * SegCfg<F>::S == row_width &&
+                               b.total_base_cols * 2 > SegCfg<F>::S;
+    if (row_width != base_cols && !pad_in_kernel)
         HIP_TRY(hipMemsetAsync(d_lde, 0, (size_t)p->n_traces * Nrows * row_width * sizeof(T), st));
 
     SegDesc<F> d;
@@ -770,6 +777,7 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
     d.total_base_cols = b.total_base_cols;
     d.row_width = row_width;
     d.trace_lde_elems = Nrows * row_width;
+    d.pad_in_kernel = pad_in_kernel;
     bool hashed = false;  // leaves produced by the last evaluation pass itself (one segment, one trace)
     d.leaves = d_leaves;
     d.hash_epr = b.total_base_cols;  // the combined row of all traces (= base_cols for one trace)
