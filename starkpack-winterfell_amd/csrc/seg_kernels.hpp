@@ -121,6 +121,7 @@ struct SegArgs {
     // segments cover the padded row exactly -- the zero padding lanes (segments.rs:65-72) are then written with the data
     // (whole 64-byte pieces) and the caller does not have to clear the matrix first
     uint32_t store_cols, total_store_cols;
+    uint32_t tail_pad;  // zero elements the last segment writes after its own S lanes (0 or S: f128 rows of 8 elements)
     uint32_t coset0;           // first coset computed by this call (coset sharding across GPUs); 0 otherwise
     uint32_t rows_per_k;       // cosets held by the output matrix: row = k * rows_per_k + local coset (= blowup unless sharded)
     // coset-packed lanes (narrow matrices: total_base_cols <= S/2): a row holds 2^cpr_log cosets x 2^lg_log lanes;
@@ -803,10 +804,43 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
             }
         }
         if (!has_rows) pa = pb = nullptr;
+        if (PACKED && a.store_cols != a.base_cols) {
+            // One trace, padded row of S (or 2 S) elements: whole rows leave this pass. A coset owns 2^lg lanes
+            // (lg >= 1: a lane pair is one 2-element slot of its row, and also writes the zero slots a multiple of the
+            // group size further along; lg == 0: each lane is a coset of its own and writes its whole row).
+            const uint32_t lg = a.lg_log, ncos = 1u << a.cpr_log, n_slots = (uint32_t)a.row_width / 2;
+            const P2 zz{F::zero(), F::zero()};
+            T *row_a = nullptr, *row_b = nullptr;
+            if (has_rows && (lane_a >> lg) < ncos)
+                row_a = a.dst + (((uint64_t)c << a.cpr_log) + (lane_a >> lg)) * a.row_width;
+            if (has_rows && lg == 0 && lane_b < ncos) row_b = a.dst + (((uint64_t)c << a.cpr_log) + lane_b) * a.row_width;
+            const uint32_t slot = lg ? ((lane_a & ((1u << lg) - 1)) >> 1) : 0, gs = lg ? (1u << (lg - 1)) : 1;
+            for (uint32_t pj = 0; (row_a || row_b) && pj < D; pj += pstride) {
+                const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, a.logD)) << out_shift);
+                const P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
+                const uint64_t off = (uint64_t)(uint32_t)k * k_stride;
+                if (lg) {
+                    store_pair(row_a + off + 2 * slot, v);
+                    for (uint32_t s2 = slot + gs; s2 < n_slots; s2 += gs) store_pair(row_a + off + 2 * s2, zz);
+                } else {
+                    if (row_a) {
+                        store_pair(row_a + off, P2{v.a, F::zero()});
+                        for (uint32_t s2 = 1; s2 < n_slots; s2++) store_pair(row_a + off + 2 * s2, zz);
+                    }
+                    if (row_b) {
+                        store_pair(row_b + off, P2{v.b, F::zero()});
+                        for (uint32_t s2 = 1; s2 < n_slots; s2++) store_pair(row_b + off + 2 * s2, zz);
+                    }
+                }
+            }
+            pa = pb = nullptr;
+        }
+        const bool tail = !PACKED && a.tail_pad && g + 1 == a.n_seg;  // (single trace: every lane has its pa)
         for (uint32_t pj = 0; (pa || pb) && pj < D; pj += pstride) {
             const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, a.logD)) << out_shift);
             const P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
             const uint64_t off = (uint64_t)(uint32_t)k * k_stride;  // k < 2^32 rows: one 32 x 32 -> 64 multiply
+            if (tail) store_pair(pa + off + S, P2{F::zero(), F::zero()});
             if (pair_store) {
 #ifdef WF_EXP_SKIP_STORE
                 if (*reinterpret_cast<const uint32_t *>(&v.a) == a.logN + 77777u)
@@ -977,6 +1011,7 @@ __global__ void __launch_bounds__(F::BYTES == 8 ? 1024 : 512) k_seg_last_hash(Se
             }
             if (pa) {
                 const uint32_t k0 = seg_digit_reverse<F>(pos0, a.logD);
+                const bool tail = a.tail_pad && g + 1 == a.n_seg;  // (single trace: every lane has its pa)
                 for (uint32_t pj = 0; pj < D; pj += pstride) {
                     const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, a.logD)) << out_shift);
                     const P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
@@ -987,6 +1022,7 @@ __global__ void __launch_bounds__(F::BYTES == 8 ? 1024 : 512) k_seg_last_hash(Se
                         pa[off] = v.a;
                         if (pb) pb[off] = v.b;
                     }
+                    if (tail) store_pair(pa + off + S, P2{F::zero(), F::zero()});
                 }
             }
         }

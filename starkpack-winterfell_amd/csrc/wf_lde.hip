@@ -417,6 +417,21 @@ static int seg_launch_dims(uint32_t logD, uint32_t &threads, size_t &lds) {
 //                                      out = [n_seg][N][S] coefficients, natural order, scaled by 1/N
 //   evaluation    (rows_out == true) : in  = [n_seg][N][S] coefficients (read only), work = [cosets][n_seg][N][S],
 //                                      out = row-major LDE matrices (see SegArgs)
+// Coset packing of narrow evaluations (<= S/2 base columns in one segment, an even number of cosets): 2^cpr cosets of
+// 2^lg lanes each share the lanes of a row.
+template <class F>
+static bool packed_shape(uint32_t n_seg, uint32_t total_base_cols, uint32_t n_cosets, uint32_t *cpr_log, uint32_t *lg_log) {
+    if (n_seg != 1 || total_base_cols * 2 > SegCfg<F>::S || n_cosets < 2) return false;
+    uint32_t lg = 0;
+    while ((1u << lg) < total_base_cols) lg++;
+    uint32_t cpr = 0;
+    while ((2u << cpr) <= (SegCfg<F>::S >> lg) && n_cosets % (2u << cpr) == 0) cpr++;
+    if (cpr == 0) return false;
+    *cpr_log = cpr;
+    *lg_log = lg;
+    return true;
+}
+
 template <class F>
 struct SegDesc {
     typedef typename F::T T;
@@ -457,8 +472,9 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
     }
     a.base_cols = d.base_cols;
     a.total_base_cols = d.total_base_cols;
-    a.store_cols = d.pad_in_kernel ? (uint32_t)d.row_width : d.base_cols;
-    a.total_store_cols = d.pad_in_kernel ? (uint32_t)d.row_width : d.total_base_cols;
+    a.store_cols = d.pad_in_kernel ? d.n_seg * SegCfg<F>::S : d.base_cols;
+    a.total_store_cols = d.pad_in_kernel ? d.n_seg * SegCfg<F>::S : d.total_base_cols;
+    a.tail_pad = d.pad_in_kernel ? (uint32_t)d.row_width - d.n_seg * SegCfg<F>::S : 0;
     a.coset0 = d.coset0;
     a.rows_per_k = d.n_cosets;
     a.row_width = d.row_width;
@@ -468,18 +484,10 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
     // lanes of a row instead of leaving them empty
     uint32_t n_groups = d.n_cosets;
     bool packed = false;
-    if (d.rows_out && d.n_seg == 1 && d.total_base_cols * 2 <= SegCfg<F>::S && d.n_cosets >= 2) {
-        uint32_t lg = 0;
-        while ((1u << lg) < d.total_base_cols) lg++;
-        uint32_t cpr = 0;
-        while ((2u << cpr) <= (SegCfg<F>::S >> lg) && d.n_cosets % (2u << cpr) == 0) cpr++;
-        if (cpr > 0) {
-            packed = true;
-            a.cpr_log = cpr;
-            a.lg_log = lg;
-            n_groups = d.n_cosets >> cpr;
-            a.n_cosets = n_groups;
-        }
+    if (d.rows_out && packed_shape<F>(d.n_seg, d.total_base_cols, d.n_cosets, &a.cpr_log, &a.lg_log)) {
+        packed = true;
+        n_groups = d.n_cosets >> a.cpr_log;
+        a.n_cosets = n_groups;
     }
     const char *tag_s = d.rows_out ? "evaluate.strided_pass" : "interpolate.strided_pass";
     const char *tag_l = d.rows_out ? "evaluate.last_pass" : "interpolate.last_pass";
@@ -755,10 +763,16 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
     TableSet *cos;
     int rc = coset_tables<F>(ctx, logR, logB, off, olo, ohi, &cos);
     if (rc) return rc;
-    // Zero padding lanes (segments.rs:65-72): a single trace whose segments cover the padded row exactly (always for f64)
-    // and that is not coset-packed gets them from the last evaluation pass; everything else is cleared up front.
-    const bool pad_in_kernel = row_width != base_cols && p->n_traces == 1 && (uint64_t)b.n_seg * SegCfg<F>::S == row_width &&
-                               b.total_base_cols * 2 > SegCfg<F>::S;
+    // Zero padding lanes (segments.rs:65-72): a single trace whose segments cover the padded row, or all but its last S
+    // elements (f128 rows are padded to 2 S),
+    // gets them from the last evaluation pass (coset-packed f128 rows excepted: 128-byte rows written 32 bytes at a time
+    // by one lane measured slower than clearing them); everything else is cleared up front.
+    uint32_t cpr_unused, lg_unused;
+    const uint64_t seg_lanes = (uint64_t)b.n_seg * SegCfg<F>::S;
+    const bool pad_in_kernel = row_width != base_cols && p->n_traces == 1 &&
+                               (seg_lanes == row_width || seg_lanes + SegCfg<F>::S == row_width) &&
+                               (b.total_base_cols * 2 > SegCfg<F>::S ||
+                                (F::BYTES == 8 && packed_shape<F>(b.n_seg, b.total_base_cols, n_cosets, &cpr_unused, &lg_unused)));
     if (row_width != base_cols && !pad_in_kernel)
         HIP_TRY(hipMemsetAsync(d_lde, 0, (size_t)p->n_traces * Nrows * row_width * sizeof(T), st));
 

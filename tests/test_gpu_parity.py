@@ -243,3 +243,36 @@ def test_random_shapes(ctx, orc, capi, cfg):
         for c in range(n_cols):
             assert np.array_equal(got["polys"][t * n_cols + c], want["polys"][t][c])
     assert np.array_equal(got["nodes"], want["nodes"])
+
+
+@pytest.mark.parametrize("field,ext,logR,logB,n_cols,n_traces", [
+    (F64, 1, 10, 3, 1, 1), (F64, 1, 10, 3, 2, 1), (F64, 1, 10, 3, 3, 1), (F64, 1, 10, 3, 4, 1), (F64, 1, 10, 3, 5, 1),
+    (F64, 1, 10, 3, 7, 1), (F64, 2, 10, 3, 1, 1), (F64, 3, 10, 3, 1, 1), (F64, 1, 10, 1, 3, 1), (F64, 1, 10, 2, 1, 1),
+    (F64, 1, 10, 3, 11, 1), (F64, 1, 10, 3, 3, 2), (F64, 1, 10, 3, 5, 3), (F64, 1, 13, 3, 2, 1),
+    (F128, 1, 10, 3, 1, 1), (F128, 1, 10, 3, 2, 1), (F128, 1, 10, 3, 3, 1), (F128, 2, 10, 3, 1, 1), (F128, 1, 10, 3, 5, 1),
+    (F128, 1, 10, 3, 3, 2)])
+def test_padding_lanes_are_written(ctx, orc, capi, field, ext, logR, logB, n_cols, n_traces):
+    """The zero padding of LDE rows (segments.rs:65-72) must not depend on what the caller's buffer held: the device
+    form is run into an LDE buffer pre-filled with ones and compared in full, padding lanes included."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(hash((field, ext, logR, logB, n_cols, n_traces, "pad")) % 2**32)
+    R, N = 1 << logR, 1 << (logR + logB)
+    traces = [rand_cols(rng, field, n_cols, R * ext) for _ in range(n_traces)]
+    offset = 7 if field == F64 else 3
+    want = orc.build_trace_commitment(field, traces, ext, logR, logB, offset)
+    params = capi.make_params(field, ext, logR, logB, n_cols, n_traces)
+    flat = np.concatenate([np.ascontiguousarray(c).reshape(-1) for t in traces for c in t]).view(np.int64)
+    d_trace = torch.from_numpy(flat.copy()).to(dev)
+    d_polys = torch.empty_like(d_trace)
+    want_lde = np.stack([np.ascontiguousarray(l) for l in want["lde"]])
+    d_lde = torch.full((want_lde.size,), -1, dtype=torch.int64, device=dev)
+    d_leaves = torch.empty((N, 32), dtype=torch.uint8, device=dev)
+    d_nodes = torch.empty((N, 32), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.trace_commit_dev(params, d_trace.data_ptr(), d_polys.data_ptr(), d_lde.data_ptr(), d_leaves.data_ptr(),
+                         d_nodes.data_ptr())
+    torch.cuda.synchronize()
+    got = d_lde.cpu().numpy().view(np.uint64).reshape(want_lde.shape)
+    assert np.array_equal(got, want_lde)
+    assert np.array_equal(d_leaves.cpu().numpy().reshape(-1), np.ascontiguousarray(want["leaves"]).view(np.uint8).reshape(-1))
