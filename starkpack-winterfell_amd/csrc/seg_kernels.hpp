@@ -53,6 +53,19 @@ __device__ __forceinline__ void store_pair(T *dst, const Pair<T> &v) {
 #endif
 }
 
+// Zero padding of an LDE row (segments.rs:65-72) from its first padding element `pz` (column `cols` of a row of
+// `row_width` elements, row_width even): one single element if `cols` is odd, then aligned pairs.
+template <class F>
+__device__ __forceinline__ void store_row_padding(typename F::T *pz, uint32_t cols, uint32_t row_width) {
+    uint32_t z = cols;
+    if (z & 1) {
+        *pz++ = F::zero();
+        z++;
+    }
+    const Pair<typename F::T> zz{F::zero(), F::zero()};
+    for (; z < row_width; z += 2, pz += 2) store_pair(pz, zz);
+}
+
 // A lane pair rebuilt from the 16-byte vector registers it was loaded into.  Tile data that waits in registers between
 // its (early) global load and its use is kept in native vector registers: arrays of Pair<> in the same role stay in
 // scratch memory in some instantiations (the PACKED ones), which doubles the tile's memory traffic.
@@ -121,6 +134,7 @@ struct SegArgs {
     // segments cover the padded row exactly -- the zero padding lanes (segments.rs:65-72) are then written with the data
     // (whole 64-byte pieces) and the caller does not have to clear the matrix first
     uint32_t store_cols, total_store_cols;
+    uint32_t pad_traces;  // the lane that stores a trace's last column also zeroes the rest of that (padded) row
     uint32_t tail_pad;  // zero elements the last segment writes after its own S lanes (0 or S: f128 rows of 8 elements)
     uint32_t coset0;           // first coset computed by this call (coset sharding across GPUs); 0 otherwise
     uint32_t rows_per_k;       // cosets held by the output matrix: row = k * rows_per_k + local coset (= blowup unless sharded)
@@ -590,6 +604,42 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
     }
 }
 
+// Row stores of the last evaluation pass for narrow side-by-side traces (STARKPack: several traces in the lanes of a
+// segment, each with an LDE matrix of its own whose rows are padded to 8 elements).  A lane pair storing its own 16
+// bytes would touch a different 64-byte row in every lane: four consecutive threads write one whole row instead -- the
+// trace's columns that live in this segment and, from the segment holding its last column, the zero padding -- so a
+// store instruction covers 16 complete rows.  `x` is the tile after its transform, [row position][S lanes].
+template <class F>
+__device__ __forceinline__ void store_rows_narrow(const typename F::T *x, const SegArgs<F> &a, uint32_t g, uint32_t c,
+                                                  uint64_t rev_o, uint32_t out_shift, uint32_t k_stride, uint32_t tid,
+                                                  uint32_t n_threads) {
+    using T = typename F::T;
+    constexpr uint32_t S = SegCfg<F>::S;
+    const uint32_t D = 1u << a.logD, bc = a.store_cols;
+    const uint32_t lo = g * S, hi = min(lo + S, a.total_store_cols);  // the lanes of this segment that hold columns
+    const uint32_t s2 = 2 * (tid & 3), psub = tid >> 2, pstep = n_threads >> 2;
+    for (uint32_t t = lo / bc; t <= (hi - 1) / bc; t++) {
+        const uint32_t b0 = t * bc + s2, b1 = b0 + 1, last = t * bc + bc - 1;
+        const bool d0 = s2 < bc, d1 = s2 + 1 < bc;            // columns of the trace (else padding)
+        const bool pad_here = last >= lo && last < hi;          // this segment writes the trace's padding
+        const bool in0 = d0 ? (b0 >= lo && b0 < hi) : pad_here, in1 = d1 ? (b1 >= lo && b1 < hi) : pad_here;
+        if (!in0 && !in1) continue;
+        T *row = a.dst + (uint64_t)t * a.trace_lde_elems + (uint64_t)c * a.row_width + s2;
+        for (uint32_t pos = psub; pos < D; pos += pstep) {
+            const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << out_shift);
+            const uint64_t off = (uint64_t)(uint32_t)k * k_stride;
+            const T v0 = d0 && in0 ? x[pos * S + (b0 - lo)] : F::zero();
+            const T v1 = d1 && in1 ? x[pos * S + (b1 - lo)] : F::zero();
+            if (in0 && in1)
+                store_pair(row + off, Pair<T>{v0, v1});
+            else if (in0)
+                row[off] = v0;
+            else
+                row[off + 1] = v1;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Last pass.  grid.x = n_cosets * n_seg * O ; work-group = (coset c, segment g, row block o) of D contiguous rows.
 template <class F, int OUT, bool PACKED = false>
@@ -775,7 +825,7 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
     } else {
         // destination of each lane for k = 0: dst + trace * trace_elems + (coset) * row_width + column
         const uint32_t k_stride = a.rows_per_k * (uint32_t)a.row_width;  // elements between consecutive k (< 2^19)
-        T *pa = nullptr, *pb = nullptr;
+        T *pa = nullptr, *pb = nullptr, *pz = nullptr, *pz2 = nullptr;  // pz*: first padding element after a trace's last column
         bool pair_store = false;
         if (PACKED) {
             const uint32_t lgm = (1u << a.lg_log) - 1;
@@ -797,13 +847,19 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
                 const uint32_t t0 = B / a.store_cols, c0 = B - t0 * a.store_cols;
                 pa = a.dst + (uint64_t)t0 * a.trace_lde_elems + (uint64_t)c * a.row_width + c0;
                 pair_store = c0 + 1 < a.store_cols && (c0 & 1) == 0;  // both lanes in one trace, 16-byte aligned
+                if (a.pad_traces && c0 + 1 == a.store_cols) pz = pa + 1;
             }
             if (B + 1 < a.total_store_cols) {
                 const uint32_t t1 = (B + 1) / a.store_cols, c1 = (B + 1) - t1 * a.store_cols;
                 pb = a.dst + (uint64_t)t1 * a.trace_lde_elems + (uint64_t)c * a.row_width + c1;
+                if (a.pad_traces && c1 + 1 == a.store_cols) pz2 = pb + 1;
             }
         }
-        if (!has_rows) pa = pb = nullptr;
+        if (!has_rows) pa = pb = pz = pz2 = nullptr;
+        if (!PACKED && a.pad_traces && a.row_width == 8) {
+            store_rows_narrow<F>(x, a, g, c, rev_o, out_shift, k_stride, threadIdx.x, blockDim.x);
+            pa = pb = nullptr;
+        }
         if (PACKED && a.store_cols != a.base_cols) {
             // One trace, padded row of S (or 2 S) elements: whole rows leave this pass. A coset owns 2^lg lanes
             // (lg >= 1: a lane pair is one 2-element slot of its row, and also writes the zero slots a multiple of the
@@ -841,6 +897,8 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
             const P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
             const uint64_t off = (uint64_t)(uint32_t)k * k_stride;  // k < 2^32 rows: one 32 x 32 -> 64 multiply
             if (tail) store_pair(pa + off + S, P2{F::zero(), F::zero()});
+            if (pz) store_row_padding<F>(pz + off, a.store_cols, (uint32_t)a.row_width);
+            if (pz2) store_row_padding<F>(pz2 + off, a.store_cols, (uint32_t)a.row_width);
             if (pair_store) {
 #ifdef WF_EXP_SKIP_STORE
                 if (*reinterpret_cast<const uint32_t *>(&v.a) == a.logN + 77777u)
@@ -993,20 +1051,25 @@ __global__ void __launch_bounds__(F::BYTES == 8 ? 1024 : 512) k_seg_last_hash(Se
             const uint32_t tid = opaque_tid();
             const uint32_t pstride = step >> hp_shift, pos0 = tid >> hp_shift, lane_a = 2 * (tid & (HP - 1));
             const uint32_t B = g * S + lane_a;  // global base column of lane a
-            T *pa = nullptr, *pb = nullptr;
+            T *pa = nullptr, *pb = nullptr, *pz = nullptr, *pz2 = nullptr;  // pz*: first padding element after a trace's last column
             bool pair = false;
             if (!MULTI) {
                 if (pos0 < D && lane_a < a.store_cols) {
                     pa = a.dst + (uint64_t)c * a.row_width + lane_a;
                     pair = lane_a + 1 < a.store_cols;
+                    if (a.pad_traces && lane_a + 2 >= a.store_cols) pz = pa + (a.store_cols - lane_a);
                 }
+            } else if (a.pad_traces && a.row_width == 8) {
+                store_rows_narrow<F>(x, a, g, c, rev_o, out_shift, k_stride, tid, blockDim.x);
             } else if (pos0 < D && B < a.total_store_cols) {
                 const uint32_t t0 = B / a.store_cols, c0 = B - t0 * a.store_cols;
                 pa = a.dst + (uint64_t)t0 * a.trace_lde_elems + (uint64_t)c * a.row_width + c0;
                 pair = c0 + 1 < a.store_cols && (c0 & 1) == 0;  // both lanes in one trace, 16-byte aligned
+                if (a.pad_traces && c0 + 1 == a.store_cols) pz = pa + 1;
                 if (B + 1 < a.total_store_cols) {
                     const uint32_t t1 = (B + 1) / a.store_cols, c1 = (B + 1) - t1 * a.store_cols;
                     pb = a.dst + (uint64_t)t1 * a.trace_lde_elems + (uint64_t)c * a.row_width + c1;
+                    if (a.pad_traces && c1 + 1 == a.store_cols) pz2 = pb + 1;
                 }
             }
             if (pa) {
@@ -1023,6 +1086,8 @@ __global__ void __launch_bounds__(F::BYTES == 8 ? 1024 : 512) k_seg_last_hash(Se
                         if (pb) pb[off] = v.b;
                     }
                     if (tail) store_pair(pa + off + S, P2{F::zero(), F::zero()});
+                    if (pz) store_row_padding<F>(pz + off, a.store_cols, (uint32_t)a.row_width);
+                    if (MULTI && pz2) store_row_padding<F>(pz2 + off, a.store_cols, (uint32_t)a.row_width);
                 }
             }
         }

@@ -444,6 +444,7 @@ struct SegDesc {
     uint32_t hash_epr = 0;
     bool *fused = nullptr;
     const TableSet *pre;
+    bool pad_traces = false;     // rows_out, unpacked: the lane with a trace's last column zeroes the rest of that row
     bool pad_in_kernel = false;  // rows_out: the last pass also writes the zero padding lanes of the rows
     uint32_t base_cols, total_base_cols, coset0;
     uint64_t row_width, trace_lde_elems;
@@ -474,6 +475,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
     a.total_base_cols = d.total_base_cols;
     a.store_cols = d.pad_in_kernel ? d.n_seg * SegCfg<F>::S : d.base_cols;
     a.total_store_cols = d.pad_in_kernel ? d.n_seg * SegCfg<F>::S : d.total_base_cols;
+    a.pad_traces = d.pad_traces ? 1 : 0;
     a.tail_pad = d.pad_in_kernel ? (uint32_t)d.row_width - d.n_seg * SegCfg<F>::S : 0;
     a.coset0 = d.coset0;
     a.rows_per_k = d.n_cosets;
@@ -773,7 +775,11 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
                                (seg_lanes == row_width || seg_lanes + SegCfg<F>::S == row_width) &&
                                (b.total_base_cols * 2 > SegCfg<F>::S ||
                                 (F::BYTES == 8 && packed_shape<F>(b.n_seg, b.total_base_cols, n_cosets, &cpr_unused, &lg_unused)));
-    if (row_width != base_cols && !pad_in_kernel)
+    // Other shapes (STARKPack traces side by side in the lanes, each with a padded row of its own): the lane holding a
+    // trace's last column writes that row's zeros.  Only coset-packed multi-trace / f128 matrices are cleared up front.
+    const bool pad_traces = row_width != base_cols && !pad_in_kernel &&
+                            !packed_shape<F>(b.n_seg, b.total_base_cols, n_cosets, &cpr_unused, &lg_unused);
+    if (row_width != base_cols && !pad_in_kernel && !pad_traces)
         HIP_TRY(hipMemsetAsync(d_lde, 0, (size_t)p->n_traces * Nrows * row_width * sizeof(T), st));
 
     SegDesc<F> d;
@@ -792,6 +798,7 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
     d.row_width = row_width;
     d.trace_lde_elems = Nrows * row_width;
     d.pad_in_kernel = pad_in_kernel;
+    d.pad_traces = pad_traces;
     bool hashed = false;  // leaves produced by the last evaluation pass itself (one segment, one trace)
     d.leaves = d_leaves;
     d.hash_epr = b.total_base_cols;  // the combined row of all traces (= base_cols for one trace)

@@ -11,7 +11,10 @@ F64, F128 = 1, 2
 
 
 @pytest.mark.parametrize("field,logR,logB,n_cols,n_traces,world", [
-    (F64, 11, 3, 8, 1, 8), (F64, 12, 3, 5, 3, 4), (F64, 8, 3, 10, 2, 2), (F128, 10, 2, 10, 2, 4), (F64, 10, 3, 8, 2, 1)])
+    (F64, 11, 3, 8, 1, 8), (F64, 12, 3, 5, 3, 4), (F64, 8, 3, 10, 2, 2), (F128, 10, 2, 10, 2, 4), (F64, 10, 3, 8, 2, 1),
+    # narrow matrices, one coset per rank (never coset-packed) and two (packed): who writes the rows' zero padding differs
+    (F64, 10, 3, 3, 1, 8), (F64, 10, 3, 1, 1, 8), (F64, 10, 3, 2, 3, 8), (F64, 10, 3, 2, 1, 4), (F64, 10, 3, 1, 3, 4),
+    (F128, 10, 3, 1, 1, 8), (F128, 10, 3, 3, 1, 4), (F128, 10, 3, 1, 2, 4), (F128, 10, 3, 5, 1, 8)])
 def test_coset_sharded_commitment(ctx, orc, capi, field, logR, logB, n_cols, n_traces, world):
     import torch
     from starkpack_winterfell_amd import shard
@@ -32,7 +35,7 @@ def test_coset_sharded_commitment(ctx, orc, capi, field, logR, logB, n_cols, n_t
         for rank in range(world):
             c0, nc = shard.cosets_of_rank(blowup, rank, world)
             d_polys = torch.empty_like(d_trace)
-            d_lde = torch.empty(n_traces * R * nc * rw * w, dtype=torch.int64, device=dev)
+            d_lde = torch.full((n_traces * R * nc * rw * w,), -1, dtype=torch.int64, device=dev)  # padding must be written
             d_leaves = torch.empty((R * nc, 32), dtype=torch.uint8, device=dev)
             ctx.trace_commit_shard_dev(params, c0, nc, d_trace.data_ptr(), d_polys.data_ptr(), d_lde.data_ptr(),
                                        d_leaves.data_ptr(), stream.cuda_stream)
