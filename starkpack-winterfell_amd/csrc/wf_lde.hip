@@ -412,15 +412,14 @@ static int seg_launch_dims(uint32_t logD, uint32_t &threads, size_t &lds) {
     return 0;
 }
 
-// One transform of n_seg segments (x n_cosets cosets).
-//   interpolation (rows_out == false): in  = [n_seg][N][S] evaluations (overwritten when N needs > 1 pass),
-//                                      out = [n_seg][N][S] coefficients, natural order, scaled by 1/N
-//   evaluation    (rows_out == true) : in  = [n_seg][N][S] coefficients (read only), work = [cosets][n_seg][N][S],
-//                                      out = row-major LDE matrices (see SegArgs)
 // Coset packing of narrow evaluations (<= S/2 base columns in one segment, an even number of cosets): 2^cpr cosets of
 // 2^lg lanes each share the lanes of a row.
 template <class F>
-static bool packed_shape(uint32_t n_seg, uint32_t total_base_cols, uint32_t n_cosets, uint32_t *cpr_log, uint32_t *lg_log) {
+static bool packed_shape(uint32_t n_seg, uint32_t total_base_cols, uint32_t base_cols, uint32_t n_cosets, uint32_t *cpr_log,
+                         uint32_t *lg_log) {
+    // several traces side by side: their rows go to different matrices, which the unpacked kernels write whole (store_rows_narrow)
+    // and hash in the same pass -- packing only pays for them while at least 3/4 of the lanes would idle (measured)
+    if (total_base_cols != base_cols && total_base_cols * 4 > SegCfg<F>::S) return false;
     if (n_seg != 1 || total_base_cols * 2 > SegCfg<F>::S || n_cosets < 2) return false;
     uint32_t lg = 0;
     while ((1u << lg) < total_base_cols) lg++;
@@ -432,6 +431,11 @@ static bool packed_shape(uint32_t n_seg, uint32_t total_base_cols, uint32_t n_co
     return true;
 }
 
+// One transform of n_seg segments (x n_cosets cosets).
+//   interpolation (rows_out == false): in  = [n_seg][N][S] evaluations (overwritten when N needs > 1 pass),
+//                                      out = [n_seg][N][S] coefficients, natural order, scaled by 1/N
+//   evaluation    (rows_out == true) : in  = [n_seg][N][S] coefficients (read only), work = [cosets][n_seg][N][S],
+//                                      out = row-major LDE matrices (see SegArgs)
 template <class F>
 struct SegDesc {
     typedef typename F::T T;
@@ -486,7 +490,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
     // lanes of a row instead of leaving them empty
     uint32_t n_groups = d.n_cosets;
     bool packed = false;
-    if (d.rows_out && packed_shape<F>(d.n_seg, d.total_base_cols, d.n_cosets, &a.cpr_log, &a.lg_log)) {
+    if (d.rows_out && packed_shape<F>(d.n_seg, d.total_base_cols, d.base_cols, d.n_cosets, &a.cpr_log, &a.lg_log)) {
         packed = true;
         n_groups = d.n_cosets >> a.cpr_log;
         a.n_cosets = n_groups;
@@ -774,11 +778,11 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
     const bool pad_in_kernel = row_width != base_cols && p->n_traces == 1 &&
                                (seg_lanes == row_width || seg_lanes + SegCfg<F>::S == row_width) &&
                                (b.total_base_cols * 2 > SegCfg<F>::S ||
-                                (F::BYTES == 8 && packed_shape<F>(b.n_seg, b.total_base_cols, n_cosets, &cpr_unused, &lg_unused)));
+                                (F::BYTES == 8 && packed_shape<F>(b.n_seg, b.total_base_cols, base_cols, n_cosets, &cpr_unused, &lg_unused)));
     // Other shapes (STARKPack traces side by side in the lanes, each with a padded row of its own): the lane holding a
     // trace's last column writes that row's zeros.  Only coset-packed multi-trace / f128 matrices are cleared up front.
     const bool pad_traces = row_width != base_cols && !pad_in_kernel &&
-                            !packed_shape<F>(b.n_seg, b.total_base_cols, n_cosets, &cpr_unused, &lg_unused);
+                            !packed_shape<F>(b.n_seg, b.total_base_cols, base_cols, n_cosets, &cpr_unused, &lg_unused);
     if (row_width != base_cols && !pad_in_kernel && !pad_traces)
         HIP_TRY(hipMemsetAsync(d_lde, 0, (size_t)p->n_traces * Nrows * row_width * sizeof(T), st));
 

@@ -250,7 +250,11 @@ def test_random_shapes(ctx, orc, capi, cfg):
     (F64, 1, 10, 3, 7, 1), (F64, 2, 10, 3, 1, 1), (F64, 3, 10, 3, 1, 1), (F64, 1, 10, 1, 3, 1), (F64, 1, 10, 2, 1, 1),
     (F64, 1, 10, 3, 11, 1), (F64, 1, 10, 3, 3, 2), (F64, 1, 10, 3, 5, 3), (F64, 1, 13, 3, 2, 1),
     (F128, 1, 10, 3, 1, 1), (F128, 1, 10, 3, 2, 1), (F128, 1, 10, 3, 3, 1), (F128, 2, 10, 3, 1, 1), (F128, 1, 10, 3, 5, 1),
-    (F128, 1, 10, 3, 3, 2)])
+    (F128, 1, 10, 3, 3, 2),
+    # narrow traces side by side (STARKPack): whole padded rows written by thread quads; the two-lane case stays packed
+    (F64, 1, 10, 3, 1, 4), (F64, 1, 10, 3, 2, 2), (F64, 1, 10, 3, 1, 2), (F64, 1, 10, 3, 1, 3), (F64, 1, 10, 3, 2, 16),
+    (F64, 1, 10, 3, 7, 3), (F64, 1, 12, 3, 3, 5), (F64, 2, 10, 3, 1, 5), (F128, 1, 10, 3, 1, 2), (F128, 1, 10, 3, 2, 5),
+    (F128, 1, 10, 3, 7, 2)])
 def test_padding_lanes_are_written(ctx, orc, capi, field, ext, logR, logB, n_cols, n_traces):
     """The zero padding of LDE rows (segments.rs:65-72) must not depend on what the caller's buffer held: the device
     form is run into an LDE buffer pre-filled with ones and compared in full, padding lanes included."""
