@@ -270,7 +270,9 @@ int wf_commitment_evaluate_polys_at(const wf_commitment *c, const void *z, uint3
 
 /* fft::evaluate_poly (math/src/fft/mod.rs:85): in place, n elements of ext_degree coordinates, natural order. */
 int wf_fft_evaluate_poly(wf_ctx *ctx, uint32_t field, uint32_t ext_degree, void *poly_inout, size_t n);
-/* fft::evaluate_poly_with_offset (mod.rs:171): result has n*blowup elements. */
+/* fft::evaluate_poly_with_offset (mod.rs:171): result has n*blowup elements; n a power of two >= 2 and blowup a power of
+ * two >= 1, as there (mod.rs:181-201) -- the periodic columns PeriodicValueTable::new evaluates are as short as 2
+ * (prover/src/constraints/periodic_table.rs:44-55), LargePolyConstraint::new uses it too (constraints/boundary.rs:426-433). */
 int wf_fft_evaluate_poly_with_offset(wf_ctx *ctx, uint32_t field, uint32_t ext_degree, const void *poly, size_t n,
                                      const uint8_t domain_offset[16], size_t blowup, void *result);
 /* fft::interpolate_poly (mod.rs:274): in place. */

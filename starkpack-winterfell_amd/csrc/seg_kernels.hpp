@@ -914,6 +914,34 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
     // Fused leaf hashing, after the row stores have been issued (they drain while the lanes hash): one lane per row
     // position (blockDim >= D/2: at most two rows per thread); the S lanes of a row are its whole 64 bytes (unused lanes
     // are zero), canonical bytes as in hash_elements (blake/mod.rs:46-59).
+    if (OUT == SEG_OUT_ROWS && PACKED && a.leaves) {
+        // coset-packed rows: the 2^lg lanes of local coset j are the message of LDE row (c << cpr) + j (its unused lanes,
+        // like the rest of the 64-byte block, are zero)
+        constexpr uint32_t WPE = F::BYTES / 4;
+        const uint32_t lg = a.lg_log, ncos = 1u << a.cpr_log;
+        for (uint32_t pos = threadIdx.x; pos < D; pos += blockDim.x) {
+            const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << (a.logN - a.logD));
+            uint32_t *leaf = a.leaves + ((uint64_t)(uint32_t)k * a.rows_per_k + ((uint64_t)c << a.cpr_log)) * 8;
+#pragma unroll 1
+            for (uint32_t j = 0; j < ncos; j++) {
+                const T *e = x + (size_t)pos * S + (j << lg);
+                uint32_t m[16], out[8];
+#pragma unroll
+                for (uint32_t w = 0; w < 16; w++) m[w] = 0;
+                elem_words<F>(e[0], &m[0]);
+                if (lg >= 1) elem_words<F>(e[1], &m[WPE]);
+                if (S >= 8 && lg >= 2) {  // (f128 rows pack at most two lanes per coset)
+                    elem_words<F>(e[2], &m[(2 * WPE) & 15]);
+                    elem_words<F>(e[3], &m[(3 * WPE) & 15]);
+                }
+                b3::set_iv(out);
+                b3::compress(out, m, 0, 0, a.hash_epr * F::BYTES, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT);
+                uint4 *dl = reinterpret_cast<uint4 *>(leaf + j * 8);
+                dl[0] = make_uint4(out[0], out[1], out[2], out[3]);
+                dl[1] = make_uint4(out[4], out[5], out[6], out[7]);
+            }
+        }
+    }
     if (OUT == SEG_OUT_ROWS && !PACKED && a.leaves) {
         constexpr uint32_t WPE = F::BYTES / 4;
         for (uint32_t pos = threadIdx.x; pos < D; pos += blockDim.x) {

@@ -563,11 +563,15 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         if (rc) return rc;
         const uint64_t grid = (uint64_t)n_groups * d.n_seg * a.O;
         if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
-        const bool may_fuse = d.rows_out && d.leaves && !packed && getenv("WF_EXP_NO_FUSED_HASH") == nullptr;
+        const bool fuse_on = d.rows_out && d.leaves && getenv("WF_EXP_NO_FUSED_HASH") == nullptr;
+        const bool may_fuse = fuse_on && !packed;
         const uint64_t tickets = (uint64_t)d.n_cosets * a.O;
         const bool persistent = may_fuse && !single && d.n_seg <= 16 && threads * 2 == (1u << a.logD) && tickets % 8 == 0 &&
                                 getenv("WF_EXP_NO_PERSISTENT") == nullptr;
-        const bool fuse = persistent || (may_fuse && d.n_seg == 1 && d.total_base_cols == d.base_cols);
+        // coset-packed rows are hashed in the pass where the separate kernel is the slower one (measured): f128, four
+        // lanes per coset, or rows gathered from several traces; one- and two-lane f64 rows keep k_hash_rows
+        const bool fuse_packed = fuse_on && packed && (F::BYTES == 16 || a.lg_log >= 2 || d.total_base_cols != d.base_cols);
+        const bool fuse = persistent || (may_fuse && d.n_seg == 1 && d.total_base_cols == d.base_cols) || fuse_packed;
         a.leaves = fuse ? (uint32_t *)d.leaves : nullptr;
         a.hash_epr = d.hash_epr;
         if (d.fused) *d.fused = fuse;
@@ -1661,10 +1665,19 @@ int wf_fft_evaluate_poly_with_offset(wf_ctx *ctx, uint32_t field, uint32_t ext, 
     int rc = check_fft_args(ctx, field, ext, poly, n, &l);
     if (rc) return rc;
     if (!result || !domain_offset) return fail(WF_ERR_ARG, "null argument");
-    if (blowup < 2 || (blowup & (blowup - 1))) return fail(WF_ERR_BLOWUP, "blowup must be a power of two >= 2");
+    // preconditions of the reference function itself (fft/mod.rs:181-201), not those of a trace: any power-of-two size
+    // from 2 (periodic columns, periodic_table.rs:44-55) and any power-of-two blowup from 1
+    if (blowup < 1 || (blowup & (blowup - 1))) return fail(WF_ERR_BLOWUP, "blowup must be a power of two");
     uint32_t lb = 0;
     while (((size_t)1 << lb) < blowup) lb++;
-    if (l < 3) return fail(WF_ERR_TRACE_LENGTH, "polynomial size must be at least 8");
+    if (l < 1) return fail(WF_ERR_TRACE_LENGTH, "polynomial size must be at least 2");
+    if (lb > 7) return fail(WF_ERR_BLOWUP, "blowup must be at most 128");
+    const uint32_t adicity = field == WF_FIELD_F64 ? F64::TWO_ADICITY : F128::TWO_ADICITY;
+    if (l + lb > adicity) return fail(WF_ERR_DOMAIN, "no multiplicative subgroup of size 2^%u in this field", l + lb);
+    u128 off;
+    memcpy(&off, domain_offset, 16);
+    if (off == 0 || off >= (field == WF_FIELD_F64 ? (u128)F64::P : F128::P()))
+        return fail(WF_ERR_OFFSET, "domain offset must be a non-zero field element");
     wf_params p;
     memset(&p, 0, sizeof(p));
     p.field = field;
@@ -1675,16 +1688,14 @@ int wf_fft_evaluate_poly_with_offset(wf_ctx *ctx, uint32_t field, uint32_t ext, 
     p.n_traces = 1;
     p.digest_bytes = 32;
     memcpy(p.domain_offset, domain_offset, 16);
-    if (lb > 7) return fail(WF_ERR_BLOWUP, "blowup must be at most 128");
-    rc = check_params(&p, true);
-    if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t eb = wf_elem_bytes(field), ldeb = wf_lde_bytes(&p), colb = wf_column_bytes(&p);
     if ((rc = ensure(ctx->io[0], colb))) return rc;
     if ((rc = ensure(ctx->io[2], ldeb))) return rc;
     hipStream_t st = ctx->stream;
     HIP_TRY(hipMemcpyAsync(ctx->io[0].p, poly, colb, hipMemcpyHostToDevice, st));
-    rc = wf_constraint_commit_dev(ctx, &p, ctx->io[0].p, ctx->io[2].p, nullptr, nullptr, st);
+    rc = field == WF_FIELD_F64 ? constraint_commit_dev<F64>(ctx, &p, ctx->io[0].p, ctx->io[2].p, nullptr, nullptr, st)
+                               : constraint_commit_dev<F128>(ctx, &p, ctx->io[0].p, ctx->io[2].p, nullptr, nullptr, st);
     if (rc) return rc;
     const size_t rows = n * blowup, rw = wf_row_width(&p);
     HIP_TRY(hipMemcpy2DAsync(result, ext * eb, ctx->io[2].p, rw * eb, ext * eb, rows, hipMemcpyDeviceToHost, st));
