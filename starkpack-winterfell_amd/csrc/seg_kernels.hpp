@@ -604,6 +604,30 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
     }
 }
 
+// Row stores of f128 segments: a lane pair is 32 bytes and goes out as two 16-byte store instructions that each cover
+// half of every pair; one element per thread makes each instruction write whole 64-byte runs (the S lanes of a row).
+// `tail`: this segment also writes the S zero elements that pad the row (SegArgs::tail_pad, one trace); `pad`: the lane
+// with a trace's last column also writes the zeros that pad that trace's row (SegArgs::pad_traces).
+template <class F>
+__device__ __forceinline__ void store_rows_by_element(const typename F::T *x, const SegArgs<F> &a, uint32_t g, uint32_t c,
+                                                      uint64_t rev_o, uint32_t out_shift, uint32_t k_stride, uint32_t tid,
+                                                      uint32_t n_threads, bool tail, bool pad) {
+    using T = typename F::T;
+    constexpr uint32_t S = SegCfg<F>::S;
+    const uint32_t D = 1u << a.logD, e = tid & (S - 1), B = g * S + e;
+    if (B >= a.total_store_cols) return;
+    const uint32_t t = B / a.store_cols, col = B - t * a.store_cols;
+    T *pa = a.dst + (uint64_t)t * a.trace_lde_elems + (uint64_t)c * a.row_width + col;
+    const uint32_t n_pad = pad && col + 1 == a.store_cols ? (uint32_t)a.row_width - a.store_cols : 0;
+    for (uint32_t pos = tid / S; pos < D; pos += n_threads / S) {
+        const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << out_shift);
+        const uint64_t off = (uint64_t)(uint32_t)k * k_stride;
+        pa[off] = x[pos * S + e];
+        if (tail) pa[off + S] = F::zero();
+        for (uint32_t z = 1; z <= n_pad; z++) pa[off + z] = F::zero();
+    }
+}
+
 // Row stores of the last evaluation pass for narrow side-by-side traces (STARKPack: several traces in the lanes of a
 // segment, each with an LDE matrix of its own whose rows are padded to 8 elements).  A lane pair storing its own 16
 // bytes would touch a different 64-byte row in every lane: four consecutive threads write one whole row instead -- the
@@ -859,6 +883,10 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
         if (!PACKED && a.pad_traces && a.row_width == 8) {
             store_rows_narrow<F>(x, a, g, c, rev_o, out_shift, k_stride, threadIdx.x, blockDim.x);
             pa = pb = nullptr;
+        } else if (!PACKED && F::BYTES == 16) {
+            store_rows_by_element<F>(x, a, g, c, rev_o, out_shift, k_stride, threadIdx.x, blockDim.x,
+                                     a.tail_pad && g + 1 == a.n_seg, a.pad_traces);
+            pa = pb = nullptr;
         }
         if (PACKED && a.store_cols != a.base_cols) {
             // One trace, padded row of S (or 2 S) elements: whole rows leave this pass. A coset owns 2^lg lanes
@@ -891,7 +919,7 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
             }
             pa = pb = nullptr;
         }
-        const bool tail = !PACKED && a.tail_pad && g + 1 == a.n_seg;  // (single trace: every lane has its pa)
+        const bool tail = !PACKED && F::BYTES == 16 && a.tail_pad && g + 1 == a.n_seg;  // (single trace: every lane has its pa)
         for (uint32_t pj = 0; (pa || pb) && pj < D; pj += pstride) {
             const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, a.logD)) << out_shift);
             const P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
@@ -984,7 +1012,7 @@ __device__ __forceinline__ uint32_t opaque_tid() {
 }
 
 // MULTI = false: one segment of one trace (the bench workload) -- no chaining values to carry, one lane pair mapping.
-template <class F, bool MULTI>
+template <class F, bool MULTI, bool PADT = false>  // PADT: SegArgs::pad_traces (kept out of the other instantiations' registers)
 __global__ void __launch_bounds__(F::BYTES == 8 ? 1024 : 512) k_seg_last_hash(SegArgs<F> a) {  // f128 tiles: D <= 2^10
     typedef typename F::T T;
     typedef Pair<T> P2;
@@ -1081,28 +1109,30 @@ __global__ void __launch_bounds__(F::BYTES == 8 ? 1024 : 512) k_seg_last_hash(Se
             const uint32_t B = g * S + lane_a;  // global base column of lane a
             T *pa = nullptr, *pb = nullptr, *pz = nullptr, *pz2 = nullptr;  // pz*: first padding element after a trace's last column
             bool pair = false;
-            if (!MULTI) {
+            if (F::BYTES == 16 && !(PADT && a.row_width == 8)) {
+                store_rows_by_element<F>(x, a, g, c, rev_o, out_shift, k_stride, tid, blockDim.x, a.tail_pad && g + 1 == a.n_seg, PADT);
+            } else if (!MULTI) {
                 if (pos0 < D && lane_a < a.store_cols) {
                     pa = a.dst + (uint64_t)c * a.row_width + lane_a;
                     pair = lane_a + 1 < a.store_cols;
-                    if (a.pad_traces && lane_a + 2 >= a.store_cols) pz = pa + (a.store_cols - lane_a);
+                    if (PADT && lane_a + 2 >= a.store_cols) pz = pa + (a.store_cols - lane_a);
                 }
-            } else if (a.pad_traces && a.row_width == 8) {
+            } else if (PADT && a.row_width == 8) {
                 store_rows_narrow<F>(x, a, g, c, rev_o, out_shift, k_stride, tid, blockDim.x);
             } else if (pos0 < D && B < a.total_store_cols) {
                 const uint32_t t0 = B / a.store_cols, c0 = B - t0 * a.store_cols;
                 pa = a.dst + (uint64_t)t0 * a.trace_lde_elems + (uint64_t)c * a.row_width + c0;
                 pair = c0 + 1 < a.store_cols && (c0 & 1) == 0;  // both lanes in one trace, 16-byte aligned
-                if (a.pad_traces && c0 + 1 == a.store_cols) pz = pa + 1;
+                if (PADT && c0 + 1 == a.store_cols) pz = pa + 1;
                 if (B + 1 < a.total_store_cols) {
                     const uint32_t t1 = (B + 1) / a.store_cols, c1 = (B + 1) - t1 * a.store_cols;
                     pb = a.dst + (uint64_t)t1 * a.trace_lde_elems + (uint64_t)c * a.row_width + c1;
-                    if (a.pad_traces && c1 + 1 == a.store_cols) pz2 = pb + 1;
+                    if (PADT && c1 + 1 == a.store_cols) pz2 = pb + 1;
                 }
             }
             if (pa) {
                 const uint32_t k0 = seg_digit_reverse<F>(pos0, a.logD);
-                const bool tail = a.tail_pad && g + 1 == a.n_seg;  // (single trace: every lane has its pa)
+                const bool tail = F::BYTES == 16 && a.tail_pad && g + 1 == a.n_seg;  // (single trace: every lane has its pa)
                 for (uint32_t pj = 0; pj < D; pj += pstride) {
                     const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, a.logD)) << out_shift);
                     const P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
@@ -1114,8 +1144,8 @@ __global__ void __launch_bounds__(F::BYTES == 8 ? 1024 : 512) k_seg_last_hash(Se
                         if (pb) pb[off] = v.b;
                     }
                     if (tail) store_pair(pa + off + S, P2{F::zero(), F::zero()});
-                    if (pz) store_row_padding<F>(pz + off, a.store_cols, (uint32_t)a.row_width);
-                    if (MULTI && pz2) store_row_padding<F>(pz2 + off, a.store_cols, (uint32_t)a.row_width);
+                    if (PADT && pz) store_row_padding<F>(pz + off, a.store_cols, (uint32_t)a.row_width);
+                    if (PADT && MULTI && pz2) store_row_padding<F>(pz2 + off, a.store_cols, (uint32_t)a.row_width);
                 }
             }
         }

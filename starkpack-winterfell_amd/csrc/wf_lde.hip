@@ -578,20 +578,17 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         prof_mark(ctx, st, tag_l);
         if (persistent) {
             const bool multi = d.n_seg > 1 || d.total_base_cols != d.base_cols;
-            if (lds > 64 * 1024) {
-                HIP_TRY(hipFuncSetAttribute((const void *)k_seg_last_hash<F, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                HIP_TRY(hipFuncSetAttribute((const void *)k_seg_last_hash<F, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            }
+            const void *kern = multi ? (a.pad_traces ? (const void *)k_seg_last_hash<F, true, true> : (const void *)k_seg_last_hash<F, true, false>)
+                                     : (a.pad_traces ? (const void *)k_seg_last_hash<F, false, true> : (const void *)k_seg_last_hash<F, false, false>);
+            if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             const size_t lds_p = lds - ((size_t)1 << a.logD) * sizeof(T) + 16;  // no `aux` table; two ticket words
             const uint64_t resident = (uint64_t)ctx->num_cus * std::max<size_t>(1, (160 * 1024) / lds_p);
             int rcq = ensure(ctx->tickets, 64);
             if (rcq) return rcq;
             HIP_TRY(hipMemsetAsync(ctx->tickets.p, 0, 32, st));
             a.tile_counters = (uint32_t *)ctx->tickets.p;
-            if (multi)
-                hipLaunchKernelGGL((k_seg_last_hash<F, true>), dim3((uint32_t)std::min<uint64_t>(tickets, resident)), dim3(threads), lds_p, st, a);
-            else
-                hipLaunchKernelGGL((k_seg_last_hash<F, false>), dim3((uint32_t)std::min<uint64_t>(tickets, resident)), dim3(threads), lds_p, st, a);
+            void *kargs[] = {&a};
+            HIP_TRY(hipLaunchKernel(kern, dim3((uint32_t)std::min<uint64_t>(tickets, resident)), dim3(threads), kargs, lds_p, st));
         } else if (d.rows_out && packed)
             hipLaunchKernelGGL((k_seg_last<F, SEG_OUT_ROWS, true>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
         else if (d.rows_out)
