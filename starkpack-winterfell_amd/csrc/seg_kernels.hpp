@@ -148,6 +148,8 @@ struct SegArgs {
     // is not read back by k_hash_rows (RowMatrix::commit_to_rows, row_matrix.rs:183-203)
     uint32_t *leaves;          // nullptr: no fused hashing
     uint32_t hash_epr;         // elements of a row that are hashed (elements_per_row)
+    uint32_t *chunk_cvs;       // k_seg_last_hash<.., CHUNKED>: [LDE row][n_chunks][8] chunk chaining values (rows > 1024 bytes)
+    uint32_t n_chunks;         //   ceil(n_seg / 16): a BLAKE3 chunk is 16 blocks = 16 segments of a row
     uint32_t *tile_counters;   // k_seg_last_hash: 8 zeroed counters, one per XCD (dynamic tile assignment)
 };
 
@@ -1012,7 +1014,9 @@ __device__ __forceinline__ uint32_t opaque_tid() {
 }
 
 // MULTI = false: one segment of one trace (the bench workload) -- no chaining values to carry, one lane pair mapping.
-template <class F, bool MULTI, bool PADT = false>  // PADT: SegArgs::pad_traces (kept out of the other instantiations' registers)
+// CHUNKED (with MULTI): rows longer than one BLAKE3 chunk -- a ticket is (coset, row block, chunk): the work-group walks the
+// 16 segments of that chunk and writes the rows' chunk chaining values; k_hash_merge_chunks folds them into the leaves.
+template <class F, bool MULTI, bool PADT = false, bool CHUNKED = false>  // PADT: SegArgs::pad_traces (kept out of the other instantiations' registers)
 __global__ void __launch_bounds__(F::BYTES == 8 ? 1024 : 512) k_seg_last_hash(SegArgs<F> a) {  // f128 tiles: D <= 2^10
     typedef typename F::T T;
     typedef Pair<T> P2;
@@ -1023,20 +1027,27 @@ __global__ void __launch_bounds__(F::BYTES == 8 ? 1024 : 512) k_seg_last_hash(Se
     const uint32_t D = 1u << a.logD;
     T *x = reinterpret_cast<T *>(smem_raw);
     T *twd = x + (size_t)D * S;
-    const uint64_t total = (uint64_t)a.n_cosets * a.O;  // tickets: (coset, row block)
+    const uint32_t n_chunks = CHUNKED ? a.n_chunks : 1;
+    const uint64_t total = (uint64_t)a.n_cosets * a.O * n_chunks;  // tickets: (coset, row block[, chunk])
     const uint64_t seg_elems = ((uint64_t)1 << a.logN) * S;
     const uint32_t step = blockDim.x;
     const uint32_t out_shift = a.logN - a.logD;
     const uint32_t k_stride = a.rows_per_k * (uint32_t)a.row_width;  // < 2^19
-    const uint32_t hash_bytes = a.hash_epr * F::BYTES;             // <= 1024: one chunk
+    const uint32_t hash_bytes = a.hash_epr * F::BYTES;             // <= 1024 (one chunk) unless CHUNKED
 
     for (uint32_t e = threadIdx.x; e < D; e += step) twd[e] = a.digit_tw[e];
 
-    auto decode = [&](uint64_t t, uint32_t &c, uint64_t &o, uint64_t &rev_o) {
+    auto decode = [&](uint64_t t, uint32_t &c, uint64_t &o, uint64_t &rev_o, uint32_t &ch) {
         uint64_t bid = xcd_group_index(t, total);  // coset fastest, 8 consecutive tickets on one XCD
         const uint32_t b32 = (uint32_t)bid, q32 = b32 / a.n_cosets;  // grids are below 2^31
         c = b32 - q32 * a.n_cosets;
         o = q32;
+        ch = 0;
+        if (CHUNKED) {  // chunk next-fastest: the chunks of one row block follow each other on an XCD
+            const uint32_t q2 = q32 / n_chunks;
+            ch = q32 - q2 * n_chunks;
+            o = q2;
+        }
         rev_o = 0;
         uint32_t bits = 0;
         for (uint32_t q = 0; q < a.n_prev; q++) bits += a.prev_log[q];
@@ -1064,10 +1075,11 @@ __global__ void __launch_bounds__(F::BYTES == 8 ? 1024 : 512) k_seg_last_hash(Se
     };
     uint64_t ticket = next_ticket(0);
     if (ticket >= per_xcd) return;
-    uint32_t c, g = 0;  // g stays 0 without MULTI
+    uint32_t c, g = 0, ch = 0;  // g stays 0 without MULTI, ch without CHUNKED
     uint64_t o, rev_o;
-    decode(ticket * 8 + xcd, c, o, rev_o);
-    const T *src = tile_src(c, o, 0);
+    decode(ticket * 8 + xcd, c, o, rev_o, ch);
+    g = 16 * ch;
+    const T *src = tile_src(c, o, g);
     // blockDim == D / 2 (the launcher guarantees it): the tile is one contiguous run of 4 * D 16-byte chunks (a row is 64
     // bytes for either field), eight per thread, copied to the same offsets of `x`.  Native vector registers rather
     // than arrays or structs for everything carried around the tile loop: those would live in scratch memory.
@@ -1153,13 +1165,14 @@ __global__ void __launch_bounds__(F::BYTES == 8 ? 1024 : 512) k_seg_last_hash(Se
         // the next tile -- the next segment of this row block, or the first one of a new ticket -- starts its way into
         // registers; it lands while the leaves are hashed
         bool more = true;
-        uint32_t cn = c, gn = g + 1;
+        uint32_t cn = c, gn = g + 1, chn = ch;
         uint64_t on = o, rev_on = rev_o;
-        if (!MULTI || gn == a.n_seg) {
-            gn = 0;
+        const uint32_t g_end = CHUNKED ? min(16 * ch + 16, a.n_seg) : a.n_seg;  // one past the last segment of this ticket
+        if (!MULTI || gn == g_end) {
             ticket = next_ticket(1);
             more = ticket < per_xcd;
-            if (more) decode(ticket * 8 + xcd, cn, on, rev_on);
+            if (more) decode(ticket * 8 + xcd, cn, on, rev_on, chn);
+            gn = 16 * chn;
         }
         if (more) {
             src = tile_src(cn, on, gn);
@@ -1170,9 +1183,10 @@ __global__ void __launch_bounds__(F::BYTES == 8 ? 1024 : 512) k_seg_last_hash(Se
         // of a tile row are its 64 message bytes (lanes past the last column are zero), canonical as in hash_elements
         {
             const uint32_t tid = opaque_tid();
-            const bool last = !MULTI || g + 1 == a.n_seg;
-            const uint32_t flags = (g == 0 ? (uint32_t)b3::CHUNK_START : 0u) | (last ? (uint32_t)(b3::CHUNK_END | b3::ROOT) : 0u);
-            const uint32_t blen = last ? hash_bytes - 64u * g : 64u;
+            const bool last = !MULTI || g + 1 == g_end, first = g == 16 * ch;
+            const uint32_t flags = (first ? (uint32_t)b3::CHUNK_START : 0u) |
+                                   (last ? (uint32_t)(CHUNKED ? b3::CHUNK_END : b3::CHUNK_END | b3::ROOT) : 0u);
+            const uint32_t blen = min(64u, hash_bytes - 64u * g);
 #pragma unroll 1  // one compression in flight: interleaving the two rows measured slower (and doubles the code)
             for (uint32_t r = 0; r < 2; r++) {
                 const uint32_t pos = tid + r * step;
@@ -1184,18 +1198,19 @@ __global__ void __launch_bounds__(F::BYTES == 8 ? 1024 : 512) k_seg_last_hash(Se
                 uint32_t m[16], cv[8];
 #pragma unroll
                 for (uint32_t e = 0; e < S; e++) elem_words<F>(ev[e], &m[e * WPE]);
-                if (!MULTI || g == 0) {
+                if (!MULTI || first) {
                     b3::set_iv(cv);
                 } else {
                     const uint4 lo = r == 0 ? cva0 : cvb0, hi = r == 0 ? cva1 : cvb1;
                     cv[0] = lo.x; cv[1] = lo.y; cv[2] = lo.z; cv[3] = lo.w;
                     cv[4] = hi.x; cv[5] = hi.y; cv[6] = hi.z; cv[7] = hi.w;
                 }
-                b3::compress(cv, m, 0, 0, blen, flags);
+                b3::compress(cv, m, ch, 0, blen, flags);  // counter = chunk index
                 const uint4 lo = make_uint4(cv[0], cv[1], cv[2], cv[3]), hi = make_uint4(cv[4], cv[5], cv[6], cv[7]);
                 if (last) {
                     const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << out_shift);
-                    uint4 *dl = reinterpret_cast<uint4 *>(a.leaves + ((uint64_t)(uint32_t)k * a.rows_per_k + c) * 8);
+                    const uint64_t row = (uint64_t)(uint32_t)k * a.rows_per_k + c;
+                    uint4 *dl = reinterpret_cast<uint4 *>(CHUNKED ? a.chunk_cvs + (row * n_chunks + ch) * 8 : a.leaves + row * 8);
                     dl[0] = lo;
                     dl[1] = hi;
                 } else if (r == 0) {
@@ -1211,6 +1226,7 @@ __global__ void __launch_bounds__(F::BYTES == 8 ? 1024 : 512) k_seg_last_hash(Se
         __syncthreads();  // x is rewritten by the next tile
         c = cn;
         g = MULTI ? gn : 0;
+        ch = chn;
         o = on;
         rev_o = rev_on;
     }

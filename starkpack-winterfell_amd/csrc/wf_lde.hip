@@ -565,8 +565,13 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
         const bool fuse_on = d.rows_out && d.leaves && getenv("WF_EXP_NO_FUSED_HASH") == nullptr;
         const bool may_fuse = fuse_on && !packed;
-        const uint64_t tickets = (uint64_t)d.n_cosets * a.O;
-        const bool persistent = may_fuse && !single && d.n_seg <= 16 && threads * 2 == (1u << a.logD) && tickets % 8 == 0 &&
+        // rows of more than 16 segments (one BLAKE3 chunk) are fused chunk by chunk: the pass leaves chunk chaining values
+        const bool chunked = d.n_seg > 16 && getenv("WF_EXP_NO_CHUNKED") == nullptr;
+        const uint32_t n_chunks = chunked ? (d.n_seg + 15) / 16 : 1;
+        const uint64_t tickets = (uint64_t)d.n_cosets * a.O * n_chunks;
+        const uint64_t launch_rows = (uint64_t)d.n_cosets << d.logN;
+        const bool persistent = may_fuse && !single && (d.n_seg <= 16 || chunked) && threads * 2 == (1u << a.logD) &&
+                                tickets % 8 == 0 && tickets < (1ull << 31) && launch_rows * n_chunks * 32 < (1ull << 40) &&
                                 getenv("WF_EXP_NO_PERSISTENT") == nullptr;
         // coset-packed rows are hashed in the pass where the separate kernel is the slower one (measured): f128, four
         // lanes per coset, or rows gathered from several traces; one- and two-lane f64 rows keep k_hash_rows
@@ -578,8 +583,16 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         prof_mark(ctx, st, tag_l);
         if (persistent) {
             const bool multi = d.n_seg > 1 || d.total_base_cols != d.base_cols;
-            const void *kern = multi ? (a.pad_traces ? (const void *)k_seg_last_hash<F, true, true> : (const void *)k_seg_last_hash<F, true, false>)
-                                     : (a.pad_traces ? (const void *)k_seg_last_hash<F, false, true> : (const void *)k_seg_last_hash<F, false, false>);
+            const void *kern =
+                chunked ? (a.pad_traces ? (const void *)k_seg_last_hash<F, true, true, true> : (const void *)k_seg_last_hash<F, true, false, true>)
+                : multi ? (a.pad_traces ? (const void *)k_seg_last_hash<F, true, true> : (const void *)k_seg_last_hash<F, true, false>)
+                        : (a.pad_traces ? (const void *)k_seg_last_hash<F, false, true> : (const void *)k_seg_last_hash<F, false, false>);
+            if (chunked) {
+                int rcc = ensure(ctx->hash_tmp, (size_t)launch_rows * n_chunks * 32);
+                if (rcc) return rcc;
+                a.chunk_cvs = (uint32_t *)ctx->hash_tmp.p;
+                a.n_chunks = n_chunks;
+            }
             if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             const size_t lds_p = lds - ((size_t)1 << a.logD) * sizeof(T) + 16;  // no `aux` table; two ticket words
             const uint64_t resident = (uint64_t)ctx->num_cus * std::max<size_t>(1, (160 * 1024) / lds_p);
@@ -589,6 +602,11 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             a.tile_counters = (uint32_t *)ctx->tickets.p;
             void *kargs[] = {&a};
             HIP_TRY(hipLaunchKernel(kern, dim3((uint32_t)std::min<uint64_t>(tickets, resident)), dim3(threads), kargs, lds_p, st));
+            if (chunked) {
+                HIP_TRY(hipGetLastError());
+                hipLaunchKernelGGL(k_hash_merge_chunks, dim3((uint32_t)((launch_rows + 255) / 256)), dim3(256), 0, st,
+                                   (const uint32_t *)ctx->hash_tmp.p, n_chunks, launch_rows, (uint32_t *)d.leaves);
+            }
         } else if (d.rows_out && packed)
             hipLaunchKernelGGL((k_seg_last<F, SEG_OUT_ROWS, true>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
         else if (d.rows_out)

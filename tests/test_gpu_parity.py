@@ -93,6 +93,14 @@ CASES = [
     (F64, 1, 12, 7, 8, 1),     # blowup 128: 128 cosets per row block
     (F64, 1, 11, 1, 7, 1),     # blowup 2: two cosets
     (F64, 3, 11, 3, 2, 1),     # cubic extension: 6 base columns
+    # two passes, rows longer than one BLAKE3 chunk: the persistent last pass leaves chunk chaining values
+    (F64, 1, 12, 1, 200, 1),   # 1600-byte rows: 25 segments, chunks of 16 + 9 blocks
+    (F64, 1, 12, 2, 255, 1),   # 2040 bytes: the last block of the second chunk is short (56 bytes)
+    (F64, 1, 12, 1, 17, 9),    # 9 packed traces x 17 columns: 153 lanes, padded rows of 24 elements each
+    (F64, 1, 12, 1, 3, 50),    # 50 narrow traces: whole-row stores + chunked hashing
+    (F128, 1, 11, 1, 10, 20),  # 20 packed f128 do_work traces: 50 segments, 3200-byte rows (4 chunks)
+    (F128, 1, 11, 2, 70, 1),   # 1120-byte rows: 18 segments, the second chunk has two blocks
+    (F64, 2, 12, 1, 65, 1),    # 130 base columns (quadratic extension): 17 segments -> a one-block second chunk
 ]
 
 
