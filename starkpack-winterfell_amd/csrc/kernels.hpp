@@ -424,6 +424,58 @@ __global__ void __launch_bounds__(256) k_hash_merge_chunks(const uint32_t *__res
     dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
 }
 
+// The same fold with 16 lanes per row (16 rows per work-group): a row's chaining values sit in LDS and are merged level
+// by level in place -- adjacent pairs, an odd last one carried up, which is BLAKE3's left-full tree.  One lane per row
+// (above) leaves the chip idle when there are few long rows: 8192 rows of 80 chunks are 79 dependent compressions on 128
+// waves.  Dynamic LDS: 16 * n * 32 bytes (the launcher uses this kernel for n <= 128).
+__global__ void __launch_bounds__(256) k_hash_merge_chunks_par(const uint32_t *__restrict__ cvs, uint32_t n, uint64_t n_rows,
+                                                               uint32_t *__restrict__ leaves) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char merge_smem[];
+    const uint32_t lane = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const uint64_t row = (uint64_t)blockIdx.x * 16 + r;
+    const bool live = row < n_rows;
+    uint4 *my = reinterpret_cast<uint4 *>(merge_smem) + (size_t)r * n * 2;  // chaining value k = my[2k], my[2k + 1]
+    if (live) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(cvs + row * n * 8);
+        for (uint32_t i = lane; i < 2 * n; i += 16) my[i] = src[i];
+    }
+    __syncthreads();
+    for (uint32_t cnt = n; cnt > 1;) {  // cnt is the same for every row: the barriers below are uniform
+        const uint32_t pairs = cnt >> 1, odd = cnt & 1;
+        for (uint32_t i0 = 0; i0 < pairs; i0 += 16) {
+            const uint32_t i = i0 + lane;
+            const bool act = live && i < pairs;
+            uint32_t m[16], cv[8];
+            if (act) {
+                const uint4 q0 = my[4 * i], q1 = my[4 * i + 1], q2 = my[4 * i + 2], q3 = my[4 * i + 3];
+                m[0] = q0.x; m[1] = q0.y; m[2] = q0.z; m[3] = q0.w;
+                m[4] = q1.x; m[5] = q1.y; m[6] = q1.z; m[7] = q1.w;
+                m[8] = q2.x; m[9] = q2.y; m[10] = q2.z; m[11] = q2.w;
+                m[12] = q3.x; m[13] = q3.y; m[14] = q3.z; m[15] = q3.w;
+                b3::set_iv(cv);
+                b3::compress(cv, m, 0, 0, 64, b3::PARENT | (cnt == 2 ? (uint32_t)b3::ROOT : 0u));
+            }
+            __syncthreads();  // a round's outputs (slots i0..i0+15) overlap only its own inputs (2 i0..2 i0+31), and only for i0 = 0
+            if (act) {
+                my[2 * i] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+                my[2 * i + 1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+            }
+        }
+        if (odd && live && lane == 0) {  // the unpaired last value moves up unchanged (every pair of this level has been read)
+            const uint4 lo = my[2 * (cnt - 1)], hi = my[2 * (cnt - 1) + 1];
+            my[2 * pairs] = lo;
+            my[2 * pairs + 1] = hi;
+        }
+        __syncthreads();
+        cnt = pairs + odd;
+    }
+    if (live && lane == 0) {
+        uint4 *dst = reinterpret_cast<uint4 *>(leaves + row * 8);
+        dst[0] = my[0];
+        dst[1] = my[1];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Merkle levels (build_merkle_nodes, crypto/src/merkle/mod.rs:350-374): each work-group folds 2*blockDim children
 // through up to `levels` levels, keeping the intermediate digests in LDS and writing every level to `nodes`.

@@ -101,6 +101,11 @@ CASES = [
     (F128, 1, 11, 1, 10, 20),  # 20 packed f128 do_work traces: 50 segments, 3200-byte rows (4 chunks)
     (F128, 1, 11, 2, 70, 1),   # 1120-byte rows: 18 segments, the second chunk has two blocks
     (F64, 2, 12, 1, 65, 1),    # 130 base columns (quadratic extension): 17 segments -> a one-block second chunk
+    # few, very long rows: chunk chaining values merged by 16 lanes per row (k_hash_merge_chunks_par, 32..128 chunks)
+    (F128, 1, 3, 3, 10, 512),  # the reference's do_work default width: 512 packed traces, 80 chunks per row
+    (F128, 1, 3, 1, 10, 206),  # 33 chunks: an unpaired chaining value is carried up at several levels
+    (F128, 1, 4, 1, 10, 250),  # 40 chunks
+    (F64, 1, 4, 1, 255, 17),   # 34 chunks of f64 rows
 ]
 
 
