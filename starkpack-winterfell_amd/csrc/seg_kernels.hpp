@@ -678,7 +678,7 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
     const uint32_t D = 1u << a.logD;
     T *x = reinterpret_cast<T *>(smem_raw);
     T *twd = x + (size_t)D * S;
-    T *aux = twd + D;
+    T *aux = twd;  // input factors of a single-pass evaluation: same LDS as the twiddles, which are written after the fill
 
     // coset fastest: with SEG_OUT_ROWS the cosets of one row block write the 64-byte pieces of the same rows
     uint64_t bid = xcd_group_index(blockIdx.x, gridDim.x);
@@ -775,8 +775,10 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
 #pragma unroll
     for (uint32_t q = 0; q < 2; q++) {
         if (threadIdx.x + q * blockDim.x < D) {
-            twd[kq[q]] = tw_q[q];
-            if (scale_in) aux[kq[q]] = F::mul(fi_a[q], fi_b[q]);
+            if (scale_in)
+                aux[kq[q]] = F::mul(fi_a[q], fi_b[q]);  // (in the twiddles' place until the tile is filled)
+            else
+                twd[kq[q]] = tw_q[q];
         }
     }
     __syncthreads();
@@ -822,6 +824,12 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
             WF_FILL_ITEM(3, r6, r7);
         }
 #undef WF_FILL_ITEM
+    }
+    if (scale_in) {  // the input factors have been consumed: the digit twiddles take their place
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < 2; q++)
+            if (threadIdx.x + q * blockDim.x < D) twd[kq[q]] = tw_q[q];
     }
     __syncthreads();
 #ifndef WF_EXP_SKIP_NTT

@@ -393,9 +393,11 @@ static int digit_table(wf_ctx *ctx, uint32_t logD, bool inverse, const typename 
 }
 
 template <class F>
-static int seg_launch_dims(uint32_t logD, uint32_t &threads, size_t &lds) {
+static int seg_launch_dims(uint32_t logD, uint32_t &threads, size_t &lds, bool last_pass) {
     const size_t D = (size_t)1 << logD;
-    lds = (D * SegCfg<F>::S + 2 * D) * sizeof(typename F::T);
+    // tile + digit twiddles (+ the factor table of a strided pass; a last pass keeps its input factors where the
+    // twiddles go afterwards: a 2^10-row f128 tile is 80 KiB, two work-groups per CU)
+    lds = (D * SegCfg<F>::S + (last_pass ? 1 : 2) * D) * sizeof(typename F::T);
     if (lds > 160 * 1024) return fail(WF_ERR_ARG, "internal: pass needs %zu bytes of LDS", lds);
     // one work item of the widest round per thread (radix-16 on 8 lanes for f64, radix-4 on lane pairs for f128: D/2
     // items either way), so that no wave idles through the transform rounds; a 2^11-row f64 tile fills the LDS of a CU
@@ -524,7 +526,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         }
         uint32_t threads;
         size_t lds;
-        rc = seg_launch_dims<F>(a.logD, threads, lds);
+        rc = seg_launch_dims<F>(a.logD, threads, lds, false);
         if (rc) return rc;
         const uint64_t grid = (uint64_t)n_groups * d.n_seg * a.O * a.I;
         if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
@@ -561,7 +563,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         //  - else not at all: k_hash_rows reads the LDE back.
         uint32_t threads;
         size_t lds;
-        rc = seg_launch_dims<F>(a.logD, threads, lds);
+        rc = seg_launch_dims<F>(a.logD, threads, lds, true);
         if (rc) return rc;
         const uint64_t grid = (uint64_t)n_groups * d.n_seg * a.O;
         if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
@@ -596,7 +598,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
                 a.n_chunks = n_chunks;
             }
             if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            const size_t lds_p = lds - ((size_t)1 << a.logD) * sizeof(T) + 16;  // no `aux` table; two ticket words
+            const size_t lds_p = lds + 16;  // two ticket words behind the twiddles
             const uint64_t resident = (uint64_t)ctx->num_cus * std::max<size_t>(1, (160 * 1024) / lds_p);
             int rcq = ensure(ctx->tickets, 64);
             if (rcq) return rcq;
