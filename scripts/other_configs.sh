@@ -13,6 +13,9 @@ done <<'LIST'
 1,1,20,3,8,8 eight packed traces under one tree
 1,1,20,3,2,16 sixteen packed 2-column (Fibonacci-like) traces
 1,1,20,3,4,4 four packed 4-column traces
+1,1,20,3,200,1 wide trace: 1600-byte rows (two BLAKE3 chunks), fused chunk by chunk
+1,1,18,3,255,1 MAX_TRACE_WIDTH columns at 2^18
+2,1,14,3,10,32 32 packed f128 do_work traces of 2^14 steps
 1,2,20,3,4,1 quadratic-extension columns, 8 base columns
 1,2,20,3,2,1 4 base columns: coset-packed lanes
 1,2,20,3,1,1 composition-poly shape: one E column
