@@ -244,24 +244,31 @@ struct Plan {
 // digits of at most `max_digit` bits (what one work-group can hold in LDS: 11 for f64, 10 for f128), balanced.
 // `avoid_full`: a plan of two maximal digits would run both passes with a single work-group per CU (the tile fills
 // the LDS), which measures ~10 % slower than three passes over smaller tiles (2^22 f64, 2^20 f128).
-static Plan make_plan(uint32_t L, uint32_t max_digit, bool avoid_full = false) {
+static Plan make_plan(uint32_t L, uint32_t max_digit, bool avoid_full = false, bool few_tiles = false) {
     Plan p;
     p.n_pass = L <= 10 ? 1 : (int)((L + max_digit - 1) / max_digit);
     if (avoid_full && p.n_pass == 2 && L == 2 * max_digit) p.n_pass = 3;
+    // segment kernels: a 2^11-row tile is one work-group per CU, and a transform of that size over a few segments only
+    // a handful of them -- two passes of small tiles are faster then (2^11 x 8 f64: 0.123 -> 0.10 ms)
+    if (few_tiles && p.n_pass == 1 && L > 10) p.n_pass = 2;
     uint32_t base = L / p.n_pass, rem = L % p.n_pass;
     for (int i = 0; i < p.n_pass; i++) p.dig[i] = base + (i < (int)rem ? 1 : 0);
+    // a maximal digit goes last: the last pass keeps one table less in LDS (an f128 2^10-row tile leaves room for two
+    // work-groups per CU there, not in a strided pass) -- f128 2^19 x 10: 2.99 -> 2.81 ms, f64 2^21 x 64: 20.9 -> 19.8 ms
+    if (avoid_full && p.n_pass >= 2 && p.dig[0] == max_digit && p.dig[p.n_pass - 1] < max_digit)
+        std::swap(p.dig[0], p.dig[p.n_pass - 1]);
     return p;
 }
 
 // the plan of the segment kernels (run_seg_transform and the sizing of its work buffer must agree on it)
 template <class F>
-static Plan seg_plan(uint32_t logN) {
+static Plan seg_plan(uint32_t logN, uint32_t n_seg) {
     uint32_t max_digit = F::BYTES == 8 ? 11 : 10;
     if (const char *e = getenv("WF_EXP_MAX_DIGIT")) {  // tuning experiment: force more, smaller passes
         const uint32_t v = (uint32_t)atoi(e);
         if (v >= 4 && v < max_digit && (logN + v - 1) / v <= 4) max_digit = v;  // Plan holds 4 digits
     }
-    return make_plan(logN, max_digit, true);
+    return make_plan(logN, max_digit, true, n_seg <= 8);
 }
 
 template <class F>
@@ -465,7 +472,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
     TableSet *tw;
     int rc = root_tables<F>(ctx, d.logN, inverse, &tw);
     if (rc) return rc;
-    const Plan plan = seg_plan<F>(d.logN);
+    const Plan plan = seg_plan<F>(d.logN, d.n_seg);
     const uint64_t N = (uint64_t)1 << d.logN;
 
     SegArgs<F> a;
@@ -784,7 +791,7 @@ static int path_buffers(wf_ctx *ctx, const wf_params *p, PathBufs<F> &b) {
     b.total_base_cols = p->n_cols * p->ext_degree * p->n_traces;
     b.n_seg = (b.total_base_cols + S - 1) / S;
     const size_t seg_vals = (size_t)b.n_seg * S << p->log2_trace_len;
-    const size_t work_vals = seg_plan<F>(p->log2_trace_len).n_pass > 1 ? seg_vals << p->log2_blowup : 0;
+    const size_t work_vals = seg_plan<F>(p->log2_trace_len, b.n_seg).n_pass > 1 ? seg_vals << p->log2_blowup : 0;
     int rc = ensure(ctx->scratch, (2 * seg_vals + work_vals) * sizeof(T));
     if (rc) return rc;
     b.segA = (T *)ctx->scratch.p;
