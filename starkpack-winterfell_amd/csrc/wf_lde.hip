@@ -584,11 +584,12 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         // one segment of one trace: k_seg_last hashes its rows itself, and with tiles below 2^10 rows one work-group per
         // tile beats the ticket kernel (2^14..2^18 x 8: -3..-14 %, 2^22 x 8: -10 %; 2^20 x 8, 2^10-row tiles: +5 %)
         const bool one_seg = d.n_seg == 1 && d.total_base_cols == d.base_cols;
+        const bool always = getenv("WF_EXP_PERSISTENT_ALWAYS") != nullptr;  // (tests: the ticket kernel on every shape it can run)
         const bool persistent = may_fuse && !single && (d.n_seg <= 16 || chunked) && threads * 2 == (1u << a.logD) &&
-                                (!one_seg || a.logD >= 10) &&
+                                (always || !one_seg || a.logD >= 10) &&
                                 // several segments of one trace, rows of one chunk: below 2^20 LDE rows the separate
                                 // row-hash kernel costs less than the ticket kernel's small tiles (2^14 x 16: -15 %)
-                                (one_seg || chunked || d.total_base_cols != d.base_cols || launch_rows >= (1ull << 20)) &&
+                                (always || one_seg || chunked || d.total_base_cols != d.base_cols || launch_rows >= (1ull << 20)) &&
                                 tickets % 8 == 0 && tickets < (1ull << 31) && launch_rows * n_chunks * 32 < (1ull << 40) &&
                                 getenv("WF_EXP_NO_PERSISTENT") == nullptr;
         // coset-packed rows are hashed in the pass where the separate kernel is the slower one (measured): f128, four

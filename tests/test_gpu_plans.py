@@ -13,13 +13,14 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("switch", ["WF_EXP_MAX_DIGIT=5", "WF_EXP_MAX_DIGIT=7", "WF_EXP_NO_FUSED_HASH=1",
-                                    "WF_EXP_NO_PERSISTENT=1", "WF_EXP_NO_CHUNKED=1"])
+                                    "WF_EXP_NO_PERSISTENT=1", "WF_EXP_NO_CHUNKED=1", "WF_EXP_PERSISTENT_ALWAYS=1"])
 def test_parity_under_forced_plans(capi, switch):
     """WF_EXP_NO_FUSED_HASH: one-segment, one-trace matrices normally get their leaves from the last evaluation pass;
     with the switch they go through k_hash_rows like every other shape -- both routes must give the same bytes.
     WF_EXP_NO_PERSISTENT: the fused last pass as one work-group per tile instead of the persistent ticket kernel.
     WF_EXP_NO_CHUNKED: rows longer than one BLAKE3 chunk hashed by the separate chunk kernels instead of chunk by chunk
-    inside the persistent pass."""
+    inside the persistent pass.  WF_EXP_PERSISTENT_ALWAYS: the ticket kernel also on the small shapes that normally take
+    one work-group per tile."""
     capi.load()
     env = dict(os.environ)
     name, value = switch.split("=")
