@@ -25,13 +25,17 @@ with torch.cuda.stream(s):
     for _ in range(K): call(s.cuda_stream)
     e1.record(); torch.cuda.synchronize()
     print(f"direct: {e0.elapsed_time(e1)/K:.4f} ms")
+leaves_direct, lde_direct = leaves.clone(), lde.clone()
 g = torch.cuda.CUDAGraph()
 nodes.zero_()
 with torch.cuda.graph(g, stream=s):
     call(torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
-g.replay(); torch.cuda.synchronize()
-print("graph root matches:", bytes(nodes[1].cpu().numpy()) == root_direct)
+for it in range(3):   # every replay must redo all the work: outputs are wiped in between
+    nodes.zero_(); leaves.zero_(); lde.zero_()
+    torch.cuda.synchronize()
+    g.replay(); torch.cuda.synchronize()
+    print(f"replay {it}: root {bytes(nodes[1].cpu().numpy()) == root_direct} leaves {torch.equal(leaves, leaves_direct)} lde {torch.equal(lde, lde_direct)}")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(K): g.replay()

@@ -259,6 +259,13 @@ __global__ void __launch_bounds__(1024) k_ntt_last(NttArgs<F> a) {
     }
 }
 
+// Zero fill (n 16-byte words) -- a kernel rather than hipMemsetAsync: memset nodes of a captured graph were seen to
+// replay wrongly on this ROCm (tests/test_gpu_graph.py), kernels replay as launched.
+__global__ void __launch_bounds__(256) k_zero16(uint4 *__restrict__ dst, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = make_uint4(0, 0, 0, 0);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Leaf hashing: leaf j = BLAKE3(canonical LE bytes of row j of trace 0 || row j of trace 1 || ..)
 // (RowMatrix::commit_to_comb_rows, prover/src/matrix/row_matrix.rs:204-238; Blake3_256::hash_elements,
@@ -523,6 +530,13 @@ __global__ void __launch_bounds__(256) k_merkle_subtree(const uint32_t *__restri
 #pragma unroll
             for (int i = 0; i < 8; i++) sh[tid * 8 + i] = cv[i];
         }
+    }
+    // the launch that produces the root also writes nodes[0] = Digest::default() (merkle/mod.rs:355) -- by a kernel rather
+    // than a memset so that a captured graph of the commitment replays it
+    if (blockIdx.x == 0 && tid == 0 && (n_children >> levels) == 1) {
+        uint4 *dst = reinterpret_cast<uint4 *>(nodes);
+        dst[0] = make_uint4(0, 0, 0, 0);
+        dst[1] = make_uint4(0, 0, 0, 0);
     }
 }
 

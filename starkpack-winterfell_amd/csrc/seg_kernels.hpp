@@ -150,7 +150,7 @@ struct SegArgs {
     uint32_t hash_epr;         // elements of a row that are hashed (elements_per_row)
     uint32_t *chunk_cvs;       // k_seg_last_hash<.., CHUNKED>: [LDE row][n_chunks][8] chunk chaining values (rows > 1024 bytes)
     uint32_t n_chunks;         //   ceil(n_seg / 16): a BLAKE3 chunk is 16 blocks = 16 segments of a row
-    uint32_t *tile_counters;   // k_seg_last_hash: 8 zeroed counters, one per XCD (dynamic tile assignment)
+    uint32_t *tile_counters;   // k_seg_last_hash: 8 ticket + 8 exit counters, one per XCD, zero between launches (self-resetting)
 };
 
 // LDS position -> output index of seg_lds_ntt: radix-16 digits while >= 4 bits remain, then radix-4, then radix-2
@@ -1082,7 +1082,23 @@ __global__ void __launch_bounds__(F::BYTES == 8 ? 1024 : 512) k_seg_last_hash(Se
         return ticket_sh[slot];
     };
     uint64_t ticket = next_ticket(0);
-    if (ticket >= per_xcd) return;
+    // Counters reset themselves: every work-group takes exactly one ticket past the end, then signs off on the exit
+    // counter of its XCD (words 8..15); the last one to sign off zeroes both for the next launch.  No memset between
+    // launches -- a captured graph replays correctly (a 32-byte memset node did not: its replays kept stale counters).
+    auto sign_off = [&]() {
+        if (threadIdx.x == 0) {
+            __threadfence();
+            const uint32_t mine = (gridDim.x + 7 - xcd) >> 3;  // work-groups with blockIdx % 8 == xcd
+            if (atomicAdd(a.tile_counters + 8 + xcd, 1u) == mine - 1) {
+                atomicExch(a.tile_counters + xcd, 0u);
+                atomicExch(a.tile_counters + 8 + xcd, 0u);
+            }
+        }
+    };
+    if (ticket >= per_xcd) {
+        sign_off();
+        return;
+    }
     uint32_t c, g = 0, ch = 0;  // g stays 0 without MULTI, ch without CHUNKED
     uint64_t o, rev_o;
     decode(ticket * 8 + xcd, c, o, rev_o, ch);
@@ -1230,7 +1246,10 @@ __global__ void __launch_bounds__(F::BYTES == 8 ? 1024 : 512) k_seg_last_hash(Se
                 }
             }
         }
-        if (!more) break;
+        if (!more) {
+            sign_off();
+            break;
+        }
         __syncthreads();  // x is rewritten by the next tile
         c = cn;
         g = MULTI ? gn : 0;

@@ -615,9 +615,11 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             const size_t lds_p = lds + 16;  // two ticket words behind the twiddles
             const uint64_t resident = (uint64_t)ctx->num_cus * std::max<size_t>(1, (160 * 1024) / lds_p);
-            int rcq = ensure(ctx->tickets, 64);
-            if (rcq) return rcq;
-            HIP_TRY(hipMemsetAsync(ctx->tickets.p, 0, 32, st));
+            if (!ctx->tickets.p) {  // zeroed once: the kernel leaves its counters at zero
+                int rcq = ensure(ctx->tickets, 64);
+                if (rcq) return rcq;
+                HIP_TRY(hipMemset(ctx->tickets.p, 0, 64));
+            }
             a.tile_counters = (uint32_t *)ctx->tickets.p;
             void *kargs[] = {&a};
             HIP_TRY(hipLaunchKernel(kern, dim3((uint32_t)std::min<uint64_t>(tickets, resident)), dim3(threads), kargs, lds_p, st));
@@ -703,7 +705,7 @@ static int run_hash_rows(wf_ctx *ctx, hipStream_t st, const void *lde, uint64_t 
 }
 
 static int run_merkle(hipStream_t st, const void *leaves, uint64_t n_leaves, void *nodes) {
-    HIP_TRY(hipMemsetAsync(nodes, 0, 32, st));  // nodes[0] = Digest::default() (merkle/mod.rs:355)
+    // (nodes[0] = Digest::default(), merkle/mod.rs:355, is written by the launch that produces the root)
     const uint32_t *children = (const uint32_t *)leaves;
     uint64_t n_children = n_leaves;
     while (n_children > 1) {
@@ -831,8 +833,11 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
     // trace's last column writes that row's zeros.  Only coset-packed multi-trace / f128 matrices are cleared up front.
     const bool pad_traces = row_width != base_cols && !pad_in_kernel &&
                             !packed_shape<F>(b.n_seg, b.total_base_cols, base_cols, n_cosets, &cpr_unused, &lg_unused);
-    if (row_width != base_cols && !pad_in_kernel && !pad_traces)
-        HIP_TRY(hipMemsetAsync(d_lde, 0, (size_t)p->n_traces * Nrows * row_width * sizeof(T), st));
+    if (row_width != base_cols && !pad_in_kernel && !pad_traces) {
+        const uint64_t n16 = (uint64_t)p->n_traces * Nrows * row_width * sizeof(T) / 16;  // rows are multiples of 64 bytes
+        hipLaunchKernelGGL(k_zero16, dim3((uint32_t)std::min<uint64_t>((n16 + 255) / 256, 256 * 32)), dim3(256), 0, st, (uint4 *)d_lde, n16);
+        HIP_TRY(hipGetLastError());
+    }
 
     SegDesc<F> d;
     memset(&d, 0, sizeof(d));
