@@ -129,7 +129,9 @@ int wf_constraint_commit(wf_ctx *ctx, const wf_params *p, const void *const *pol
  *   d_polys : same shape                                                                (written)
  *   d_lde   : [n_traces] row-major matrices (wf_lde_bytes each)                         (written)
  *   d_leaves, d_nodes : wf_digests_bytes each                                           (written)
- * No host synchronisation happens inside; scratch comes from the context and is reused across calls. */
+ * No host synchronisation happens inside; scratch comes from the context and is reused across calls.  After one call
+ * with the same parameters (it allocates the scratch and builds the twiddle tables) the call is a pure sequence of
+ * kernel launches and can be captured into a HIP graph on `stream` and replayed (tests/test_gpu_graph.py). */
 int wf_trace_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_trace, void *d_polys, void *d_lde,
                         void *d_leaves, void *d_nodes, void *stream);
 int wf_constraint_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_polys, void *d_lde, void *d_leaves,
