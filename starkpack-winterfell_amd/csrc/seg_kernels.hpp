@@ -1087,7 +1087,8 @@ __global__ void __launch_bounds__(F::BYTES == 8 ? 1024 : 512) k_seg_last_hash(Se
     // launches -- a captured graph replays correctly (a 32-byte memset node did not: its replays kept stale counters).
     auto sign_off = [&]() {
         if (threadIdx.x == 0) {
-            __threadfence();
+            // (no fence: this thread's past-the-end ticket atomic has returned -- the branch here depends on its value --
+            // before the exit atomic is issued; a device-scope release fence would write back the XCD's L2 per work-group)
             const uint32_t mine = (gridDim.x + 7 - xcd) >> 3;  // work-groups with blockIdx % 8 == xcd
             if (atomicAdd(a.tile_counters + 8 + xcd, 1u) == mine - 1) {
                 atomicExch(a.tile_counters + xcd, 0u);
