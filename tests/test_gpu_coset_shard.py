@@ -14,7 +14,9 @@ F64, F128 = 1, 2
     (F64, 11, 3, 8, 1, 8), (F64, 12, 3, 5, 3, 4), (F64, 8, 3, 10, 2, 2), (F128, 10, 2, 10, 2, 4), (F64, 10, 3, 8, 2, 1),
     # narrow matrices, one coset per rank (never coset-packed) and two (packed): who writes the rows' zero padding differs
     (F64, 10, 3, 3, 1, 8), (F64, 10, 3, 1, 1, 8), (F64, 10, 3, 2, 3, 8), (F64, 10, 3, 2, 1, 4), (F64, 10, 3, 1, 3, 4),
-    (F128, 10, 3, 1, 1, 8), (F128, 10, 3, 3, 1, 4), (F128, 10, 3, 1, 2, 4), (F128, 10, 3, 5, 1, 8)])
+    (F128, 10, 3, 1, 1, 8), (F128, 10, 3, 3, 1, 4), (F128, 10, 3, 1, 2, 4), (F128, 10, 3, 5, 1, 8),
+    # rows longer than one BLAKE3 chunk in a shard: chunk chaining values indexed by the shard's own rows
+    (F64, 12, 3, 200, 1, 4), (F64, 12, 3, 40, 5, 2), (F128, 11, 3, 10, 20, 8)])
 def test_coset_sharded_commitment(ctx, orc, capi, field, logR, logB, n_cols, n_traces, world):
     import torch
     from starkpack_winterfell_amd import shard
