@@ -283,7 +283,7 @@ class Context:
         h = C.c_void_p()
         _check(L.wf_trace_commit_resident(self._h, C.byref(params), _ptr_array(cols),
                                           _ptr_array(polys) if polys else None, C.byref(h)))
-        return Commitment(h, params.field), polys
+        return Commitment(h, params.field, keep_alive=self), polys
 
     def constraint_commit_resident(self, params: Params, poly_cols):
         L = load()
@@ -291,7 +291,7 @@ class Context:
         cols = [np.ascontiguousarray(c, dtype=np.uint64) for c in poly_cols]
         h = C.c_void_p()
         _check(L.wf_constraint_commit_resident(self._h, C.byref(params), _ptr_array(cols), C.byref(h)))
-        return Commitment(h, params.field)
+        return Commitment(h, params.field, keep_alive=self)
 
     # -- building blocks -----------------------------------------------------------------------------------------
     def fft_evaluate_poly(self, field, ext, poly: np.ndarray) -> np.ndarray:
@@ -377,10 +377,11 @@ class Context:
 class Commitment:
     """wf_commitment wrapper: LDE + tree resident in HBM; rows and Merkle proofs are read from there."""
 
-    def __init__(self, handle, field, owned=True):
+    def __init__(self, handle, field, owned=True, keep_alive=None):
         self._h = handle
         self.field = field
         self._owned = owned  # layers of a FriProver belong to the prover
+        self._keep_alive = keep_alive  # the Context (or FriProver) this handle lives in: destroyed after it, never before
         n_rows, row_elems, depth = C.c_uint64(), C.c_uint64(), C.c_uint32()
         _check(load().wf_commitment_info(self._h, C.byref(n_rows), C.byref(row_elems), C.byref(depth)))
         self.n_rows, self.row_elems, self.depth = n_rows.value, row_elems.value, depth.value
@@ -456,6 +457,7 @@ class FriProver:
 
     def __init__(self, ctx: "Context", field, ext, folding, blowup, remainder_max_degree, offset: int):
         self.field, self.ext, self.folding, self.blowup = field, ext, folding, blowup
+        self._ctx = ctx  # the prover uses its context until it is destroyed: keep it alive (interpreter exit order)
         self._h = C.c_void_p()
         _check(load().wf_fri_prover_create(ctx._h, field, ext, folding, blowup, remainder_max_degree, _off16(offset),
                                            C.byref(self._h)))
@@ -508,7 +510,7 @@ class FriProver:
     def layer(self, i: int) -> Commitment:
         h = C.c_void_p()
         _check(load().wf_fri_prover_layer(self._h, i, C.byref(h)))
-        return Commitment(h, self.field, owned=False)
+        return Commitment(h, self.field, owned=False, keep_alive=self)
 
     def reset(self):
         _check(load().wf_fri_prover_reset(self._h))

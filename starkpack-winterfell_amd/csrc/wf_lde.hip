@@ -806,13 +806,15 @@ static int path_buffers(wf_ctx *ctx, const wf_params *p, PathBufs<F> &b) {
 // coefficients in segB -> row-major LDE -> leaves -> tree
 template <class F>
 static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, const PathBufs<F> &b, void *d_lde,
-                               void *d_leaves, void *d_nodes, uint32_t coset0 = 0, uint32_t n_cosets = 0) {
+                               void *d_leaves, void *d_nodes, uint32_t coset0 = 0, uint32_t n_cosets = 0,
+                               bool dense_rows = false) {
     typedef typename F::T T;
     const uint32_t W = p->ext_degree, logR = p->log2_trace_len, logB = p->log2_blowup;
     if (n_cosets == 0) n_cosets = 1u << logB;  // all of them; otherwise a shard [coset0, coset0 + n_cosets)
     const uint64_t Nrows = (uint64_t)n_cosets << logR;
-    const uint64_t row_width = wf_row_width(p);
     const uint32_t base_cols = p->n_cols * W;
+    // dense_rows: rows of exactly base_cols elements, no padding (a vector of evaluations rather than a RowMatrix)
+    const uint64_t row_width = dense_rows ? base_cols : wf_row_width(p);
 
     uint64_t olo, ohi;
     T off = offset_elem<F>(p, olo, ohi);
@@ -911,14 +913,22 @@ static int trace_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_trace
 // Prover::build_constraint_commitment on device buffers
 template <class F>
 static int constraint_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_polys, void *d_lde, void *d_leaves,
-                                 void *d_nodes, hipStream_t st) {
+                                 void *d_nodes, hipStream_t st, bool dense_rows = false) {
     PathBufs<F> b;
     int rc = path_buffers<F>(ctx, p, b);
     if (rc) return rc;
     rc = run_xpose<F>(ctx, st, true, d_polys, b.segB, (uint64_t)1 << p->log2_trace_len, p->ext_degree,
                       b.total_base_cols, b.n_seg);
     if (rc) return rc;
-    return evaluate_and_commit<F>(ctx, st, p, b, d_lde, d_leaves, d_nodes);
+    return evaluate_and_commit<F>(ctx, st, p, b, d_lde, d_leaves, d_nodes, 0, 0, dense_rows);
+}
+
+// One column of E evaluated over the LDE domain straight into a dense vector of n * blowup elements (`d_out`): possible
+// when the column goes through the coset-packed kernels (any even number of cosets), whose stores take any row stride.
+template <class F>
+static bool dense_column_ok(const wf_params *p) {
+    uint32_t cpr, lg;
+    return packed_shape<F>(1, p->ext_degree, p->ext_degree, 1u << p->log2_blowup, &cpr, &lg);
 }
 
 // ------------------------------------------------------------------------------------------------- C ABI
@@ -1157,14 +1167,17 @@ struct wf_commitment {
     uint64_t n_rows, row_width, epr, row_elems;
     uint32_t depth;
     uint8_t root[32];
+    bool borrowed;  // lde / leaves / nodes live in an arena of their owner (FRI layers): not freed one by one
 };
 
 static void free_commitment(wf_commitment *c) {
     if (!c) return;
     (void)hipSetDevice(c->ctx->device);
-    if (c->lde) (void)hipFree(c->lde);
-    if (c->leaves) (void)hipFree(c->leaves);
-    if (c->nodes) (void)hipFree(c->nodes);
+    if (!c->borrowed) {
+        if (c->lde) (void)hipFree(c->lde);
+        if (c->leaves) (void)hipFree(c->leaves);
+        if (c->nodes) (void)hipFree(c->nodes);
+    }
     if (c->polys) (void)hipFree(c->polys);
     delete c;
 }
@@ -1743,11 +1756,15 @@ int wf_fft_evaluate_poly_with_offset(wf_ctx *ctx, uint32_t field, uint32_t ext, 
     if ((rc = ensure(ctx->io[2], ldeb))) return rc;
     hipStream_t st = ctx->stream;
     HIP_TRY(hipMemcpyAsync(ctx->io[0].p, poly, colb, hipMemcpyHostToDevice, st));
-    rc = field == WF_FIELD_F64 ? constraint_commit_dev<F64>(ctx, &p, ctx->io[0].p, ctx->io[2].p, nullptr, nullptr, st)
-                               : constraint_commit_dev<F128>(ctx, &p, ctx->io[0].p, ctx->io[2].p, nullptr, nullptr, st);
+    const bool dense = field == WF_FIELD_F64 ? dense_column_ok<F64>(&p) : dense_column_ok<F128>(&p);
+    rc = field == WF_FIELD_F64 ? constraint_commit_dev<F64>(ctx, &p, ctx->io[0].p, ctx->io[2].p, nullptr, nullptr, st, dense)
+                               : constraint_commit_dev<F128>(ctx, &p, ctx->io[0].p, ctx->io[2].p, nullptr, nullptr, st, dense);
     if (rc) return rc;
     const size_t rows = n * blowup, rw = wf_row_width(&p);
-    HIP_TRY(hipMemcpy2DAsync(result, ext * eb, ctx->io[2].p, rw * eb, ext * eb, rows, hipMemcpyDeviceToHost, st));
+    if (dense)  // the device result is the vector itself: one contiguous copy instead of one 16..48-byte piece per row
+        HIP_TRY(hipMemcpyAsync(result, ctx->io[2].p, rows * ext * eb, hipMemcpyDeviceToHost, st));
+    else
+        HIP_TRY(hipMemcpy2DAsync(result, ext * eb, ctx->io[2].p, rw * eb, ext * eb, rows, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
@@ -1800,16 +1817,42 @@ struct wf_fri_prover {
     uint32_t field = 0, ext = 0, folding = 0, blowup = 0, remainder_max_degree = 0;
     uint8_t offset[16] = {0};
     void *evals = nullptr;  // evaluations of the current layer (device)
+    bool evals_borrowed = false;
     size_t n = 0;
     wf_commitment *pending = nullptr;  // committed, not yet folded
     std::vector<wf_commitment *> layers;
+    // One allocation for all layers of a proof (hipMalloc / hipFree per layer cost more than the layers' kernels from the
+    // third layer on); kept across wf_fri_prover_reset, released by wf_fri_prover_destroy.
+    DevBuf arena;
+    size_t arena_used = 0;
 };
+
+static void *fri_arena_take(wf_fri_prover *pr, size_t bytes) {
+    const size_t off = (pr->arena_used + 255) & ~(size_t)255;
+    if (!pr->arena.p || off + bytes > pr->arena.cap) return nullptr;
+    pr->arena_used = off + bytes;
+    return (char *)pr->arena.p + off;
+}
+
+// room for every layer of a proof over n evaluations: transposed values, leaves, nodes, folded evaluations
+static int fri_arena_reserve(wf_fri_prover *pr, size_t n) {
+    const size_t eb = (size_t)pr->ext * wf_elem_bytes(pr->field);
+    size_t total = 0;
+    for (size_t m = n; m >= pr->folding; m /= pr->folding) {
+        const size_t rows = m / pr->folding;
+        total += (m * eb + 256) + 2 * (rows * 32 + 256) + (rows * eb + 256);
+    }
+    pr->arena_used = 0;
+    return ensure(pr->arena, total);
+}
 
 static void fri_prover_clear(wf_fri_prover *pr) {
     (void)hipSetDevice(pr->ctx->device);
     (void)hipStreamSynchronize(pr->ctx->stream);
-    if (pr->evals) (void)hipFree(pr->evals);
+    if (pr->evals && !pr->evals_borrowed) (void)hipFree(pr->evals);
     pr->evals = nullptr;
+    pr->evals_borrowed = false;
+    pr->arena_used = 0;
     pr->n = 0;
     free_commitment(pr->pending);
     pr->pending = nullptr;
@@ -1873,6 +1916,7 @@ int wf_fri_prover_create(wf_ctx *ctx, uint32_t field, uint32_t ext, uint32_t fol
 void wf_fri_prover_destroy(wf_fri_prover *pr) {
     if (!pr) return;
     fri_prover_clear(pr);
+    if (pr->arena.p) (void)hipFree(pr->arena.p);
     delete pr;
 }
 
@@ -1893,7 +1937,10 @@ static int fri_prover_begin(wf_fri_prover *pr, const void *src, size_t n, bool o
         return fail(WF_ERR_DOMAIN, "no multiplicative subgroup of size 2^%u in this field", l);
     HIP_TRY(hipSetDevice(pr->ctx->device));
     const size_t bytes = n * pr->ext * wf_elem_bytes(pr->field);
+    int rca = fri_arena_reserve(pr, n);
+    if (rca) return rca;
     HIP_TRY(hipMalloc(&pr->evals, bytes));
+    pr->evals_borrowed = false;
     HIP_TRY(hipMemcpyAsync(pr->evals, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     pr->n = n;
@@ -1931,14 +1978,22 @@ int wf_fri_prover_begin_poly(wf_fri_prover *pr, const void *poly, size_t n, size
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t eb = wf_elem_bytes(pr->field), rows = n * lde_blowup, rw = wf_row_width(&p);
     if ((rc = ensure(ctx->io[0], wf_column_bytes(&p)))) return rc;
-    if ((rc = ensure(ctx->io[2], wf_lde_bytes(&p)))) return rc;
+    const bool dense = pr->field == WF_FIELD_F64 ? dense_column_ok<F64>(&p) : dense_column_ok<F128>(&p);
+    if (!dense && (rc = ensure(ctx->io[2], wf_lde_bytes(&p)))) return rc;
+    if ((rc = fri_arena_reserve(pr, rows))) return rc;
     HIP_TRY(hipMalloc(&pr->evals, rows * pr->ext * eb));
+    pr->evals_borrowed = false;
     hipStream_t st = ctx->stream;
     rc = hipMemcpyAsync(ctx->io[0].p, poly, wf_column_bytes(&p), hipMemcpyHostToDevice, st) == hipSuccess ? 0 : fail(WF_ERR_HIP, "upload failed");
-    // one column of E evaluated to row-major (row width 8), then its ext_degree live lanes gathered into a dense vector
-    if (rc == 0) rc = wf_constraint_commit_dev(ctx, &p, ctx->io[0].p, ctx->io[2].p, nullptr, nullptr, st);
-    if (rc == 0 && hipMemcpy2DAsync(pr->evals, pr->ext * eb, ctx->io[2].p, rw * eb, pr->ext * eb, rows, hipMemcpyDeviceToDevice, st) != hipSuccess)
-        rc = fail(WF_ERR_HIP, "gathering the evaluations failed");
+    if (rc == 0 && dense) {  // the evaluation writes the dense vector itself
+        rc = pr->field == WF_FIELD_F64 ? constraint_commit_dev<F64>(ctx, &p, ctx->io[0].p, pr->evals, nullptr, nullptr, st, true)
+                                       : constraint_commit_dev<F128>(ctx, &p, ctx->io[0].p, pr->evals, nullptr, nullptr, st, true);
+    } else if (rc == 0) {
+        // one column of E evaluated to row-major (row width 8), then its ext_degree live lanes gathered into a dense vector
+        rc = wf_constraint_commit_dev(ctx, &p, ctx->io[0].p, ctx->io[2].p, nullptr, nullptr, st);
+        if (rc == 0 && hipMemcpy2DAsync(pr->evals, pr->ext * eb, ctx->io[2].p, rw * eb, pr->ext * eb, rows, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            rc = fail(WF_ERR_HIP, "gathering the evaluations failed");
+    }
     if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = fail(WF_ERR_HIP, "stream synchronisation failed");
     if (rc) {
         (void)hipFree(pr->evals);
@@ -1972,12 +2027,21 @@ int wf_fri_prover_commit_layer(wf_fri_prover *pr, uint8_t root_out[32]) {
     c->row_width = c->epr = c->row_elems = (uint64_t)pr->folding * pr->ext;
     for (uint64_t t = rows; t > 1; t >>= 1) c->depth++;
     c->p.log2_trace_len = c->depth;
-    hipError_t e = hipMalloc(&c->lde, pr->n * pr->ext * eb);
-    if (e == hipSuccess) e = hipMalloc(&c->leaves, rows * 32);
-    if (e == hipSuccess) e = hipMalloc(&c->nodes, rows * 32);
-    if (e != hipSuccess) {
-        free_commitment(c);
-        return fail(WF_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+    const size_t used0 = pr->arena_used;
+    c->lde = fri_arena_take(pr, pr->n * pr->ext * eb);
+    c->leaves = c->lde ? fri_arena_take(pr, rows * 32) : nullptr;
+    c->nodes = c->leaves ? fri_arena_take(pr, rows * 32) : nullptr;
+    c->borrowed = c->nodes != nullptr;
+    if (!c->borrowed) {  // (arena too small: cannot happen after fri_arena_reserve, kept as a fallback)
+        pr->arena_used = used0;
+        c->lde = c->leaves = c->nodes = nullptr;
+        hipError_t e = hipMalloc(&c->lde, pr->n * pr->ext * eb);
+        if (e == hipSuccess) e = hipMalloc(&c->leaves, rows * 32);
+        if (e == hipSuccess) e = hipMalloc(&c->nodes, rows * 32);
+        if (e != hipSuccess) {
+            free_commitment(c);
+            return fail(WF_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+        }
     }
     hipStream_t st = ctx->stream;
     rc = pr->field == WF_FIELD_F64
@@ -2001,19 +2065,23 @@ int wf_fri_prover_fold(wf_fri_prover *pr, const void *alpha) {
     wf_ctx *ctx = pr->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t rows = pr->n / pr->folding;
-    void *next = nullptr;
-    HIP_TRY(hipMalloc(&next, rows * pr->ext * wf_elem_bytes(pr->field)));
+    void *next = fri_arena_take(pr, rows * pr->ext * wf_elem_bytes(pr->field));
+    const bool next_borrowed = next != nullptr;
+    if (!next) HIP_TRY(hipMalloc(&next, rows * pr->ext * wf_elem_bytes(pr->field)));
     hipStream_t st = ctx->stream;
+    // (asynchronous: the folded layer is consumed by the next call on the same stream; alpha is copied at launch)
     int rc = pr->field == WF_FIELD_F64
                  ? fri_apply_drp_dev<F64>(ctx, st, pr->ext, pr->pending->lde, rows, pr->folding, pr->offset, alpha, next)
                  : fri_apply_drp_dev<F128>(ctx, st, pr->ext, pr->pending->lde, rows, pr->folding, pr->offset, alpha, next);
-    if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = fail(WF_ERR_HIP, "stream synchronisation failed");
     if (rc) {
-        (void)hipFree(next);
+        if (!next_borrowed) (void)hipFree(next);
         return rc;
     }
-    (void)hipFree(pr->evals);
+    if (!pr->evals_borrowed) {  // the caller's first layer: its own allocation (hipFree waits for the fold that reads it)
+        (void)hipFree(pr->evals);
+    }
     pr->evals = next;
+    pr->evals_borrowed = next_borrowed;
     pr->n = rows;
     pr->layers.push_back(pr->pending);
     pr->pending = nullptr;
@@ -2032,7 +2100,8 @@ int wf_fri_prover_set_remainder(wf_fri_prover *pr, void *remainder_out, size_t c
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t eb = wf_elem_bytes(pr->field), bytes = pr->n * pr->ext * eb;
     std::vector<unsigned char> host(bytes);
-    HIP_TRY(hipMemcpy(host.data(), pr->evals, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(host.data(), pr->evals, bytes, hipMemcpyDeviceToHost, ctx->stream));  // (after the last fold)
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     // the remainder layer is tiny ((remainder_max_degree + 1) * blowup evaluations): through the host-buffer entry points
     int rc = wf_fft_interpolate_poly_with_offset(ctx, pr->field, pr->ext, host.data(), pr->n, pr->offset);
     if (rc) return rc;
@@ -2040,8 +2109,9 @@ int wf_fri_prover_set_remainder(wf_fri_prover *pr, void *remainder_out, size_t c
     rc = wf_hash_rows(ctx, pr->field, remainder_out, 1, len * pr->ext, commitment_out);  // hash_elements(&remainder_poly)
     if (rc) return rc;
     *len_out = len;
-    (void)hipFree(pr->evals);
+    if (!pr->evals_borrowed) (void)hipFree(pr->evals);
     pr->evals = nullptr;
+    pr->evals_borrowed = false;
     pr->n = 0;
     return 0;
 }
