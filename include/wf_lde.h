@@ -70,7 +70,8 @@ typedef struct wf_params {
 /* ---- context ------------------------------------------------------------------------------------------------- */
 
 /* Creates a context bound to HIP device `device` (twiddle tables, scratch and a stream live in it).
- * One context per GPU; a context is not thread-safe, distinct contexts are independent. */
+ * One context per GPU; a context is not thread-safe, distinct contexts are independent.  Commitments and FRI provers
+ * created on a context use it until they are destroyed: destroy them first, the context last. */
 int wf_ctx_create(int device, wf_ctx **out);
 void wf_ctx_destroy(wf_ctx *ctx);
 const char *wf_last_error(void);
