@@ -74,6 +74,9 @@ typedef struct wf_params {
  * created on a context use it until they are destroyed: destroy them first, the context last. */
 int wf_ctx_create(int device, wf_ctx **out);
 void wf_ctx_destroy(wf_ctx *ctx);
+/* A context parks the device buffers of destroyed resident commitments (up to 16) for the next commitment of the same
+ * shape -- a prover producing proof after proof allocates once.  This returns them to the driver. */
+int wf_ctx_release_cached(wf_ctx *ctx);
 const char *wf_last_error(void);
 /* Number of HIP devices visible (0 if none / no driver). */
 int wf_device_count(void);

@@ -18,7 +18,7 @@ ELEM_WORDS = {F64: 1, F128: 2}
 
 SYMBOLS = [
     "wf_ctx_create", "wf_ctx_destroy", "wf_last_error", "wf_device_count", "wf_ctx_synchronize", "wf_ctx_stream",
-    "wf_ctx_profile_enable", "wf_ctx_profile_read", "wf_params_check", "wf_elem_bytes", "wf_row_width", "wf_column_bytes", "wf_lde_bytes", "wf_digests_bytes",
+    "wf_ctx_release_cached", "wf_ctx_profile_enable", "wf_ctx_profile_read", "wf_params_check", "wf_elem_bytes", "wf_row_width", "wf_column_bytes", "wf_lde_bytes", "wf_digests_bytes",
     "wf_trace_commit", "wf_constraint_commit", "wf_trace_commit_dev", "wf_constraint_commit_dev",
     "wf_trace_commit_shard_dev", "wf_merkle_build_dev", "wf_trace_commit_resident", "wf_constraint_commit_resident", "wf_commitment_destroy", "wf_commitment_root",
     "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_prove", "wf_commitment_prove_batch",
@@ -187,6 +187,10 @@ class Context:
         self._h = C.c_void_p()
         _check(load().wf_ctx_create(device, C.byref(self._h)))
         self.device = device
+
+    def release_cached(self):
+        """Return the parked buffers of destroyed resident commitments to the driver (wf_ctx_release_cached)."""
+        _check(load().wf_ctx_release_cached(self._h))
 
     def close(self):
         if self._h:

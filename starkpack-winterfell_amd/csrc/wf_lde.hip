@@ -67,7 +67,35 @@ struct wf_ctx {
     DevBuf io[5];     // staging for the host-buffer API: trace, polys, lde, leaves, nodes
     DevBuf hash_tmp;  // chunk chaining values of rows longer than one BLAKE3 chunk
     DevBuf tickets;   // per-XCD tile counters of the persistent last pass
+    // Buffers of destroyed resident commitments, kept for the next commitment of the same shape (four hipFree + four
+    // hipMalloc of 64..512 MiB cost about as much as the commitment itself); released by wf_ctx_release_cached / destroy.
+    std::vector<std::pair<void *, size_t>> pool;
 };
+
+static hipError_t pool_alloc(wf_ctx *ctx, void **p, size_t bytes) {
+    for (size_t i = 0; i < ctx->pool.size(); i++)
+        if (ctx->pool[i].second == bytes) {
+            *p = ctx->pool[i].first;
+            ctx->pool.erase(ctx->pool.begin() + i);
+            return hipSuccess;
+        }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess && !ctx->pool.empty()) {  // out of memory with buffers of other sizes parked: release them, retry
+        (void)hipGetLastError();
+        for (auto &b : ctx->pool) (void)hipFree(b.first);
+        ctx->pool.clear();
+        e = hipMalloc(p, bytes);
+    }
+    return e;
+}
+
+static void pool_free(wf_ctx *ctx, void *p, size_t bytes) {
+    if (!p) return;
+    if (bytes && ctx->pool.size() < 16)
+        ctx->pool.emplace_back(p, bytes);
+    else
+        (void)hipFree(p);
+}
 
 // logical kernel of a mark: the text before the first '.', with the layout changes counted as interpolation
 static int prof_group(const char *name) {
@@ -974,9 +1002,18 @@ void wf_ctx_destroy(wf_ctx *ctx) {
         if (b.p) (void)hipFree(b.p);
     if (ctx->hash_tmp.p) (void)hipFree(ctx->hash_tmp.p);
     if (ctx->tickets.p) (void)hipFree(ctx->tickets.p);
+    for (auto &b : ctx->pool) (void)hipFree(b.first);
     for (auto e : ctx->prof_ev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+int wf_ctx_release_cached(wf_ctx *ctx) {
+    if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (auto &b : ctx->pool) (void)hipFree(b.first);
+    ctx->pool.clear();
+    return 0;
 }
 
 int wf_ctx_synchronize(wf_ctx *ctx) {
@@ -1168,17 +1205,18 @@ struct wf_commitment {
     uint32_t depth;
     uint8_t root[32];
     bool borrowed;  // lde / leaves / nodes live in an arena of their owner (FRI layers): not freed one by one
+    size_t lde_bytes, dig_bytes, polys_bytes;  // allocation sizes when they come from the context's buffer pool (else 0)
 };
 
 static void free_commitment(wf_commitment *c) {
     if (!c) return;
     (void)hipSetDevice(c->ctx->device);
     if (!c->borrowed) {
-        if (c->lde) (void)hipFree(c->lde);
-        if (c->leaves) (void)hipFree(c->leaves);
-        if (c->nodes) (void)hipFree(c->nodes);
+        pool_free(c->ctx, c->lde, c->lde_bytes);
+        pool_free(c->ctx, c->leaves, c->dig_bytes);
+        pool_free(c->ctx, c->nodes, c->dig_bytes);
     }
-    if (c->polys) (void)hipFree(c->polys);
+    pool_free(c->ctx, c->polys, c->polys_bytes);
     delete c;
 }
 
@@ -1204,8 +1242,11 @@ static int commit_resident(wf_ctx *ctx, const wf_params *p, bool constraint, con
     c->row_elems = c->epr * p->n_traces;
     c->depth = p->log2_trace_len + p->log2_blowup;
     hipError_t e;
-    if ((e = hipMalloc(&c->lde, ldeb * p->n_traces)) != hipSuccess || (e = hipMalloc(&c->leaves, digb)) != hipSuccess ||
-        (e = hipMalloc(&c->nodes, digb)) != hipSuccess || (e = hipMalloc(&c->polys, TC * colb)) != hipSuccess) {
+    c->lde_bytes = ldeb * p->n_traces;
+    c->dig_bytes = digb;
+    c->polys_bytes = TC * colb;
+    if ((e = pool_alloc(ctx, &c->lde, c->lde_bytes)) != hipSuccess || (e = pool_alloc(ctx, &c->leaves, digb)) != hipSuccess ||
+        (e = pool_alloc(ctx, &c->nodes, digb)) != hipSuccess || (e = pool_alloc(ctx, &c->polys, c->polys_bytes)) != hipSuccess) {
         free_commitment(c);
         return fail(WF_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
     }
