@@ -1,0 +1,54 @@
+"""Wall clock of the GPU side of one proof at the bench scale, chained as Prover::generate_proof chains it
+(prover/src/lib.rs:240-610) with every handle resident: trace commitment -> OOD frame -> constraint commitment ->
+FRI commit phase on a DEEP polynomial -> queries of all trees.  Constraint evaluation and DEEP composition (user code in
+the reference) are replaced by random polynomials of the right shape.
+    python scripts/time_pipeline.py [logR] [cols] [n_traces]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import starkpack_winterfell_amd.capi as capi
+
+logR = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+cols = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+n_traces = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+logB, ext, folding, max_rem, n_queries = 3, 2, 4, 127, 50
+R, N = 1 << logR, 1 << (logR + logB)
+ctx = capi.Context(0)
+rng = np.random.default_rng(1)
+trace = [rng.integers(0, 2**62, size=R, dtype=np.uint64) for _ in range(cols * n_traces)]
+comp = [rng.integers(0, 2**62, size=(R, ext), dtype=np.uint64) for _ in range(2)]
+deep = rng.integers(0, 2**62, size=(R, ext), dtype=np.uint64)
+z = rng.integers(0, 2**62, size=ext, dtype=np.uint64)
+pos = np.sort(rng.choice(N, size=n_queries, replace=False)).astype(np.uint64)
+fri = capi.FriProver(ctx, capi.F64, ext, folding, 1 << logB, max_rem, 7)
+n_layers = capi.fri_num_layers(folding, 1 << logB, max_rem, N)
+alphas = [rng.integers(0, 2**62, size=ext, dtype=np.uint64) for _ in range(n_layers)]
+for rep in range(4):
+    t = [time.perf_counter()]
+    tcom, _ = ctx.trace_commit_resident(capi.make_params(capi.F64, 1, logR, logB, cols, n_traces), trace, want_polys=False)
+    t.append(time.perf_counter())
+    tcom.evaluate_polys_at(z, ext, cols * n_traces)
+    tcom.evaluate_polys_at(z, ext, cols * n_traces)      # z * g
+    t.append(time.perf_counter())
+    ccom = ctx.constraint_commit_resident(capi.make_params(capi.F64, ext, logR, logB, 2, 1), comp)
+    t.append(time.perf_counter())
+    fri.begin_poly(deep, 1 << logB)
+    for i in range(n_layers):
+        fri.commit_layer()
+        fri.fold(alphas[i])
+    fri.set_remainder(1 << 12)
+    t.append(time.perf_counter())
+    tcom.read_rows(pos); tcom.prove_batch(pos)
+    ccom.read_rows(pos); ccom.prove_batch(pos)
+    p, size = pos, N
+    for i in range(n_layers):
+        p = capi.fri_fold_positions(p, size, folding)
+        lay = fri.layer(i)
+        lay.read_rows(p); lay.prove_batch(p)
+        size //= folding
+    t.append(time.perf_counter())
+    fri.reset(); tcom.close(); ccom.close()
+    t.append(time.perf_counter())
+    d = [(b - a) * 1e3 for a, b in zip(t, t[1:])]
+    print(f"rep {rep}: trace commit {d[0]:.2f}  OOD frame {d[1]:.2f}  constraint commit {d[2]:.2f}  FRI commit phase {d[3]:.2f}  "
+          f"queries {d[4]:.2f}  release {d[5]:.2f}  total {sum(d):.2f} ms")

@@ -1604,7 +1604,11 @@ static int eval_columns_at_dev(wf_ctx *ctx, hipStream_t st, const void *d_polys,
     memcpy(a.z, z_host, ext_z * sizeof(T));
     for (uint32_t w = 0; w < ext_z; w++)
         if (!F::is_valid(a.z[w])) return fail(WF_ERR_ARG, "z is not a valid field element");
-    const dim3 grid((uint32_t)n_cols), block(256);
+    a.n_blocks = (uint32_t)((n + EVAL_BLOCK - 1) / EVAL_BLOCK);
+    int rcp = ensure(ctx->hash_tmp, n_cols * a.n_blocks * ext_z * sizeof(T));  // (block values; no hashing runs alongside)
+    if (rcp) return rcp;
+    a.partial = (T *)ctx->hash_tmp.p;
+    const dim3 grid(a.n_blocks, (uint32_t)n_cols), grid2((uint32_t)n_cols), block(256);
     prof_mark(ctx, st, "ood.evaluate_columns_at");
     const uint32_t key = ext_c * 10 + ext_z;
     switch (key) {
@@ -1619,6 +1623,14 @@ static int eval_columns_at_dev(wf_ctx *ctx, hipStream_t st, const void *d_polys,
             return fail(WF_ERR_EXTENSION, "f128 has no cubic extension");
         default:
             return fail(WF_ERR_EXTENSION, "cannot evaluate degree-%u extension coefficients at a degree-%u extension point", ext_c, ext_z);
+    }
+    HIP_TRY(hipGetLastError());
+    switch (ext_z) {
+        case 1: hipLaunchKernelGGL((k_eval_columns_sum<F, 1>), grid2, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((k_eval_columns_sum<F, 2>), grid2, block, 0, st, a); break;
+        default:
+            if constexpr (F::FIELD_ID == 1) hipLaunchKernelGGL((k_eval_columns_sum<F, 3>), grid2, block, 0, st, a);
+            break;
     }
     HIP_TRY(hipGetLastError());
     prof_mark(ctx, st, "between_calls");

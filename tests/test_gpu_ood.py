@@ -11,7 +11,7 @@ F64, F128 = 1, 2
 
 @pytest.mark.parametrize("field,ext_c,ext_z", [(F64, 1, 1), (F64, 1, 2), (F64, 1, 3), (F64, 2, 2), (F64, 3, 3),
                                                (F128, 1, 1), (F128, 1, 2), (F128, 2, 2)])
-@pytest.mark.parametrize("logn", [3, 7, 8, 13])
+@pytest.mark.parametrize("logn", [3, 7, 8, 12, 13, 17])   # below / at / above one 4096-coefficient block, many blocks
 def test_evaluate_columns_at(ctx, orc, field, ext_c, ext_z, logn):
     rng = np.random.default_rng(logn * 10 + ext_z)
     n = 1 << logn
