@@ -190,6 +190,12 @@ int wf_commitment_prove(const wf_commitment *c, uint64_t index, uint8_t *path_ou
 int wf_commitment_prove_batch(const wf_commitment *c, const uint64_t *positions, size_t n, uint8_t *leaves_out,
                               uint8_t *nodes_out, size_t nodes_capacity, uint32_t *node_counts, size_t *n_vectors,
                               size_t *n_nodes, uint32_t *depth_out);
+/* TraceCommitment::query / ConstraintCommitment::query (prover/src/trace/commitment.rs:87-111,
+ * prover/src/constraints/commitment.rs:54-69) and FriProver::query_layer (fri/src/prover/mod.rs:266-300): the queried
+ * rows (as wf_commitment_read_rows) AND their batch proof (as wf_commitment_prove_batch) in one host round trip. */
+int wf_commitment_query(const wf_commitment *c, const uint64_t *positions, size_t n, void *rows_out, uint8_t *leaves_out,
+                        uint8_t *nodes_out, size_t nodes_capacity, uint32_t *node_counts, size_t *n_vectors, size_t *n_nodes,
+                        uint32_t *depth_out);
 
 /* ---- FRI layer commitments ---------------------------------------------------------------------- */
 

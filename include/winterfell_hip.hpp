@@ -350,9 +350,6 @@ class TraceCommitment {
         std::vector<uint64_t> pos(positions.begin(), positions.end());
         const size_t n = pos.size(), row_elems = n_traces_ * epr_;
         std::vector<typename E::BaseField> flat(n * row_elems);
-        wf_check(wf_commitment_read_rows(h_, pos.data(), n, flat.data()));
-        std::vector<std::vector<typename E::BaseField>> rows;
-        for (size_t i = 0; i < n; i++) rows.emplace_back(flat.begin() + i * row_elems, flat.begin() + (i + 1) * row_elems);
         const size_t depth = tree_depth();
         BatchMerkleProof proof;
         proof.leaves.resize(n);
@@ -360,8 +357,11 @@ class TraceCommitment {
         std::vector<uint32_t> counts(n);
         size_t n_vec = 0, n_nodes = 0;
         uint32_t d = 0;
-        wf_check(wf_commitment_prove_batch(h_, pos.data(), n, proof.leaves[0].data(), nodes[0].data(), nodes.size(),
-                                           counts.data(), &n_vec, &n_nodes, &d));
+        // rows and proof in one host round trip
+        wf_check(wf_commitment_query(h_, pos.data(), n, flat.data(), proof.leaves[0].data(), nodes[0].data(), nodes.size(),
+                                     counts.data(), &n_vec, &n_nodes, &d));
+        std::vector<std::vector<typename E::BaseField>> rows;
+        for (size_t i = 0; i < n; i++) rows.emplace_back(flat.begin() + i * row_elems, flat.begin() + (i + 1) * row_elems);
         size_t k = 0;
         for (size_t i = 0; i < n_vec; i++) {
             proof.nodes.emplace_back(nodes.begin() + k, nodes.begin() + k + counts[i]);
@@ -498,17 +498,16 @@ class FriProver {
             wf_check(wf_commitment_info(layer, &n_rows, &row_elems, &depth));
             const size_t words = row_elems * (sizeof(typename E::BaseField) / 8);
             std::vector<uint64_t> flat(m * words);
-            wf_check(wf_commitment_read_rows(layer, folded.data(), m, flat.data()));
             FriProofLayer pl;
             pl.positions = folded;
-            for (size_t j = 0; j < m; j++) pl.values.emplace_back(flat.begin() + j * words, flat.begin() + (j + 1) * words);
             pl.proof.leaves.resize(m);
             std::vector<Digest> nodes(m * (depth + 1));
             std::vector<uint32_t> counts(m);
             size_t n_vec = 0, n_nodes = 0;
             uint32_t d = 0;
-            wf_check(wf_commitment_prove_batch(layer, folded.data(), m, pl.proof.leaves[0].data(), nodes[0].data(), nodes.size(),
-                                               counts.data(), &n_vec, &n_nodes, &d));
+            wf_check(wf_commitment_query(layer, folded.data(), m, flat.data(), pl.proof.leaves[0].data(), nodes[0].data(),
+                                         nodes.size(), counts.data(), &n_vec, &n_nodes, &d));
+            for (size_t j = 0; j < m; j++) pl.values.emplace_back(flat.begin() + j * words, flat.begin() + (j + 1) * words);
             size_t k = 0;
             for (size_t v = 0; v < n_vec; v++) {
                 pl.proof.nodes.emplace_back(nodes.begin() + k, nodes.begin() + k + counts[v]);

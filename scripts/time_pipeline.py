@@ -38,13 +38,13 @@ for rep in range(4):
         fri.fold(alphas[i])
     fri.set_remainder(1 << 12)
     t.append(time.perf_counter())
-    tcom.read_rows(pos); tcom.prove_batch(pos)
-    ccom.read_rows(pos); ccom.prove_batch(pos)
+    tcom.query(pos)
+    ccom.query(pos)
     p, size = pos, N
     for i in range(n_layers):
         p = capi.fri_fold_positions(p, size, folding)
         lay = fri.layer(i)
-        lay.read_rows(p); lay.prove_batch(p)
+        lay.query(p)
         size //= folding
     t.append(time.perf_counter())
     fri.reset(); tcom.close(); ccom.close()

@@ -18,7 +18,7 @@ ELEM_WORDS = {F64: 1, F128: 2}
 
 SYMBOLS = [
     "wf_ctx_create", "wf_ctx_destroy", "wf_last_error", "wf_device_count", "wf_ctx_synchronize", "wf_ctx_stream",
-    "wf_ctx_release_cached", "wf_ctx_profile_enable", "wf_ctx_profile_read", "wf_params_check", "wf_elem_bytes", "wf_row_width", "wf_column_bytes", "wf_lde_bytes", "wf_digests_bytes",
+    "wf_ctx_release_cached", "wf_commitment_query", "wf_ctx_profile_enable", "wf_ctx_profile_read", "wf_params_check", "wf_elem_bytes", "wf_row_width", "wf_column_bytes", "wf_lde_bytes", "wf_digests_bytes",
     "wf_trace_commit", "wf_constraint_commit", "wf_trace_commit_dev", "wf_constraint_commit_dev",
     "wf_trace_commit_shard_dev", "wf_merkle_build_dev", "wf_trace_commit_resident", "wf_constraint_commit_resident", "wf_commitment_destroy", "wf_commitment_root",
     "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_prove", "wf_commitment_prove_batch",
@@ -442,6 +442,25 @@ class Commitment:
             out.append([bytes(nodes[k + j]) for j in range(int(counts[i]))])
             k += int(counts[i])
         return [bytes(x) for x in leaves[:n]], out, depth.value
+
+    def query(self, positions):
+        """TraceCommitment::query: (rows, (leaves, nodes, depth)) in one round trip (wf_commitment_query)."""
+        pos = np.ascontiguousarray(positions, dtype=np.uint64)
+        n = len(pos)
+        w = ELEM_WORDS[self.field]
+        rows = np.empty((n, self.row_elems, w) if w > 1 else (n, self.row_elems), dtype=np.uint64)
+        cap = max(1, n) * (self.depth + 1)
+        leaves = np.empty((max(1, n), 32), dtype=np.uint8)
+        nodes = np.empty((cap, 32), dtype=np.uint8)
+        counts = np.zeros(max(1, n), dtype=np.uint32)
+        n_vec, n_nodes, depth = C.c_size_t(), C.c_size_t(), C.c_uint32()
+        _check(load().wf_commitment_query(self._h, _p(pos), n, _p(rows), _p(leaves), _p(nodes), cap, _p(counts),
+                                          C.byref(n_vec), C.byref(n_nodes), C.byref(depth)))
+        out, k = [], 0
+        for i in range(n_vec.value):
+            out.append([bytes(nodes[k + j]) for j in range(int(counts[i]))])
+            k += int(counts[i])
+        return rows, ([bytes(x) for x in leaves[:n]], out, depth.value)
 
 
 def fri_num_layers(folding: int, blowup: int, remainder_max_degree: int, domain_size: int) -> int:

@@ -1375,13 +1375,10 @@ int wf_commitment_prove(const wf_commitment *c, uint64_t index, uint8_t *path_ou
     return fetch_digests(c, ids, path_out);
 }
 
-int wf_commitment_prove_batch(const wf_commitment *c, const uint64_t *positions, size_t n, uint8_t *leaves_out,
-                              uint8_t *nodes_out, size_t nodes_capacity, uint32_t *node_counts, size_t *n_vectors,
-                              size_t *n_nodes, uint32_t *depth_out) {
-    int rc = check_positions(c, positions, n);
-    if (rc) return rc;
-    if (!leaves_out || !nodes_out || !node_counts || !n_vectors || !n_nodes) return fail(WF_ERR_ARG, "null argument");
-    HIP_TRY(hipSetDevice(c->ctx->device));
+// The digests a BatchMerkleProof of `positions` consists of (MerkleTree::prove_batch, merkle/mod.rs:222-284), as ids for
+// k_gather_digests (id < n_rows: leaf, else node id - n_rows): vec_ids[i] = the nodes vector of the i-th normalised index.
+static int batch_proof_ids(const wf_commitment *c, const uint64_t *positions, size_t n, std::vector<std::vector<uint64_t>> &vec_ids,
+                           size_t &total) {
     // map_indexes (merkle/mod.rs:376-395): duplicates are an error
     std::map<uint64_t, size_t> index_map;
     for (size_t i = 0; i < n; i++) index_map[positions[i]] = i;
@@ -1393,7 +1390,7 @@ int wf_commitment_prove_batch(const wf_commitment *c, const uint64_t *positions,
         if (idx.empty() || idx.back() != e) idx.push_back(e);
     }
     // ids of the digests of each vector, in the order prove_batch pushes them (:238-276)
-    std::vector<std::vector<uint64_t>> vec_ids(idx.size());
+    vec_ids.assign(idx.size(), {});
     std::vector<uint64_t> next;
     const uint64_t nl = c->n_rows;
     for (size_t i = 0; i < idx.size(); i++) {
@@ -1415,15 +1412,56 @@ int wf_commitment_prove_batch(const wf_commitment *c, const uint64_t *positions,
             i += 1;
         }
     }
-    size_t total = 0;
+    total = 0;
     for (auto &v : vec_ids) total += v.size();
-    if (total > nodes_capacity) return fail(WF_ERR_ARG, "nodes_out too small: %zu digests needed", total);
-    std::vector<uint64_t> ids;
-    for (size_t i = 0; i < n; i++) ids.push_back(positions[i]);
-    for (auto &v : vec_ids) ids.insert(ids.end(), v.begin(), v.end());
-    std::vector<uint8_t> buf(ids.size() * 32);
-    rc = fetch_digests(c, ids, buf.data());
+    return 0;
+}
+
+// rows_out == nullptr: the proof only
+static int query_impl(const wf_commitment *c, const uint64_t *positions, size_t n, void *rows_out, uint8_t *leaves_out,
+                      uint8_t *nodes_out, size_t nodes_capacity, uint32_t *node_counts, size_t *n_vectors, size_t *n_nodes,
+                      uint32_t *depth_out) {
+    int rc = check_positions(c, positions, n);
     if (rc) return rc;
+    if (!leaves_out || !nodes_out || !node_counts || !n_vectors || !n_nodes) return fail(WF_ERR_ARG, "null argument");
+    wf_ctx *ctx = c->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<std::vector<uint64_t>> vec_ids;
+    size_t total = 0;
+    if ((rc = batch_proof_ids(c, positions, n, vec_ids, total))) return rc;
+    if (total > nodes_capacity) return fail(WF_ERR_ARG, "nodes_out too small: %zu digests needed", total);
+    std::vector<uint64_t> ids(positions, positions + n);  // the queried leaves first: also the positions of the row gather
+    for (auto &v : vec_ids) ids.insert(ids.end(), v.begin(), v.end());
+    // one upload, the gathers, one download, one synchronisation
+    const size_t eb = wf_elem_bytes(c->p.field);
+    const size_t rows_bytes = rows_out ? ((n * c->row_elems * eb + 255) & ~(size_t)255) : 0, dig_bytes = ids.size() * 32;
+    if ((rc = ensure(ctx->io[3], ids.size() * 8))) return rc;
+    if ((rc = ensure(ctx->io[4], rows_bytes + dig_bytes))) return rc;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->io[3].p, ids.data(), ids.size() * 8, hipMemcpyHostToDevice, st));
+    if (rows_out && n) {
+        const uint64_t trace_elems = c->n_rows * c->row_width;
+        if (c->p.field == WF_FIELD_F64)
+            hipLaunchKernelGGL(k_gather_rows<F64>, dim3((uint32_t)n, c->p.n_traces), dim3(64), 0, st, (const uint64_t *)c->lde,
+                               trace_elems, (uint32_t)c->row_width, (uint32_t)c->epr, (const uint64_t *)ctx->io[3].p,
+                               (uint64_t *)ctx->io[4].p);
+        else
+            hipLaunchKernelGGL(k_gather_rows<F128>, dim3((uint32_t)n, c->p.n_traces), dim3(64), 0, st, (const U128 *)c->lde,
+                               trace_elems, (uint32_t)c->row_width, (uint32_t)c->epr, (const uint64_t *)ctx->io[3].p,
+                               (U128 *)ctx->io[4].p);
+        HIP_TRY(hipGetLastError());
+    }
+    std::vector<uint8_t> buf(dig_bytes);
+    if (!ids.empty()) {
+        const uint32_t nid = (uint32_t)ids.size();
+        hipLaunchKernelGGL(k_gather_digests, dim3((2 * nid + 255) / 256), dim3(256), 0, st, (const uint4 *)c->leaves,
+                           (const uint4 *)c->nodes, c->n_rows, (const uint64_t *)ctx->io[3].p, nid,
+                           (uint4 *)((char *)ctx->io[4].p + rows_bytes));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(buf.data(), (char *)ctx->io[4].p + rows_bytes, dig_bytes, hipMemcpyDeviceToHost, st));
+    }
+    if (rows_out && n) HIP_TRY(hipMemcpyAsync(rows_out, ctx->io[4].p, n * c->row_elems * eb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     memcpy(leaves_out, buf.data(), n * 32);
     memcpy(nodes_out, buf.data() + n * 32, total * 32);
     for (size_t i = 0; i < vec_ids.size(); i++) node_counts[i] = (uint32_t)vec_ids[i].size();
@@ -1431,6 +1469,19 @@ int wf_commitment_prove_batch(const wf_commitment *c, const uint64_t *positions,
     *n_nodes = total;
     if (depth_out) *depth_out = c->depth;
     return 0;
+}
+
+int wf_commitment_prove_batch(const wf_commitment *c, const uint64_t *positions, size_t n, uint8_t *leaves_out,
+                              uint8_t *nodes_out, size_t nodes_capacity, uint32_t *node_counts, size_t *n_vectors,
+                              size_t *n_nodes, uint32_t *depth_out) {
+    return query_impl(c, positions, n, nullptr, leaves_out, nodes_out, nodes_capacity, node_counts, n_vectors, n_nodes, depth_out);
+}
+
+int wf_commitment_query(const wf_commitment *c, const uint64_t *positions, size_t n, void *rows_out, uint8_t *leaves_out,
+                        uint8_t *nodes_out, size_t nodes_capacity, uint32_t *node_counts, size_t *n_vectors, size_t *n_nodes,
+                        uint32_t *depth_out) {
+    if (!rows_out) return fail(WF_ERR_ARG, "rows_out is null");
+    return query_impl(c, positions, n, rows_out, leaves_out, nodes_out, nodes_capacity, node_counts, n_vectors, n_nodes, depth_out);
 }
 
 // FRI layer pieces --------------------------------------------------------------------------------

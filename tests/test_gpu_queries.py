@@ -48,6 +48,8 @@ def test_resident_trace_commitment_queries(ctx, orc, capi, field, ext, logR, log
     for sel in (positions, positions[:1], [6, 7], [N - 2, N - 1, 0], sorted(positions)[:17]):
         got = com.prove_batch(sel)
         assert got == orc.merkle_prove_batch(want["nodes"], want["leaves"], sel)
+        q_rows, q_proof = com.query(sel)                 # both in one round trip (TraceCommitment::query)
+        assert np.array_equal(q_rows, com.read_rows(sel)) and q_proof == got
     com.close()
 
 
@@ -62,6 +64,8 @@ def test_resident_constraint_commitment(ctx, orc, capi):
     for i, p in enumerate(pos):
         assert np.array_equal(rows[i], want["lde"][p, :8])
     assert com.prove_batch(pos) == orc.merkle_prove_batch(want["nodes"], want["leaves"], pos)
+    q_rows, q_proof = com.query(pos)
+    assert np.array_equal(q_rows, rows) and q_proof == com.prove_batch(pos)
     com.close()
 
 
@@ -72,6 +76,8 @@ def test_query_errors(ctx, capi):
     for bad, code in (([], -19), (list(range(128)) * 2, -19), ([1, 1], -18), ([128], -18)):
         with pytest.raises(capi.WfError) as e:
             com.prove_batch(bad)
+        with pytest.raises(capi.WfError) as e:
+            com.query(bad)
         assert e.value.code == code
     with pytest.raises(capi.WfError) as e:
         com.read_rows([500])
