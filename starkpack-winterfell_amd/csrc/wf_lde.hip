@@ -646,7 +646,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             if (!ctx->tickets.p) {  // zeroed once: the kernel leaves its counters at zero
                 int rcq = ensure(ctx->tickets, 64);
                 if (rcq) return rcq;
-                HIP_TRY(hipMemset(ctx->tickets.p, 0, 64));
+                HIP_TRY(hipMemsetAsync(ctx->tickets.p, 0, 64, st));  // ordered on the launch stream (first use only)
             }
             a.tile_counters = (uint32_t *)ctx->tickets.p;
             void *kargs[] = {&a};
