@@ -1024,8 +1024,10 @@ __device__ __forceinline__ uint32_t opaque_tid() {
 // MULTI = false: one segment of one trace (the bench workload) -- no chaining values to carry, one lane pair mapping.
 // CHUNKED (with MULTI): rows longer than one BLAKE3 chunk -- a ticket is (coset, row block, chunk): the work-group walks the
 // 16 segments of that chunk and writes the rows' chunk chaining values; k_hash_merge_chunks folds them into the leaves.
-template <class F, bool MULTI, bool PADT = false, bool CHUNKED = false>  // PADT: SegArgs::pad_traces (kept out of the other instantiations' registers)
-__global__ void __launch_bounds__(F::BYTES == 8 ? 1024 : 512) k_seg_last_hash(SegArgs<F> a) {  // f128 tiles: D <= 2^10
+// SMALL: tiles of at most 2^9 rows (<= 256 threads): compiled without the 128-VGPR cap that 1024-thread work-groups impose
+// (the multi-segment variants spill a few registers under it)
+template <class F, bool MULTI, bool PADT = false, bool CHUNKED = false, bool SMALL = false>  // PADT: SegArgs::pad_traces (kept out of the other instantiations' registers)
+__global__ void __launch_bounds__(SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512)) k_seg_last_hash(SegArgs<F> a) {  // f128 tiles: D <= 2^10
     typedef typename F::T T;
     typedef Pair<T> P2;
     constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;

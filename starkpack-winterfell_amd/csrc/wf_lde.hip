@@ -630,9 +630,12 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         prof_mark(ctx, st, tag_l);
         if (persistent) {
             const bool multi = d.n_seg > 1 || d.total_base_cols != d.base_cols;
+            const bool small = threads <= 256;  // the multi-segment variants without the 128-VGPR cap (2^22 x 64: last pass -3 %)
             const void *kern =
-                chunked ? (a.pad_traces ? (const void *)k_seg_last_hash<F, true, true, true> : (const void *)k_seg_last_hash<F, true, false, true>)
-                : multi ? (a.pad_traces ? (const void *)k_seg_last_hash<F, true, true> : (const void *)k_seg_last_hash<F, true, false>)
+                chunked ? (a.pad_traces ? (small ? (const void *)k_seg_last_hash<F, true, true, true, true> : (const void *)k_seg_last_hash<F, true, true, true>)
+                                        : (small ? (const void *)k_seg_last_hash<F, true, false, true, true> : (const void *)k_seg_last_hash<F, true, false, true>))
+                : multi ? (a.pad_traces ? (small ? (const void *)k_seg_last_hash<F, true, true, false, true> : (const void *)k_seg_last_hash<F, true, true>)
+                                        : (small ? (const void *)k_seg_last_hash<F, true, false, false, true> : (const void *)k_seg_last_hash<F, true, false>))
                         : (a.pad_traces ? (const void *)k_seg_last_hash<F, false, true> : (const void *)k_seg_last_hash<F, false, false>);
             if (chunked) {
                 int rcc = ensure(ctx->hash_tmp, (size_t)launch_rows * n_chunks * 32);
