@@ -46,9 +46,11 @@ def test_fft_evaluate_and_interpolate(ctx, orc, field, ext, logn):
 
 
 @pytest.mark.parametrize("field,offset", [(F64, 7), (F64, 12345678901234567), (F128, 3), (F128, 2**100 + 17)])
-@pytest.mark.parametrize("ext", [1, 2])
+@pytest.mark.parametrize("ext", [1, 2, 3])
 @pytest.mark.parametrize("logn", [3, 6, 10, 12])
 def test_fft_with_offset(ctx, orc, field, offset, ext, logn):
+    if field == F128 and ext == 3:
+        pytest.skip("f128 has no cubic extension (f128/mod.rs:296-314)")
     rng = np.random.default_rng(7 * logn + ext)
     n = 1 << logn
     p = _rand(rng, field, n * ext)
