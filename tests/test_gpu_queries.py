@@ -87,3 +87,31 @@ def test_query_errors(ctx, capi):
     assert e.value.code == -18
     assert len(com.prove_batch(list(range(128)))[0]) == 128   # every leaf: no internal nodes needed
     com.close()
+
+
+def test_parked_buffers_are_reused_and_released(ctx, orc, capi):
+    """A destroyed resident commitment leaves its device buffers with the context (wf_ctx_release_cached hands them back);
+    the next commitment of the same shape must not see anything of the previous one."""
+    import torch
+    rng = np.random.default_rng(5)
+    p = capi.make_params(F64, 1, 12, 3, 8, 1)
+    roots = []
+    for rep in range(3):
+        cols = rand_cols(rng, F64, 8, 1 << 12)
+        want = orc.build_trace_commitment(F64, [cols], 1, 12, 3, 7)
+        com, _ = ctx.trace_commit_resident(p, cols)
+        assert com.root() == want["root"]
+        pos = [1, 77, (1 << 15) - 1]
+        rows, proof = com.query(pos)
+        for i, q in enumerate(pos):
+            assert np.array_equal(rows[i], want["lde"][0][q, :8])
+        assert proof == orc.merkle_prove_batch(want["nodes"], want["leaves"], pos)
+        roots.append(com.root())
+        com.close()
+    assert len(set(roots)) == 3
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info(0)[0]
+    ctx.release_cached()
+    free_after = torch.cuda.mem_get_info(0)[0]
+    assert free_after >= free_before + (1 << 15) * 64       # at least the parked LDE (2 MiB) came back
+    ctx.release_cached()                                      # idempotent
