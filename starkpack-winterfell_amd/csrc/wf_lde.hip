@@ -962,6 +962,16 @@ static bool dense_column_ok(const wf_params *p) {
     return packed_shape<F>(1, p->ext_degree, p->ext_degree, 1u << p->log2_blowup, &cpr, &lg);
 }
 
+// The same for a whole narrow matrix of one trace (n_cols * ext_degree <= S/2 base columns): rows of exactly that many
+// elements.  Used by resident constraint commitments, whose LDE only ever leaves the device through row queries.
+static bool dense_matrix_ok(const wf_params *p) {
+    if (p->n_traces != 1) return false;
+    const uint32_t base = p->n_cols * p->ext_degree;
+    uint32_t cpr, lg;
+    return p->field == WF_FIELD_F64 ? packed_shape<F64>(1, base, base, 1u << p->log2_blowup, &cpr, &lg)
+                                    : packed_shape<F128>(1, base, base, 1u << p->log2_blowup, &cpr, &lg);
+}
+
 // ------------------------------------------------------------------------------------------------- C ABI
 extern "C" {
 
@@ -1240,12 +1250,15 @@ static int commit_resident(wf_ctx *ctx, const wf_params *p, bool constraint, con
     c->ctx = ctx;
     c->p = *p;
     c->n_rows = (uint64_t)1 << (p->log2_trace_len + p->log2_blowup);
-    c->row_width = wf_row_width(p);
     c->epr = (uint64_t)p->n_cols * p->ext_degree;
+    // a resident constraint commitment of a narrow matrix keeps its rows dense (no padding to 8 elements: a quarter of
+    // the LDE bytes for one E column); nothing outside this library sees the row stride of a resident LDE
+    const bool dense = constraint && dense_matrix_ok(p);
+    c->row_width = dense ? c->epr : wf_row_width(p);
     c->row_elems = c->epr * p->n_traces;
     c->depth = p->log2_trace_len + p->log2_blowup;
     hipError_t e;
-    c->lde_bytes = ldeb * p->n_traces;
+    c->lde_bytes = dense ? c->n_rows * c->row_width * wf_elem_bytes(p->field) : ldeb * p->n_traces;
     c->dig_bytes = digb;
     c->polys_bytes = TC * colb;
     if ((e = pool_alloc(ctx, &c->lde, c->lde_bytes)) != hipSuccess || (e = pool_alloc(ctx, &c->leaves, digb)) != hipSuccess ||
@@ -1268,7 +1281,8 @@ static int commit_resident(wf_ctx *ctx, const wf_params *p, bool constraint, con
         }
     }
     if (constraint)
-        rc = wf_constraint_commit_dev(ctx, p, c->polys, c->lde, c->leaves, c->nodes, st);
+        rc = p->field == WF_FIELD_F64 ? constraint_commit_dev<F64>(ctx, p, c->polys, c->lde, c->leaves, c->nodes, st, dense)
+                                      : constraint_commit_dev<F128>(ctx, p, c->polys, c->lde, c->leaves, c->nodes, st, dense);
     else
         rc = wf_trace_commit_dev(ctx, p, ctx->io[0].p, c->polys, c->lde, c->leaves, c->nodes, st);
     if (rc) {
