@@ -899,33 +899,22 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
             pa = pb = nullptr;
         }
         if (PACKED && a.store_cols != a.base_cols) {
-            // One trace, padded row of S (or 2 S) elements: whole rows leave this pass. A coset owns 2^lg lanes
-            // (lg >= 1: a lane pair is one 2-element slot of its row, and also writes the zero slots a multiple of the
-            // group size further along; lg == 0: each lane is a coset of its own and writes its whole row).
-            const uint32_t lg = a.lg_log, ncos = 1u << a.cpr_log, n_slots = (uint32_t)a.row_width / 2;
-            const P2 zz{F::zero(), F::zero()};
-            T *row_a = nullptr, *row_b = nullptr;
-            if (has_rows && (lane_a >> lg) < ncos)
-                row_a = a.dst + (((uint64_t)c << a.cpr_log) + (lane_a >> lg)) * a.row_width;
-            if (has_rows && lg == 0 && lane_b < ncos) row_b = a.dst + (((uint64_t)c << a.cpr_log) + lane_b) * a.row_width;
-            const uint32_t slot = lg ? ((lane_a & ((1u << lg) - 1)) >> 1) : 0, gs = lg ? (1u << (lg - 1)) : 1;
-            for (uint32_t pj = 0; (row_a || row_b) && pj < D; pj += pstride) {
-                const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, a.logD)) << out_shift);
-                const P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
-                const uint64_t off = (uint64_t)(uint32_t)k * k_stride;
-                if (lg) {
-                    store_pair(row_a + off + 2 * slot, v);
-                    for (uint32_t s2 = slot + gs; s2 < n_slots; s2 += gs) store_pair(row_a + off + 2 * s2, zz);
-                } else {
-                    if (row_a) {
-                        store_pair(row_a + off, P2{v.a, F::zero()});
-                        for (uint32_t s2 = 1; s2 < n_slots; s2++) store_pair(row_a + off + 2 * s2, zz);
-                    }
-                    if (row_b) {
-                        store_pair(row_b + off, P2{v.b, F::zero()});
-                        for (uint32_t s2 = 1; s2 < n_slots; s2++) store_pair(row_b + off + 2 * s2, zz);
-                    }
-                }
+            // One trace, padded rows of 8 elements (f64): whole rows leave this pass, four consecutive threads per row --
+            // 16-byte slot s of the row of (position pos, local coset j) is lanes j * 2^lg + 2 s, + 1 of the tile row while
+            // 2 s < 2^lg and zeros after that (the lanes past the last column are zero in the tile).  The four local
+            // rows of a position are adjacent in the LDE: 16 consecutive threads write 256 contiguous bytes.  (A lane
+            // pair writing its own slot and its row's zeros touched 64 different rows per store instruction.)
+            const uint32_t lg = a.lg_log, gl = 1u << lg, cpr = a.cpr_log;
+            const uint32_t n_items = (D << cpr) * 4;
+            for (uint32_t idx = threadIdx.x; idx < n_items; idx += blockDim.x) {
+                const uint32_t slot = idx & 3, rj = idx >> 2, j = rj & ((1u << cpr) - 1), pos = rj >> cpr;
+                const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << out_shift);
+                T *row = a.dst + (uint64_t)(uint32_t)k * k_stride + (((uint64_t)c << cpr) + j) * a.row_width + 2 * slot;
+                const T *xs = x + pos * S + (j << lg) + 2 * slot;
+                P2 v{F::zero(), F::zero()};
+                if (2 * slot < gl) v.a = xs[0];
+                if (2 * slot + 1 < gl) v.b = xs[1];
+                store_pair(row, v);
             }
             pa = pb = nullptr;
         }
