@@ -899,22 +899,28 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
             pa = pb = nullptr;
         }
         if (PACKED && a.store_cols != a.base_cols) {
-            // One trace, padded rows of 8 elements (f64): whole rows leave this pass, four consecutive threads per row --
-            // 16-byte slot s of the row of (position pos, local coset j) is lanes j * 2^lg + 2 s, + 1 of the tile row while
+            // One trace, padded rows of 8 elements: whole rows leave this pass, one thread per 16-byte unit (four per f64
+            // row, eight per f128 row) -- for f64, slot s of the row of (position pos, local coset j) is lanes j * 2^lg + 2 s, + 1 of the tile row while
             // 2 s < 2^lg and zeros after that (the lanes past the last column are zero in the tile).  The four local
             // rows of a position are adjacent in the LDE: 16 consecutive threads write 256 contiguous bytes.  (A lane
             // pair writing its own slot and its row's zeros touched 64 different rows per store instruction.)
             const uint32_t lg = a.lg_log, gl = 1u << lg, cpr = a.cpr_log;
-            const uint32_t n_items = (D << cpr) * 4;
+            constexpr uint32_t EPU = 16 / F::BYTES;                   // elements per 16-byte unit: 2 (f64) or 1 (f128)
+            const uint32_t upr = (uint32_t)a.row_width / EPU;          // units per row: 4 (f64) or 8 (f128) -- a power of two
+            const uint32_t n_items = (D << cpr) * upr;
             for (uint32_t idx = threadIdx.x; idx < n_items; idx += blockDim.x) {
-                const uint32_t slot = idx & 3, rj = idx >> 2, j = rj & ((1u << cpr) - 1), pos = rj >> cpr;
+                const uint32_t u = idx & (upr - 1), rj = idx / upr, j = rj & ((1u << cpr) - 1), pos = rj >> cpr;
                 const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << out_shift);
-                T *row = a.dst + (uint64_t)(uint32_t)k * k_stride + (((uint64_t)c << cpr) + j) * a.row_width + 2 * slot;
-                const T *xs = x + pos * S + (j << lg) + 2 * slot;
-                P2 v{F::zero(), F::zero()};
-                if (2 * slot < gl) v.a = xs[0];
-                if (2 * slot + 1 < gl) v.b = xs[1];
-                store_pair(row, v);
+                T *row = a.dst + (uint64_t)(uint32_t)k * k_stride + (((uint64_t)c << cpr) + j) * a.row_width + EPU * u;
+                const T *xs = x + pos * S + (j << lg) + EPU * u;
+                if (EPU == 2) {
+                    P2 v{F::zero(), F::zero()};
+                    if (2 * u < gl) v.a = xs[0];
+                    if (2 * u + 1 < gl) v.b = xs[1];
+                    store_pair(row, v);
+                } else {
+                    row[0] = u < gl ? xs[0] : F::zero();
+                }
             }
             pa = pb = nullptr;
         }

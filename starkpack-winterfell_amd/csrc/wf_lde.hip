@@ -854,14 +854,13 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
     if (rc) return rc;
     // Zero padding lanes (segments.rs:65-72): a single trace whose segments cover the padded row, or all but its last S
     // elements (f128 rows are padded to 2 S),
-    // gets them from the last evaluation pass (coset-packed f128 rows excepted: 128-byte rows written 32 bytes at a time
-    // by one lane measured slower than clearing them); everything else is cleared up front.
+    // gets them from the last evaluation pass; everything else is cleared up front.
     uint32_t cpr_unused, lg_unused;
     const uint64_t seg_lanes = (uint64_t)b.n_seg * SegCfg<F>::S;
     const bool pad_in_kernel = row_width != base_cols && p->n_traces == 1 &&
                                (seg_lanes == row_width || seg_lanes + SegCfg<F>::S == row_width) &&
                                (b.total_base_cols * 2 > SegCfg<F>::S ||
-                                (F::BYTES == 8 && packed_shape<F>(b.n_seg, b.total_base_cols, base_cols, n_cosets, &cpr_unused, &lg_unused)));
+                                packed_shape<F>(b.n_seg, b.total_base_cols, base_cols, n_cosets, &cpr_unused, &lg_unused));
     // Other shapes (STARKPack traces side by side in the lanes, each with a padded row of its own): the lane holding a
     // trace's last column writes that row's zeros.  Only coset-packed multi-trace / f128 matrices are cleared up front.
     const bool pad_traces = row_width != base_cols && !pad_in_kernel &&
