@@ -643,7 +643,12 @@ __device__ __forceinline__ void store_rows_narrow(const typename F::T *x, const 
     constexpr uint32_t S = SegCfg<F>::S;
     const uint32_t D = 1u << a.logD, bc = a.store_cols;
     const uint32_t lo = g * S, hi = min(lo + S, a.total_store_cols);  // the lanes of this segment that hold columns
-    const uint32_t s2 = 2 * (tid & 3), psub = tid >> 2, pstep = n_threads >> 2;
+    // units (16 bytes = two f64 columns) per row: 4 for rows of 8 elements, 8 for rows of 16 (used for traces of 9 or 10
+    // columns, where at least 3/8 of a row is padding: 8 x 10 columns at 2^20 12.5 -> 11.7 ms; with less padding, or rows
+    // of 24, the lane pairs' own stores + one lane's zeros are faster)
+    const uint32_t upr = (uint32_t)a.row_width >> 1;
+    const uint32_t s2 = 2 * (tid % upr), psub = tid / upr, pstep = n_threads / upr;
+    if (psub >= pstep) return;  // (threads beyond the last whole group of `upr`: only when upr does not divide n_threads)
     for (uint32_t t = lo / bc; t <= (hi - 1) / bc; t++) {
         const uint32_t b0 = t * bc + s2, b1 = b0 + 1, last = t * bc + bc - 1;
         const bool d0 = s2 < bc, d1 = s2 + 1 < bc;            // columns of the trace (else padding)
@@ -890,7 +895,7 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
             }
         }
         if (!has_rows) pa = pb = pz = pz2 = nullptr;
-        if (!PACKED && a.pad_traces && a.row_width == 8) {
+        if (!PACKED && a.pad_traces && (a.row_width == 8 || (F::BYTES == 8 && a.row_width == 16 && a.store_cols <= 10))) {
             store_rows_narrow<F>(x, a, g, c, rev_o, out_shift, k_stride, threadIdx.x, blockDim.x);
             pa = pb = nullptr;
         } else if (!PACKED && F::BYTES == 16) {
@@ -1143,7 +1148,7 @@ __global__ void __launch_bounds__(SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512)) k_
             const uint32_t B = g * S + lane_a;  // global base column of lane a
             T *pa = nullptr, *pb = nullptr, *pz = nullptr, *pz2 = nullptr;  // pz*: first padding element after a trace's last column
             bool pair = false;
-            if (F::BYTES == 16 && !(PADT && a.row_width == 8)) {
+            if (F::BYTES == 16 && !(PADT && a.row_width == 8)) {  // (f128 rows of 8: thread quads below)
                 store_rows_by_element<F>(x, a, g, c, rev_o, out_shift, k_stride, tid, blockDim.x, a.tail_pad && g + 1 == a.n_seg, PADT);
             } else if (!MULTI) {
                 if (pos0 < D && lane_a < a.store_cols) {
@@ -1151,7 +1156,7 @@ __global__ void __launch_bounds__(SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512)) k_
                     pair = lane_a + 1 < a.store_cols;
                     if (PADT && lane_a + 2 >= a.store_cols) pz = pa + (a.store_cols - lane_a);
                 }
-            } else if (PADT && a.row_width == 8) {
+            } else if (PADT && (a.row_width == 8 || (F::BYTES == 8 && a.row_width == 16 && a.store_cols <= 10))) {
                 store_rows_narrow<F>(x, a, g, c, rev_o, out_shift, k_stride, tid, blockDim.x);
             } else if (pos0 < D && B < a.total_store_cols) {
                 const uint32_t t0 = B / a.store_cols, c0 = B - t0 * a.store_cols;
