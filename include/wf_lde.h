@@ -77,6 +77,10 @@ void wf_ctx_destroy(wf_ctx *ctx);
 /* A context parks the device buffers of destroyed resident commitments (up to 16) for the next commitment of the same
  * shape -- a prover producing proof after proof allocates once.  This returns them to the driver. */
 int wf_ctx_release_cached(wf_ctx *ctx);
+/* Diagnostic (needs no device): the digit passes the commitment path uses for a transform of 2^log2_n rows over
+ * n_segments segments (a segment = 8 f64 / 4 f128 base columns); returns the number of passes (<= 4), digits_out[i] =
+ * log2 of the tile rows of pass i (the last one is the pass that writes the row-major LDE), or a negative status. */
+int wf_plan_digits(uint32_t field, uint32_t log2_n, uint32_t n_segments, uint32_t digits_out[4]);
 const char *wf_last_error(void);
 /* Number of HIP devices visible (0 if none / no driver). */
 int wf_device_count(void);

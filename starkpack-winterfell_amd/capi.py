@@ -18,7 +18,7 @@ ELEM_WORDS = {F64: 1, F128: 2}
 
 SYMBOLS = [
     "wf_ctx_create", "wf_ctx_destroy", "wf_last_error", "wf_device_count", "wf_ctx_synchronize", "wf_ctx_stream",
-    "wf_ctx_release_cached", "wf_commitment_query", "wf_ctx_profile_enable", "wf_ctx_profile_read", "wf_params_check", "wf_elem_bytes", "wf_row_width", "wf_column_bytes", "wf_lde_bytes", "wf_digests_bytes",
+    "wf_ctx_release_cached", "wf_plan_digits", "wf_commitment_query", "wf_ctx_profile_enable", "wf_ctx_profile_read", "wf_params_check", "wf_elem_bytes", "wf_row_width", "wf_column_bytes", "wf_lde_bytes", "wf_digests_bytes",
     "wf_trace_commit", "wf_constraint_commit", "wf_trace_commit_dev", "wf_constraint_commit_dev",
     "wf_trace_commit_shard_dev", "wf_merkle_build_dev", "wf_trace_commit_resident", "wf_constraint_commit_resident", "wf_commitment_destroy", "wf_commitment_root",
     "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_prove", "wf_commitment_prove_batch",
@@ -461,6 +461,14 @@ class Commitment:
             out.append([bytes(nodes[k + j]) for j in range(int(counts[i]))])
             k += int(counts[i])
         return rows, ([bytes(x) for x in leaves[:n]], out, depth.value)
+
+
+def plan_digits(field: int, log2_n: int, n_segments: int = 1):
+    """wf_plan_digits: the digit passes of a 2^log2_n-row transform (needs no GPU)."""
+    out = (C.c_uint32 * 4)()
+    n = load().wf_plan_digits(field, log2_n, n_segments, out)
+    _check(n if n < 0 else 0)
+    return [int(out[i]) for i in range(n)]
 
 
 def fri_num_layers(folding: int, blowup: int, remainder_max_degree: int, domain_size: int) -> int:

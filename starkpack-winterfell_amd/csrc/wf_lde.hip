@@ -1020,6 +1020,15 @@ void wf_ctx_destroy(wf_ctx *ctx) {
     delete ctx;
 }
 
+int wf_plan_digits(uint32_t field, uint32_t log2_n, uint32_t n_segments, uint32_t digits_out[4]) {
+    if (!digits_out) return fail(WF_ERR_ARG, "digits_out is null");
+    if (field != WF_FIELD_F64 && field != WF_FIELD_F128) return fail(WF_ERR_FIELD, "unknown field id %u", field);
+    if (log2_n < 1 || log2_n > 40) return fail(WF_ERR_TRACE_LENGTH, "transform size out of range");
+    const Plan p = field == WF_FIELD_F64 ? seg_plan<F64>(log2_n, n_segments) : seg_plan<F128>(log2_n, n_segments);
+    for (int i = 0; i < 4; i++) digits_out[i] = i < p.n_pass ? p.dig[i] : 0;
+    return p.n_pass;
+}
+
 int wf_ctx_release_cached(wf_ctx *ctx) {
     if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
     HIP_TRY(hipSetDevice(ctx->device));

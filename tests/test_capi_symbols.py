@@ -56,3 +56,22 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.lower().replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_transform_plans(capi):
+    """The pass plans of the commitment path (wf_plan_digits, no GPU needed) -- each of these splits was chosen by
+    measurement; a change here is a performance change and should be deliberate."""
+    F64, F128 = 1, 2
+    plan = capi.plan_digits
+    assert plan(F64, 10) == [10] and plan(F128, 10) == [10] and plan(F64, 3) == [3]
+    assert plan(F64, 11, 1) == [6, 5] and plan(F64, 11, 8) == [6, 5]      # few 2^11-row tiles would idle most CUs
+    assert plan(F64, 11, 32) == [11]                                        # many segments: one pass
+    assert plan(F64, 20) == [10, 10] and plan(F64, 16) == [8, 8] and plan(F64, 19) == [10, 9]
+    assert plan(F64, 21) == [10, 11]                                        # the maximal digit goes last
+    assert plan(F64, 22) == [8, 7, 7] and plan(F64, 23) == [8, 8, 7]        # never two full tiles
+    assert plan(F128, 18) == [9, 9] and plan(F128, 19) == [9, 10]
+    assert plan(F128, 20) == [7, 7, 6] and plan(F128, 21) == [7, 7, 7]
+    assert plan(F64, 32) == [10, 11, 11] and plan(F128, 40) == [10, 10, 10, 10]
+    for bad in ((3, 10, 1), (1, 0, 1), (1, 41, 1)):
+        with pytest.raises(capi.WfError):
+            plan(*bad)
