@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -70,6 +71,8 @@ struct wf_ctx {
     // Buffers of destroyed resident commitments, kept for the next commitment of the same shape (four hipFree + four
     // hipMalloc of 64..512 MiB cost about as much as the commitment itself); released by wf_ctx_release_cached / destroy.
     std::vector<std::pair<void *, size_t>> pool;
+    void *pin = nullptr;  // pinned host staging for uploads of many small columns (upload_columns)
+    size_t pin_cap = 0;
 };
 
 static hipError_t pool_alloc(wf_ctx *ctx, void **p, size_t bytes) {
@@ -137,6 +140,86 @@ static int ensure(DevBuf &b, size_t bytes) {
     }
     HIP_TRY(hipMalloc(&b.p, bytes));
     b.cap = bytes;
+    return 0;
+}
+
+// Host columns ([n] separate allocations of `colb` bytes, the reference's Vec<Vec<E>>) -> one device buffer.  Large
+// columns go straight through hipMemcpyAsync (pageable copies of MiBs run at PCIe speed); thousands of small ones (512
+// packed traces of 2^10 steps: 5120 columns of 16 KiB) cost ~4.5 us per call that way -- they are gathered into a
+// pinned staging buffer by a few host threads and sent in 32 MiB pieces (24 -> ~7 ms for that case).
+static int upload_columns(wf_ctx *ctx, void *dst, const void *const *cols, size_t n, size_t colb, hipStream_t st) {
+    if (colb >= ((size_t)1 << 20) || n < 16) {
+        for (size_t i = 0; i < n; i++)
+            if (hipMemcpyAsync((char *)dst + i * colb, cols[i], colb, hipMemcpyHostToDevice, st) != hipSuccess)
+                return fail(WF_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(hipGetLastError()));
+        return 0;
+    }
+    const size_t piece = (size_t)32 << 20;
+    if (!ctx->pin) {
+        if (hipHostMalloc(&ctx->pin, 2 * piece, hipHostMallocDefault) != hipSuccess)
+            return fail(WF_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(hipGetLastError()));
+        ctx->pin_cap = 2 * piece;
+    }
+    const size_t per = std::max<size_t>(1, piece / colb);  // columns per piece
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int rc = 0;
+    for (size_t i0 = 0, k = 0; i0 < n && rc == 0; i0 += per, k++) {
+        const size_t cnt = std::min(per, n - i0), half = k & 1;
+        char *stage = (char *)ctx->pin + half * piece;
+        if (done[half]) (void)hipEventSynchronize(done[half]);  // the piece sent from this half two rounds ago has left
+        const unsigned nt = (unsigned)std::min<size_t>(8, std::max<size_t>(1, cnt * colb >> 20));
+        auto work = [&](unsigned t) {
+            for (size_t j = t; j < cnt; j += nt) memcpy(stage + j * colb, cols[i0 + j], colb);
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+        if (hipMemcpyAsync((char *)dst + i0 * colb, stage, cnt * colb, hipMemcpyHostToDevice, st) != hipSuccess)
+            rc = fail(WF_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(hipGetLastError()));
+        if (rc == 0 && !done[half] && hipEventCreateWithFlags(&done[half], hipEventDisableTiming) != hipSuccess)
+            rc = fail(WF_ERR_HIP, "hipEventCreate failed");
+        if (rc == 0) (void)hipEventRecord(done[half], st);
+    }
+    for (auto e : done)
+        if (e) {
+            (void)hipEventSynchronize(e);  // the staging buffer is free again when this returns
+            (void)hipEventDestroy(e);
+        }
+    return rc;
+}
+
+// The way back (polynomial columns to the caller's separate allocations; null entries are skipped).  Synchronous for the
+// staged route (the scatter into the caller's columns happens on the host), asynchronous on `st` for large columns.
+static int download_columns(wf_ctx *ctx, void *const *cols, const void *src, size_t n, size_t colb, hipStream_t st) {
+    if (colb >= ((size_t)1 << 20) || n < 16) {
+        for (size_t i = 0; i < n; i++)
+            if (cols[i] && hipMemcpyAsync(cols[i], (const char *)src + i * colb, colb, hipMemcpyDeviceToHost, st) != hipSuccess)
+                return fail(WF_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(hipGetLastError()));
+        return 0;
+    }
+    const size_t piece = (size_t)32 << 20;
+    if (!ctx->pin) {
+        if (hipHostMalloc(&ctx->pin, 2 * piece, hipHostMallocDefault) != hipSuccess)
+            return fail(WF_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(hipGetLastError()));
+        ctx->pin_cap = 2 * piece;
+    }
+    const size_t per = std::max<size_t>(1, piece / colb);
+    for (size_t i0 = 0; i0 < n; i0 += per) {
+        const size_t cnt = std::min(per, n - i0);
+        if (hipMemcpyAsync(ctx->pin, (const char *)src + i0 * colb, cnt * colb, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            return fail(WF_ERR_HIP, "download failed: %s", hipGetErrorString(hipGetLastError()));
+        const unsigned nt = (unsigned)std::min<size_t>(8, std::max<size_t>(1, cnt * colb >> 20));
+        auto work = [&](unsigned t) {
+            for (size_t j = t; j < cnt; j += nt)
+                if (cols[i0 + j]) memcpy(cols[i0 + j], (const char *)ctx->pin + j * colb, colb);
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+    }
     return 0;
 }
 
@@ -1015,6 +1098,7 @@ void wf_ctx_destroy(wf_ctx *ctx) {
     if (ctx->hash_tmp.p) (void)hipFree(ctx->hash_tmp.p);
     if (ctx->tickets.p) (void)hipFree(ctx->tickets.p);
     for (auto &b : ctx->pool) (void)hipFree(b.first);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (auto e : ctx->prof_ev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1183,18 +1267,14 @@ static int commit_host(wf_ctx *ctx, const wf_params *p, bool constraint, const v
     if ((rc = ensure(ctx->io[3], digb))) return rc;
     if ((rc = ensure(ctx->io[4], digb))) return rc;
     hipStream_t st = ctx->stream;
-    for (size_t i = 0; i < TC; i++)
-        HIP_TRY(hipMemcpyAsync((char *)ctx->io[0].p + i * colb, cols_in[i], colb, hipMemcpyHostToDevice, st));
+    if ((rc = upload_columns(ctx, ctx->io[0].p, cols_in, TC, colb, st))) return rc;
     void *d_polys = constraint ? ctx->io[0].p : ctx->io[1].p;
     if (constraint)
         rc = wf_constraint_commit_dev(ctx, p, ctx->io[0].p, ctx->io[2].p, ctx->io[3].p, ctx->io[4].p, st);
     else
         rc = wf_trace_commit_dev(ctx, p, ctx->io[0].p, ctx->io[1].p, ctx->io[2].p, ctx->io[3].p, ctx->io[4].p, st);
     if (rc) return rc;
-    if (polys_out)
-        for (size_t i = 0; i < TC; i++)
-            if (polys_out[i])
-                HIP_TRY(hipMemcpyAsync(polys_out[i], (char *)d_polys + i * colb, colb, hipMemcpyDeviceToHost, st));
+    if (polys_out && (rc = download_columns(ctx, polys_out, d_polys, TC, colb, st))) return rc;
     if (lde_out)
         for (size_t t = 0; t < p->n_traces; t++)
             if (lde_out[t])
@@ -1281,12 +1361,9 @@ static int commit_resident(wf_ctx *ctx, const wf_params *p, bool constraint, con
     }
     hipStream_t st = ctx->stream;
     void *stage = constraint ? c->polys : ctx->io[0].p;  // composition polys are the input themselves
-    for (size_t i = 0; i < TC; i++) {
-        e = hipMemcpyAsync((char *)stage + i * colb, cols_in[i], colb, hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) {
-            free_commitment(c);
-            return fail(WF_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
-        }
+    if ((rc = upload_columns(ctx, stage, cols_in, TC, colb, st))) {
+        free_commitment(c);
+        return rc;
     }
     if (constraint)
         rc = p->field == WF_FIELD_F64 ? constraint_commit_dev<F64>(ctx, p, c->polys, c->lde, c->leaves, c->nodes, st, dense)
@@ -1297,9 +1374,10 @@ static int commit_resident(wf_ctx *ctx, const wf_params *p, bool constraint, con
         free_commitment(c);
         return rc;
     }
-    if (polys_out && !constraint)
-        for (size_t i = 0; i < TC; i++)
-            if (polys_out[i]) (void)hipMemcpyAsync(polys_out[i], (char *)c->polys + i * colb, colb, hipMemcpyDeviceToHost, st);
+    if (polys_out && !constraint && (rc = download_columns(ctx, polys_out, c->polys, TC, colb, st))) {
+        free_commitment(c);
+        return rc;
+    }
     e = hipMemcpyAsync(c->root, (char *)c->nodes + 32, 32, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
