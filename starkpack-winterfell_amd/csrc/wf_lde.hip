@@ -1824,10 +1824,9 @@ int wf_evaluate_columns_at(wf_ctx *ctx, uint32_t field, uint32_t ext_degree, con
     if ((rc = ensure(ctx->io[0], n_cols * colb))) return rc;
     if ((rc = ensure(ctx->io[4], out_bytes))) return rc;
     hipStream_t st = ctx->stream;
-    for (size_t i = 0; i < n_cols; i++) {
+    for (size_t i = 0; i < n_cols; i++)
         if (!poly_cols[i]) return fail(WF_ERR_ARG, "column %zu is null", i);
-        HIP_TRY(hipMemcpyAsync((char *)ctx->io[0].p + i * colb, poly_cols[i], colb, hipMemcpyHostToDevice, st));
-    }
+    if ((rc = upload_columns(ctx, ctx->io[0].p, poly_cols, n_cols, colb, st))) return rc;
     rc = field == WF_FIELD_F64
              ? eval_columns_at_dev<F64>(ctx, st, ctx->io[0].p, n_cols, n, ext_degree, z, z_ext_degree, ctx->io[4].p)
              : eval_columns_at_dev<F128>(ctx, st, ctx->io[0].p, n_cols, n, ext_degree, z, z_ext_degree, ctx->io[4].p);
