@@ -115,3 +115,19 @@ def test_parked_buffers_are_reused_and_released(ctx, orc, capi):
     free_after = torch.cuda.mem_get_info(0)[0]
     assert free_after >= free_before + (1 << 15) * 64       # at least the parked LDE (2 MiB) came back
     ctx.release_cached()                                      # idempotent
+
+
+def test_many_small_columns_are_staged(ctx, orc, capi):
+    """640 host columns of 64 KiB (40 MiB: more than one 32 MiB staging piece) in, their polynomials back out: the staged
+    upload / download route of the host-column entry points (upload_columns / download_columns)."""
+    rng = np.random.default_rng(9)
+    logR, n_cols, n_traces = 13, 8, 80
+    traces = [rand_cols(rng, F64, n_cols, 1 << logR) for _ in range(n_traces)]
+    want = orc.build_trace_commitment(F64, traces, 1, logR, 1, 7, threads=16)
+    com, polys = ctx.trace_commit_resident(capi.make_params(F64, 1, logR, 1, n_cols, n_traces),
+                                           [c for t in traces for c in t], want_polys=True)
+    assert com.root() == want["root"]
+    for t in (0, 41, 79):
+        for c in (0, 7):
+            assert np.array_equal(polys[t * n_cols + c], want["polys"][t][c])
+    com.close()
