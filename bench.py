@@ -1,23 +1,38 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json metric on MI355X: trace-LDE + Merkle-commit of a 2^20 x 8 f64 trace at blowup 8.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode proofs|packed]
 
 A "step" is one pass of the hot path (Prover::build_trace_commitment, /root/reference/prover/src/lib.rs:615-670)
 over one synthetic trace that is already resident in HBM: interpolate 8 columns -> evaluate over the 8 cosets into
-the row-major LDE matrix -> hash 2^23 rows -> build the Merkle tree.  At N > 1 every rank commits its own
-independent proof (weak scaling, BASELINE.json configs[3]) and the step ends with the path's one collective, an
-all-gather of the 32-byte roots over RCCL.
+the row-major LDE matrix -> hash 2^23 rows -> build the Merkle tree.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     : dominant logical kernel, its algorithmic bytes per launch
-                 / its HIP-event duration measured inside the timed region, against the 8 TB/s HBM peak
-  cpu_baseline : the CPU oracle (oracle/, "port" of the reference's concurrent path) timed on this box's host
-                 cores on one full commitment of the same workload (rank 0, N == 1 only)
+N > 1: one process per GPU.  As a plain command (`python bench.py --gpus 8`) this process only starts the ranks --
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as child processes, before anything here touches
+the GPU -- and passes their output and exit code through; started by torch.distributed.run itself (RANK in the
+environment) it is a rank.
+  --mode proofs (default; BASELINE.json configs[3]): every rank commits its own independent proof (weak scaling)
+      and the step sequence ends with the path's one collective, an all-gather of the 32-byte roots over RCCL
+      (wf_comm_all_gather_roots: the collective lives inside libwf_lde.so, behind the C ABI).
+  --mode packed: ONE STARKPack commitment of 8 packed 2^20 x 8 traces, sharded by coset over the ranks
+      (wf_trace_commit_sharded_dev; strong scaling).
+WF_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks: the ranks share
+the device and the bytes of the collectives travel over a torch.distributed gloo group (wf_transport).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
+  roofline       : dominant logical kernel, its algorithmic bytes per launch
+                   / its HIP-event duration measured inside the timed region, against the 8 TB/s HBM peak
+  cpu_baseline   : the CPU oracle (oracle/, "port" of the reference's concurrent path) timed on this box's host
+                   cores on full commitments of the same workload (rank 0, N == 1 only)
+  with_transfers : the same commitment through the host-buffer and the resident entry points (PCIe included;
+                   N == 1 only, outside the timed region; never `value`)
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,28 +40,31 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 LOG_R, LOG_B, N_COLS = 20, 3, 8
+PACKED_TRACES = 8
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 # integer-VALU rates of the path's two instruction sequences in isolation on one MI355X (scripts/microbench.hip; the
-# better of the boxes measured this round, profiles/r01_microbench.txt): Goldilocks butterflies, BLAKE3 compressions
+# better of the boxes measured, profiles/r01_microbench.txt): Goldilocks butterflies, BLAKE3 compressions.  Constants,
+# not measured in this run: `alu.frac` is the step against THAT yardstick.
 ALU_BFLY_PER_S = 1.59e12
 ALU_COMPRESS_PER_S = 57.0e9
 
 
-def work_model(log_r=LOG_R, log_b=LOG_B, c=N_COLS, e=8):
-    """algorithmic bytes and field operations of one commitment."""
+def work_model(log_r=LOG_R, log_b=LOG_B, c=N_COLS, e=8, n_traces=1):
+    """algorithmic bytes and field operations of one commitment (n_traces packed traces)."""
     R, N = 1 << log_r, 1 << (log_r + log_b)
     beta = 1 << log_b
+    C = c * n_traces
     bytes_k = {
-        "interpolate": R * c * e + R * c * e,          # K1: read trace, write polys
-        "evaluate": R * c * e + N * c * e,             # K2: read polys, write LDE
-        "hash_rows": N * c * e + N * 32,               # K3: read LDE rows, write leaves
+        "interpolate": R * C * e + R * C * e,          # K1: read trace, write polys
+        "evaluate": R * C * e + N * C * e,             # K2: read polys, write LDE
+        "hash_rows": N * C * e + N * 32,               # K3: read LDE rows, write leaves
         "merkle": N * 32 + N * 32,                     # K4: read leaves, write nodes
     }
-    b_alg = R * c * e * 2 + N * c * e + N * 32 * 2     # §8(d): each datum of the path exactly once
-    butterflies = c * (R // 2) * log_r * (1 + beta)
-    muls = butterflies + c * R + beta * c * R
-    field_ops = 3 * butterflies + c * R + beta * c * R
-    compressions = N * ((c * e + 63) // 64) + (N - 1)
+    b_alg = R * C * e * 2 + N * C * e + N * 32 * 2     # §8(d): each datum of the path exactly once
+    butterflies = C * (R // 2) * log_r * (1 + beta)
+    muls = butterflies + C * R + beta * C * R
+    field_ops = 3 * butterflies + C * R + beta * C * R
+    compressions = N * ((C * e + 63) // 64) + (N - 1)
     return dict(bytes_per_kernel=bytes_k, b_alg=b_alg, field_ops=field_ops, modmuls=muls, compressions=compressions,
                 butterflies=butterflies)
 
@@ -60,17 +78,51 @@ def rand_f64_dev(torch, n, seed, device):
     return torch.where(bad, v & 0x7FFFFFFFFFFFFFFF, v)
 
 
-def cpu_baseline(model, trace_host=None, gpu_root=None):
-    """One full commitment of the bench workload (the very trace rank 0 committed on the GPU) with the threaded CPU
-    oracle -- test infrastructure, used here only as the reported CPU baseline and as a last parity gate."""
-    import numpy as np
-    from oracle import oracle as O
-    O.build()
+def csrc_sha():
+    """Digest of the kernel sources: profiles/traffic.json is only quoted for the kernels it was measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "starkpack-winterfell_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def probe(cmd):
+    """First line a toolchain probe prints, or None (cargo / rustc on the GPU box: BASELINE.md §3)."""
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=20)
+        return (out.stdout or out.stderr).strip().splitlines()[0] if out.returncode == 0 else None
+    except (OSError, subprocess.SubprocessError, IndexError):
+        return None
+
+
+def cpu_baseline(model, trace_host=None, gpu_root=None, runs=5, warmups=2):
+    """Full commitments of the bench workload (the very trace rank 0 committed on the GPU) with the threaded CPU
+    oracle -- test infrastructure, used here only as the reported CPU baseline and as a last parity gate.  The C
+    entry point is timed on preallocated, already faulted-in outputs (no Python allocation inside the clock)."""
     threads = min(os.cpu_count() or 1, 64)
     try:
         threads = min(threads, len(os.sched_getaffinity(0)))
     except AttributeError:
         pass
+    # libgomp reads these when liboracle.so (first user of the system libgomp in this process) is loaded
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+    import numpy as np
+    from oracle import oracle as O
+    O.build()
     rng = np.random.default_rng(0x57415446)
     p = np.uint64(2**64 - 2**32 + 1)
 
@@ -82,16 +134,80 @@ def cpu_baseline(model, trace_host=None, gpu_root=None):
             out.append(v)
         return out
 
-    O.build_trace_commitment(O.F64, [cols(14)], 1, 14, LOG_B, 7, threads=threads)  # warm-up (threads, page cache)
     data = cols(LOG_R) if trace_host is None else [np.ascontiguousarray(c) for c in trace_host]
-    t0 = time.perf_counter()
-    res = O.build_trace_commitment(O.F64, [data], 1, LOG_R, LOG_B, 7, threads=threads)
-    dt = time.perf_counter() - t0
-    return dict(value=model["field_ops"] / dt, unit="field-ops/s", cores=threads, kind="port",
-                sample=f"1 full commitment (2^{LOG_R} x {N_COLS} f64, blowup {1 << LOG_B}) after a 2^14-row warm-up; "
-                       f"{dt * 1e3:.0f} ms wall incl. output allocation",
-                ms=dt * 1e3, root=res["root"].hex(),
-                root_matches_gpu=(None if gpu_root is None else res["root"].hex() == gpu_root))
+    res = None
+    for _ in range(warmups):  # threads, page cache, output pages
+        res = O.build_trace_commitment(O.F64, [data], 1, LOG_R, LOG_B, 7, threads=threads, out=res)
+    times = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        res = O.build_trace_commitment(O.F64, [data], 1, LOG_R, LOG_B, 7, threads=threads, out=res)
+        times.append((time.perf_counter() - t0) * 1e3)
+    times.sort()
+    median = times[len(times) // 2]
+    return dict(value=model["field_ops"] / (median * 1e-3), unit="field-ops/s", cores=threads, kind="port",
+                sample=f"{runs} full commitments (2^{LOG_R} x {N_COLS} f64, blowup {1 << LOG_B}) after {warmups} warm-ups, "
+                       f"outputs preallocated; median {median:.0f} ms, min {times[0]:.0f} ms",
+                median_ms=median, min_ms=times[0], max_ms=times[-1], runs=runs, warmups=warmups,
+                cpu_model=cpu_model(), threads_pinned=os.environ.get("OMP_PROC_BIND") == "close",
+                omp_places=os.environ.get("OMP_PLACES"), root=res["root"].hex(),
+                root_matches_gpu=(None if gpu_root is None else res["root"].hex() == gpu_root),
+                reference_toolchain={"cargo": probe(["cargo", "--version"]), "rustc": probe(["rustc", "--version"])})
+
+
+def with_transfers(ctx, capi, params, trace_host, gpu_root):
+    """The commitment through the entry points that take HOST columns (what Prover::build_trace_commitment hands
+    over): copy-out form (64 MiB in, LDE + leaves + nodes + polys out over PCIe) and resident form (64 MiB in, the
+    32-byte root out).  Median of 3 after one warm-up; outside the timed region."""
+    import ctypes as C
+    import numpy as np
+    L = capi.load()
+    cols = [np.ascontiguousarray(c) for c in trace_host]
+    out = {}
+    N = 1 << (LOG_R + LOG_B)
+    polys = [np.zeros_like(c) for c in cols]
+    lde = np.zeros((N, 8), dtype=np.uint64)
+    leaves = np.zeros((N, 32), dtype=np.uint8)
+    nodes = np.zeros((N, 32), dtype=np.uint8)
+    root = np.zeros(32, dtype=np.uint8)
+    ts = []
+    for i in range(4):
+        t0 = time.perf_counter()
+        capi._check(L.wf_trace_commit(ctx._h, C.byref(params), capi._ptr_array(cols), capi._ptr_array(polys),
+                                      capi._ptr_array([lde]), capi._p(leaves), capi._p(nodes), capi._p(root)))
+        ts.append((time.perf_counter() - t0) * 1e3)
+    out["host_buffers_ms"] = sorted(ts[1:])[1]
+    out["host_buffers_root_matches"] = bytes(root).hex() == gpu_root
+    ts = []
+    for i in range(4):
+        t0 = time.perf_counter()
+        com, _ = ctx.trace_commit_resident(params, cols)
+        ts.append((time.perf_counter() - t0) * 1e3)
+        r = com.root().hex()
+        com.close()
+    out["resident_from_host_ms"] = sorted(ts[1:])[1]
+    out["resident_root_matches"] = r == gpu_root
+    out["note"] = "wall clock around the C call, host columns pageable numpy arrays, PCIe included; median of 3"
+    return out
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` as a plain command: start one rank per GPU and get out of the way.  This process has
+    not imported torch or touched the GPU; the ranks are children, not an exec of this process."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -99,44 +215,54 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", choices=("proofs", "packed"), default="proofs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-transfers", action="store_true")
     ap.add_argument("--per-launch", action="store_true", help="also report HIP-event times of every kernel launch")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+
     import torch
-    import torch.distributed as dist
     import starkpack_winterfell_amd.capi as capi
     from starkpack_winterfell_amd import shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     # one rank per GPU; the modulo only matters for rehearsals of the multi-rank control flow on a box with fewer GPUs
     # than ranks (WF_BENCH_BACKEND=gloo) -- RCCL itself refuses two ranks on one device
     dev_index = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    backend = os.environ.get("WF_BENCH_BACKEND", "nccl")
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
+    backend = os.environ.get("WF_BENCH_BACKEND", "rccl")
 
-    model = work_model()
     ctx = capi.Context(dev_index)
-    params = capi.make_params(capi.F64, 1, LOG_R, LOG_B, N_COLS, 1)
+    comm = None
+    if world > 1:
+        if backend == "gloo":
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+            comm = shard.Comm.with_process_group(ctx)
+        else:
+            comm = shard.Comm.with_store(ctx, shard.store_from_env(rank, world), rank, world)
+
+    packed = args.mode == "packed"
+    n_traces = PACKED_TRACES if packed else 1
+    model = work_model(n_traces=n_traces)
+    params = capi.make_params(capi.F64, 1, LOG_R, LOG_B, N_COLS, n_traces)
     R, N = 1 << LOG_R, 1 << (LOG_R + LOG_B)
-    proof_id = shard.proofs_of_rank(world, rank, world)[0]
-    trace = rand_f64_dev(torch, N_COLS * R, shard.seed_of_proof(0x57415446, proof_id), device)
+    # packed: every rank holds the same traces (one proof); proofs: a trace of its own per rank
+    proof_id = 0 if packed else shard.proofs_of_rank(world, rank, world)[0]
+    trace = rand_f64_dev(torch, n_traces * N_COLS * R, shard.seed_of_proof(0x57415446, proof_id), device)
     polys = torch.empty_like(trace)
-    lde = torch.empty(N * 8, dtype=torch.int64, device=device)
-    leaves = torch.empty((N, 32), dtype=torch.uint8, device=device)
-    nodes = torch.empty((N, 32), dtype=torch.uint8, device=device)
+    share = world if packed else 1  # a rank's part of the LDE rows and of the tree
+    lde = torch.empty(n_traces * (N // share) * 8, dtype=torch.int64, device=device)
+    leaves = torch.empty((N // share, 32), dtype=torch.uint8, device=device)
+    nodes = torch.empty((N // share, 32), dtype=torch.uint8, device=device)
+    top = torch.zeros((2 * world, 32), dtype=torch.uint8, device=device)
 
     stream = torch.cuda.Stream(device=device)
     torch.cuda.synchronize()
@@ -145,45 +271,54 @@ def main():
 
     # the roots of the K timed commitments of this rank; ranks run free of each other (independent proofs, no data-path
     # collective) and exchange all their roots once, inside the timed region: the path's single exchange
-    roots = torch.zeros((max(args.steps, args.warmup, 1), 32), dtype=torch.uint8, device=device)
+    n_keep = max(args.steps, args.warmup, 1)
+    roots = torch.zeros((n_keep, 32), dtype=torch.uint8, device=device)
+    all_roots = torch.zeros((world * n_keep, 32), dtype=torch.uint8, device=device)
 
     def step(k):
-        ctx.trace_commit_dev(params, trace.data_ptr(), polys.data_ptr(), lde.data_ptr(), leaves.data_ptr(),
-                             nodes.data_ptr(), stream.cuda_stream)
-        roots[k].copy_(nodes[1], non_blocking=True)
+        if packed and comm is not None:
+            comm.trace_commit_sharded_dev(params, trace.data_ptr(), polys.data_ptr(), lde.data_ptr(), leaves.data_ptr(),
+                                          nodes.data_ptr(), top.data_ptr(), stream.cuda_stream)
+            roots[k].copy_(top[1], non_blocking=True)
+        else:
+            ctx.trace_commit_dev(params, trace.data_ptr(), polys.data_ptr(), lde.data_ptr(), leaves.data_ptr(),
+                                 nodes.data_ptr(), stream.cuda_stream)
+            roots[k].copy_(nodes[1], non_blocking=True)
+
+    def gather(k):
+        if comm is not None and not packed:
+            comm.all_gather_roots(roots.data_ptr(), k, all_roots.data_ptr(), stream.cuda_stream)
 
     with torch.cuda.stream(stream):
         for k in range(args.warmup):
             step(k)
-        if world > 1:
-            shard.all_gather_roots(roots)  # warm the communicator up as well
+        gather(max(args.warmup, 1))  # warm the communicator up as well
         torch.cuda.synchronize()
         ctx.profile_read()  # drop the warm-up events
-        if world > 1:
-            dist.barrier()
+        if comm is not None:
+            comm.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(args.steps):
             step(k)
-        all_roots = shard.all_gather_roots(roots[:args.steps]) if world > 1 else roots[:args.steps]
+        gather(args.steps)
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        if comm is not None:
+            comm.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         # HIP events recorded on the launch stream in front of every kernel of the K timed steps
         for name, ms in ctx.profile_read():
             per_launch.setdefault(name, []).append(ms)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    root_hex = bytes(nodes[1].cpu().numpy()).hex()
+    if comm is not None:
+        elapsed = comm.max_f64(elapsed)  # MAX over ranks
+    root_hex = bytes(roots[args.steps - 1].cpu().numpy()).hex()
+    n_roots = world * args.steps if (comm is not None and not packed) else args.steps
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        commits = world * args.steps
+        commits = (1 if packed else world) * args.steps
         value = commits * model["field_ops"] / elapsed
         avg = {k: sum(v) / len(v) for k, v in per_launch.items()}
         logical = {
@@ -202,23 +337,34 @@ def main():
             for name, ms in ctx.profile_read():
                 fine.setdefault(name, []).append(ms)
             avg = {k: sum(v) / len(v) for k, v in fine.items()}
-        # one segment, one trace: the leaves are hashed by the last evaluation pass itself (no k_hash_rows launch, the
-        # LDE is not read back); the evaluate kernel then also owns the write of the leaves
-        bytes_k = dict(model["bytes_per_kernel"])
+        # the leaves are hashed by the last evaluation pass itself (no k_hash_rows launch, the LDE is not read back);
+        # the evaluate kernel then also owns the write of the leaves
+        per_rank = world if packed else 1
+        bytes_k = {k: v // per_rank for k, v in model["bytes_per_kernel"].items()}
         fused_hash = "hash_rows" not in avg
         if fused_hash:
-            bytes_k["evaluate"] += N * 32
+            bytes_k["evaluate"] += N * 32 // per_rank
             bytes_k["hash_rows"] = 0
         dom = max(logical, key=logical.get)
         dom_ms = logical[dom]
         achieved = bytes_k[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
+        # HBM-side bytes of the dominant kernel from the PMC passes of scripts/profile_round.sh -- quoted only while the
+        # kernel sources are the ones they were measured on
+        traffic, traffic_sha = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not packed and world == 1:
             try:
-                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_step")
+                tj = json.load(open(tpath))
+                traffic_sha = tj.get("_csrc_sha")
+                if traffic_sha == csrc_sha():
+                    traffic = tj.get(dom, {}).get("hbm_bytes_per_step")
             except Exception:
                 traffic = None
+        workload = (f"{PACKED_TRACES} packed traces of 2^20 rows x 8 cols f64 under ONE tree (STARKPack), blowup 8, sharded "
+                    f"by coset over {world} GPU(s)" if packed else
+                    "BASELINE.json configs[1]: 2^20 rows x 8 cols f64, blowup 8, BLAKE3-256 Merkle; one independent "
+                    "commitment per GPU per step"
+                    + (", the roots of all steps all-gathered over RCCL once per run (configs[3])" if world > 1 else ""))
         out = {
             "metric": "trace-LDE + Merkle-commit field-ops/s (wall-clock ms in ms_per_step), 2^20x8 f64 trace blowup=8",
             "value": value,
@@ -228,41 +374,54 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if packed else "weak",
             "vs_baseline": None,
             "dtype": "u64 (Goldilocks, Montgomery form) + u32 (BLAKE3)",
             "data": "synthetic (seeded uniform field elements, resident in HBM)",
-            "config": {"workload": "BASELINE.json configs[1]: 2^20 rows x 8 cols f64, blowup 8, BLAKE3-256 Merkle; "
-                                   "one independent commitment per GPU per step"
-                                   + (", the roots of all steps all-gathered over RCCL once per run" if world > 1 else ""),
-                       "log2_trace_len": LOG_R, "n_cols": N_COLS, "blowup": 1 << LOG_B, "n_traces": 1},
+            "config": {"workload": workload, "mode": args.mode, "log2_trace_len": LOG_R, "n_cols": N_COLS,
+                       "blowup": 1 << LOG_B, "n_traces": n_traces},
             "commits_per_s": commits / elapsed,
+            "collective": (None if comm is None else
+                           {"transport": "RCCL inside libwf_lde.so (wf_comm, C ABI)" if comm.transport == "rccl"
+                            else "wf_transport over torch.distributed gloo (rehearsal)",
+                            "rccl_version": capi.load().wf_comm_rccl_version() if comm.transport == "rccl" else None,
+                            "calls": "all-to-all of leaf digests + all-gather of sub-roots per step" if packed
+                            else "one all-gather of roots per run"}),
             # the path is integer-VALU bound: time of its butterflies and BLAKE3 compressions at the rates the same
             # instruction sequences reach in isolation (scripts/microbench.hip, profiles/r01_microbench.txt) vs the step
             "alu": {"butterflies": model["butterflies"], "blake3_compressions": model["compressions"],
                     "microbench_butterflies_per_s": ALU_BFLY_PER_S, "microbench_compressions_per_s": ALU_COMPRESS_PER_S,
-                    "ideal_ms": (model["butterflies"] / ALU_BFLY_PER_S + model["compressions"] / ALU_COMPRESS_PER_S) * 1e3,
-                    "frac": (model["butterflies"] / ALU_BFLY_PER_S + model["compressions"] / ALU_COMPRESS_PER_S) * 1e3 / ms_per_step},
-            "path": {"b_alg_bytes": model["b_alg"], "hbm_frac": model["b_alg"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "rates": "constants from profiles/r01_microbench.txt, not measured in this run",
+                    "ideal_ms": (model["butterflies"] / ALU_BFLY_PER_S + model["compressions"] / ALU_COMPRESS_PER_S) * 1e3 / per_rank,
+                    "frac": (model["butterflies"] / ALU_BFLY_PER_S + model["compressions"] / ALU_COMPRESS_PER_S) * 1e3 / per_rank / ms_per_step},
+            "path": {"b_alg_bytes": model["b_alg"], "hbm_frac": model["b_alg"] / per_rank / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "field_ops": model["field_ops"], "blake3_compressions": model["compressions"]},
             "roofline": {"bound": "hbm", "kernel": dom + (" (leaf hashing fused into its last pass)" if fused_hash and dom == "evaluate" else ""),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_measured_on_csrc": traffic_sha, "csrc": csrc_sha(),
                          "algorithmic_bytes": bytes_k[dom], "avg_ms": dom_ms},
             "launch_ms": {k: round(v, 4) for k, v in avg.items()},
             "root": root_hex,
-            "roots_gathered": int(all_roots.shape[0]),
+            "roots_gathered": n_roots,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not packed:
             th = trace.cpu().numpy().view("uint64").reshape(N_COLS, R)
-            out["cpu_baseline"] = cpu_baseline(model, th, root_hex)
-            if out["cpu_baseline"]["root_matches_gpu"] is False:
-                raise SystemExit("PARITY FAILURE: CPU oracle root != GPU root on the bench workload")
-            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            if not args.no_transfers:
+                out["with_transfers"] = with_transfers(ctx, capi, params, th, root_hex)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(model, th, root_hex)
+                if out["cpu_baseline"]["root_matches_gpu"] is False:
+                    raise SystemExit("PARITY FAILURE: CPU oracle root != GPU root on the bench workload")
+                out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
+        if backend == "gloo":
+            import torch.distributed as dist
+            dist.destroy_process_group()
+    ctx.close()
 
 
 if __name__ == "__main__":

@@ -49,8 +49,10 @@ enum wf_status {
     WF_ERR_OFFSET = -17,       /* domain offset == 0 or >= p (fft/mod.rs:201) */
     WF_ERR_LEAVES = -18,       /* fewer than two leaves / not a power of two (merkle/mod.rs:118-123) */
     WF_ERR_ARG = -19,          /* null pointer or other malformed argument */
+    WF_ERR_BUSY = -20,         /* the context is inside a call of another thread (one call at a time per wf_ctx) */
     WF_ERR_HIP = -30,          /* HIP runtime failure (no device, out of memory, launch failure) */
-    WF_ERR_DIGEST = -31        /* digest_bytes != 32 */
+    WF_ERR_DIGEST = -31,       /* digest_bytes != 32 */
+    WF_ERR_COMM = -32          /* RCCL (or caller-supplied transport) failure, librccl.so.1 not loadable */
 };
 
 /* Parameters of one commitment.  Mirrors what StarkDomain + ProofOptions carry into the two Prover methods
@@ -70,8 +72,14 @@ typedef struct wf_params {
 /* ---- context ------------------------------------------------------------------------------------------------- */
 
 /* Creates a context bound to HIP device `device` (twiddle tables, scratch and a stream live in it).
- * One context per GPU; a context is not thread-safe, distinct contexts are independent.  Commitments and FRI provers
- * created on a context use it until they are destroyed: destroy them first, the context last. */
+ * One context per GPU; distinct contexts are independent and may be used from different threads at the same time
+ * (the reference calls the path from one thread, prover/src/lib.rs:267-268).  A context serves ONE call at a time: a
+ * thread that enters while another thread's call is in progress gets WF_ERR_BUSY, nothing is corrupted.  The
+ * asynchronous (*_dev) calls share the context's scratch, so calls issued on DIFFERENT streams are ordered on the
+ * device by the library: a call first makes its stream wait for everything queued on the stream of the previous call
+ * (keep that stream alive until then); calls on one stream run back to back without any host synchronisation.
+ * Commitments and FRI provers created on a context use it until they are destroyed: destroy them first, the context
+ * last. */
 int wf_ctx_create(int device, wf_ctx **out);
 void wf_ctx_destroy(wf_ctx *ctx);
 /* A context parks the device buffers of destroyed resident commitments (up to 16) for the next commitment of the same
@@ -153,12 +161,90 @@ int wf_constraint_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_poly
  *   d_lde_shard    : [n_traces] matrices of (R * coset_count) rows x row_width, local row k*coset_count + (c - begin)
  *   d_leaves_shard : R * coset_count digests in the same local order (each leaf needs only its own row of every trace)
  * d_polys may be NULL.  The ranks then all-gather the leaf shards (the path's one exchange, RCCL), interleave them
- * to natural order (shard.interleave_leaf_shards) and build the tree with wf_merkle_build_dev. */
+ * to natural order (wf_comm_all_gather_leaf_shards) and build the tree with wf_merkle_build_dev -- or use
+ * wf_trace_commit_sharded_dev, which also shards the interpolation and the tree. */
 int wf_trace_commit_shard_dev(wf_ctx *ctx, const wf_params *p, uint32_t coset_begin, uint32_t coset_count,
                               const void *d_trace, void *d_polys, void *d_lde_shard, void *d_leaves_shard,
                               void *stream);
 /* MerkleTree::new on device buffers (leaves -> nodes), asynchronous on `stream`. */
 int wf_merkle_build_dev(wf_ctx *ctx, const void *d_leaves, size_t n_leaves, void *d_nodes, void *stream);
+
+/* ---- multi-GPU: one process per GPU, the path's exchanges behind this ABI ------------------------------ */
+
+/* The reference has no distributed code (README.md:43 lists a distributed prover as planned).  Two shardings:
+ *  (1) independent proofs, one per GPU (BASELINE configs[3]): no data-path collective; the 32-byte roots are assembled
+ *      with ONE all-gather -- wf_comm_all_gather_roots;
+ *  (2) one STARKPack commitment (commit_to_comb_rows, row_matrix.rs:204-238) sharded by coset -- wf_trace_commit_sharded_dev.
+ * A wf_comm binds a context (= a GPU) to its rank.  Transport: RCCL over xGMI (librccl.so.1 is resolved with dlopen at
+ * the first use, so hosts without it can still load this library), or a table of collectives supplied by the caller. */
+typedef struct wf_comm wf_comm;
+#define WF_COMM_ID_BYTES 128
+/* ncclGetUniqueId: rank 0 calls this and hands the bytes to every rank (over whatever the host uses: a TCP store, MPI). */
+int wf_comm_unique_id(uint8_t id_out[WF_COMM_ID_BYTES]);
+/* ncclCommInitRank on the context's device; collective over all `world` ranks. */
+int wf_comm_create(wf_ctx *ctx, const uint8_t id[WF_COMM_ID_BYTES], int rank, int world, wf_comm **out);
+/* A host that brings its own fabric code supplies the two collectives the path needs.  Pointers are DEVICE pointers of
+ * the calling rank; the transport must order its work after everything queued on `stream` and leave the result visible
+ * to work queued on `stream` afterwards (it may simply synchronise).  Return 0 on success.
+ *   all_gather: every rank contributes `bytes` at d_send; d_recv receives world * bytes, rank-major
+ *   all_to_all: block s of rank r (d_send + s * bytes) lands at d_recv + r * bytes on rank s */
+typedef struct wf_transport {
+    void *user;
+    int (*all_gather)(void *user, const void *d_send, void *d_recv, size_t bytes, void *stream);
+    int (*all_to_all)(void *user, const void *d_send, void *d_recv, size_t bytes, void *stream);
+} wf_transport;
+int wf_comm_create_with_transport(wf_ctx *ctx, const wf_transport *t, int rank, int world, wf_comm **out);
+void wf_comm_destroy(wf_comm *comm);
+int wf_comm_rank(const wf_comm *comm);
+int wf_comm_world(const wf_comm *comm);
+/* Version code of the RCCL library that was loaded (ncclGetVersion), 0 if none could be. */
+int wf_comm_rccl_version(void);
+/* ncclAllGather of raw bytes, asynchronous on `stream` (NULL = the context's stream). */
+int wf_comm_all_gather(wf_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream);
+/* The one collective of sharding (1): every rank's n_roots roots (32 bytes each, device memory) -> d_all, rank-major. */
+int wf_comm_all_gather_roots(wf_comm *comm, const void *d_roots, size_t n_roots, void *d_all, void *stream);
+/* Host-blocking helpers for drivers and benchmarks: a barrier over all ranks (through the device: everything queued on
+ * the context's stream has finished when it returns) and the maximum of one double over all ranks (in place). */
+int wf_comm_barrier(wf_comm *comm);
+int wf_comm_max_f64(wf_comm *comm, double *value);
+
+/* Partition rules (no device needed; what wf_trace_commit_sharded_dev and the tests use):
+ *   proofs : contiguous blocks of proof ids, the first ranks take the remainder
+ *   cosets : world (a power of two) must divide blowup; rank r owns cosets [r * blowup / world, (r + 1) * blowup / world)
+ *   route  : where LDE row `position` of a sharded commitment lives -- its row on rank row_rank at local row row_local
+ *            of d_lde_shard, its leaf on rank tree_rank at index leaf_local of that rank's d_leaves / local tree. */
+int wf_shard_proofs(uint32_t n_proofs, uint32_t rank, uint32_t world, uint32_t *first, uint32_t *count);
+int wf_shard_cosets(uint32_t blowup, uint32_t rank, uint32_t world, uint32_t *first, uint32_t *count);
+int wf_shard_route(uint32_t log2_lde_rows, uint32_t blowup, uint32_t world, uint64_t position, uint32_t *row_rank,
+                   uint64_t *row_local, uint32_t *tree_rank, uint64_t *leaf_local);
+
+/* Replicated-tree form of sharding (2), on top of wf_trace_commit_shard_dev: all-gather of every rank's leaf shard
+ * (trace_len * cosets_per_rank digests in (k, local coset) order) into d_leaves in natural row order (n = trace_len *
+ * cosets_per_rank * world digests); every rank then builds the whole tree with wf_merkle_build_dev. */
+int wf_comm_all_gather_leaf_shards(wf_comm *comm, const void *d_leaves_shard, size_t trace_len, uint32_t cosets_per_rank,
+                                   void *d_leaves, void *stream);
+
+/* Sharding (2) with nothing repeated per rank: ONE Prover::build_trace_commitment (prover/src/lib.rs:615-670) of
+ * n_traces packed traces spread over the W = wf_comm_world ranks; every rank passes the same parameters and trace.
+ *   interpolate : rank r interpolates the segments (groups of 8 f64 / 4 f128 base columns) [r * n_seg / W, ..) and the
+ *                 coefficients are all-gathered (when W divides the number of segments; otherwise every rank
+ *                 interpolates all columns and nothing is exchanged);
+ *   evaluate    : rank r evaluates cosets [r * blowup / W, ..): rows j = k * blowup + c of every trace, and hashes the
+ *                 combined rows -- a leaf needs no other rank's data;
+ *   exchange    : an all-to-all of digests (R * blowup / W^2 per pair) gives rank r the leaves of the contiguous range
+ *                 [r * N / W, (r + 1) * N / W), N = R * blowup; it builds the sub-tree over them;
+ *   top         : an all-gather of the W sub-roots (32 bytes each); every rank folds the top log2 W levels.
+ * Outputs (device memory of the calling rank):
+ *   d_polys     : [n_traces][n_cols] coefficient columns, complete on every rank (may be NULL)
+ *   d_lde_shard : [n_traces] matrices of R * blowup / W rows x row_width: local row k * (blowup / W) + (c - first coset)
+ *   d_leaves    : N / W digests: leaves r * N / W .. of the tree, natural order
+ *   d_nodes     : N / W digests: the sub-tree in MerkleTree::nodes layout (merkle/mod.rs:87-90) -- [1] = sub-root, which is
+ *                 node W + r of the whole tree; node i of a level with n >= W nodes is local node i - n - r * n / W + n / W
+ *   d_top       : 2 * W digests: nodes 0 .. 2 W - 1 of the whole tree ([0] = zero digest, [1] = the root, [W + s] = the
+ *                 sub-root of rank s), identical on every rank
+ * wf_shard_route says which rank serves a queried position.  Asynchronous on `stream` unless the transport blocks. */
+int wf_trace_commit_sharded_dev(wf_comm *comm, const wf_params *p, const void *d_trace, void *d_polys, void *d_lde_shard,
+                                void *d_leaves, void *d_nodes, void *d_top, void *stream);
 
 /* ---- the path, resident form: commitment stays in HBM, queries are served from there -------------------------------- */
 

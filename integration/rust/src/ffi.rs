@@ -1,0 +1,108 @@
+//! Raw declarations of the C ABI in include/wf_lde.h (the subset the binding uses; names and argument order are the
+//! header's).  Status codes: 0 = success, negative = `wf_status`; `wf_last_error()` describes the calling thread's
+//! last failure.
+
+use std::os::raw::{c_char, c_int, c_void};
+
+pub const WF_FIELD_F64: u32 = 1;
+pub const WF_FIELD_F128: u32 = 2;
+pub const WF_COMM_ID_BYTES: usize = 128;
+
+/// `wf_params` (include/wf_lde.h): what StarkDomain + ProofOptions carry into the two Prover methods.
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct WfParams {
+    pub field: u32,
+    pub ext_degree: u32,
+    pub log2_trace_len: u32,
+    pub log2_blowup: u32,
+    pub n_cols: u32,
+    pub n_traces: u32,
+    pub digest_bytes: u32,
+    pub reserved: u32,
+    pub domain_offset: [u8; 16],
+}
+
+#[repr(C)]
+pub struct WfCtx {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct WfCommitment {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct WfFriProver {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct WfComm {
+    _private: [u8; 0],
+}
+
+extern "C" {
+    pub fn wf_last_error() -> *const c_char;
+    pub fn wf_device_count() -> c_int;
+    pub fn wf_ctx_create(device: c_int, out: *mut *mut WfCtx) -> c_int;
+    pub fn wf_ctx_destroy(ctx: *mut WfCtx);
+    pub fn wf_ctx_synchronize(ctx: *mut WfCtx) -> c_int;
+    pub fn wf_row_width(p: *const WfParams) -> usize;
+
+    // host-buffer form
+    pub fn wf_trace_commit(
+        ctx: *mut WfCtx, p: *const WfParams, trace_cols: *const *const c_void, polys_out: *const *mut c_void,
+        lde_out: *const *mut c_void, leaves_out: *mut u8, nodes_out: *mut u8, root_out: *mut u8,
+    ) -> c_int;
+    pub fn wf_constraint_commit(
+        ctx: *mut WfCtx, p: *const WfParams, poly_cols: *const *const c_void, lde_out: *mut c_void,
+        leaves_out: *mut u8, nodes_out: *mut u8, root_out: *mut u8,
+    ) -> c_int;
+
+    // resident form
+    pub fn wf_trace_commit_resident(
+        ctx: *mut WfCtx, p: *const WfParams, trace_cols: *const *const c_void, polys_out: *const *mut c_void,
+        out: *mut *mut WfCommitment,
+    ) -> c_int;
+    pub fn wf_constraint_commit_resident(
+        ctx: *mut WfCtx, p: *const WfParams, poly_cols: *const *const c_void, out: *mut *mut WfCommitment,
+    ) -> c_int;
+    pub fn wf_commitment_destroy(c: *mut WfCommitment);
+    pub fn wf_commitment_root(c: *const WfCommitment, root_out: *mut u8) -> c_int;
+    pub fn wf_commitment_info(c: *const WfCommitment, n_rows: *mut u64, row_elems: *mut u64, depth: *mut u32) -> c_int;
+    pub fn wf_commitment_query(
+        c: *const WfCommitment, positions: *const u64, n: usize, rows_out: *mut c_void, leaves_out: *mut u8,
+        nodes_out: *mut u8, nodes_capacity: usize, node_counts: *mut u32, n_vectors: *mut usize, n_nodes: *mut usize,
+        depth_out: *mut u32,
+    ) -> c_int;
+    pub fn wf_commitment_evaluate_polys_at(
+        c: *const WfCommitment, z: *const c_void, z_ext_degree: u32, out: *mut c_void,
+    ) -> c_int;
+
+    // FRI commit phase, resident
+    pub fn wf_fri_prover_create(
+        ctx: *mut WfCtx, field: u32, ext_degree: u32, folding: u32, blowup: u32, remainder_max_degree: u32,
+        domain_offset: *const u8, out: *mut *mut WfFriProver,
+    ) -> c_int;
+    pub fn wf_fri_prover_destroy(pr: *mut WfFriProver);
+    pub fn wf_fri_prover_begin(pr: *mut WfFriProver, evals: *const c_void, n: usize) -> c_int;
+    pub fn wf_fri_prover_commit_layer(pr: *mut WfFriProver, root_out: *mut u8) -> c_int;
+    pub fn wf_fri_prover_fold(pr: *mut WfFriProver, alpha: *const c_void) -> c_int;
+    pub fn wf_fri_prover_set_remainder(
+        pr: *mut WfFriProver, remainder_out: *mut c_void, capacity: usize, len_out: *mut usize, commitment_out: *mut u8,
+    ) -> c_int;
+    pub fn wf_fri_prover_layer(pr: *const WfFriProver, i: usize, out: *mut *const WfCommitment) -> c_int;
+    pub fn wf_fri_prover_reset(pr: *mut WfFriProver) -> c_int;
+
+    // several GPUs: one process (or thread) per device
+    pub fn wf_comm_unique_id(id_out: *mut u8) -> c_int;
+    pub fn wf_comm_create(ctx: *mut WfCtx, id: *const u8, rank: c_int, world: c_int, out: *mut *mut WfComm) -> c_int;
+    pub fn wf_comm_destroy(comm: *mut WfComm);
+    pub fn wf_comm_all_gather_roots(
+        comm: *mut WfComm, d_roots: *const c_void, n_roots: usize, d_all: *mut c_void, stream: *mut c_void,
+    ) -> c_int;
+    pub fn wf_comm_barrier(comm: *mut WfComm) -> c_int;
+    pub fn wf_trace_commit_sharded_dev(
+        comm: *mut WfComm, p: *const WfParams, d_trace: *const c_void, d_polys: *mut c_void, d_lde_shard: *mut c_void,
+        d_leaves: *mut c_void, d_nodes: *mut c_void, d_top: *mut c_void, stream: *mut c_void,
+    ) -> c_int;
+}

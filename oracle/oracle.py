@@ -272,19 +272,24 @@ def evaluate_polys_over(field: int, polys, ext: int, log2_R: int, log2_blowup: i
 
 
 def build_trace_commitment(field: int, traces, ext: int, log2_R: int, log2_blowup: int, offset: int,
-                           threads: int = 1):
+                           threads: int = 1, out=None):
     """traces: list (per trace) of lists (per column) of arrays with R*ext elements.
-    Returns dict(polys=[[...]], lde=[...], leaves, nodes, root)."""
+    Returns dict(polys=[[...]], lde=[...], leaves, nodes, root).  out: the dict a previous call of the same shape
+    returned -- its arrays are written again instead of allocating new ones (timing runs)."""
     R, blowup = 1 << log2_R, 1 << log2_blowup
     w = ELEM_WORDS[field]
     n_traces, n_cols = len(traces), len(traces[0])
     rw = row_width(n_cols, ext)
     N = R * blowup
     cols = [np.ascontiguousarray(c, dtype=np.uint64) for t in traces for c in t]
-    polys = [np.empty_like(c) for c in cols]
-    lde = [np.zeros((N, rw, w) if w > 1 else (N, rw), dtype=np.uint64) for _ in range(n_traces)]
-    leaves = np.empty((N, 32), dtype=np.uint8)
-    nodes = np.empty((N, 32), dtype=np.uint8)
+    if out is not None:
+        polys = [c for t in out["polys"] for c in t]
+        lde, leaves, nodes = out["lde"], out["leaves"], out["nodes"]
+    else:
+        polys = [np.empty_like(c) for c in cols]
+        lde = [np.zeros((N, rw, w) if w > 1 else (N, rw), dtype=np.uint64) for _ in range(n_traces)]
+        leaves = np.empty((N, 32), dtype=np.uint8)
+        nodes = np.empty((N, 32), dtype=np.uint8)
     rc = lib().orc_build_trace_commitment(field, ext, log2_R, log2_blowup, n_cols, n_traces, _p(_off_bytes(offset)),
                                           _ptr_array(cols), _ptr_array(polys), _ptr_array(lde), _p(leaves), _p(nodes),
                                           threads)

@@ -28,6 +28,10 @@ SYMBOLS = [
     "wf_fri_prover_layer", "wf_fri_prover_reset", "wf_fri_fold_positions",
     "wf_fft_evaluate_poly", "wf_fft_evaluate_poly_with_offset", "wf_fft_interpolate_poly",
     "wf_fft_interpolate_poly_with_offset", "wf_evaluate_polys_over", "wf_hash_rows", "wf_merkle_build",
+    "wf_comm_unique_id", "wf_comm_create", "wf_comm_create_with_transport", "wf_comm_destroy", "wf_comm_rank",
+    "wf_comm_world", "wf_comm_rccl_version", "wf_comm_all_gather", "wf_comm_all_gather_roots", "wf_comm_barrier",
+    "wf_comm_max_f64", "wf_shard_proofs", "wf_shard_cosets", "wf_shard_route", "wf_comm_all_gather_leaf_shards",
+    "wf_trace_commit_sharded_dev",
 ]
 
 
@@ -43,6 +47,14 @@ class Params(C.Structure):
         ("log2_blowup", C.c_uint32), ("n_cols", C.c_uint32), ("n_traces", C.c_uint32),
         ("digest_bytes", C.c_uint32), ("reserved", C.c_uint32), ("domain_offset", C.c_uint8 * 16),
     ]
+
+
+TRANSPORT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class Transport(C.Structure):
+    """wf_transport: caller-supplied collectives (device pointers)."""
+    _fields_ = [("user", C.c_void_p), ("all_gather", TRANSPORT_FN), ("all_to_all", TRANSPORT_FN)]
 
 
 def make_params(field, ext_degree, log2_trace_len, log2_blowup, n_cols, n_traces=1, offset=None) -> Params:
@@ -155,6 +167,28 @@ def load():
         L.wf_evaluate_polys_over.argtypes = [vp, PP, vp, vp]
         L.wf_hash_rows.argtypes = [vp, u32, vp, sz, sz, vp]
         L.wf_merkle_build.argtypes = [vp, vp, sz, vp]
+        L.wf_device_count.argtypes = []
+        L.wf_ctx_release_cached.argtypes = [vp]
+        L.wf_plan_digits.argtypes = [u32, u32, u32, C.POINTER(u32)]
+        L.wf_commitment_query.argtypes = [vp, vp, sz, vp, vp, vp, sz, vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(u32)]
+        pu32, pu64 = C.POINTER(u32), C.POINTER(C.c_uint64)
+        L.wf_comm_unique_id.argtypes = [vp]
+        L.wf_comm_create.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
+        L.wf_comm_create_with_transport.argtypes = [vp, C.POINTER(Transport), i32, i32, C.POINTER(vp)]
+        L.wf_comm_destroy.argtypes = [vp]
+        L.wf_comm_destroy.restype = None
+        L.wf_comm_rank.argtypes = [vp]
+        L.wf_comm_world.argtypes = [vp]
+        L.wf_comm_rccl_version.argtypes = []
+        L.wf_comm_all_gather.argtypes = [vp, vp, vp, sz, vp]
+        L.wf_comm_all_gather_roots.argtypes = [vp, vp, sz, vp, vp]
+        L.wf_comm_barrier.argtypes = [vp]
+        L.wf_comm_max_f64.argtypes = [vp, C.POINTER(C.c_double)]
+        L.wf_shard_proofs.argtypes = [u32, u32, u32, pu32, pu32]
+        L.wf_shard_cosets.argtypes = [u32, u32, u32, pu32, pu32]
+        L.wf_shard_route.argtypes = [u32, u32, u32, C.c_uint64, pu32, pu64, pu32, pu64]
+        L.wf_comm_all_gather_leaf_shards.argtypes = [vp, vp, sz, u32, vp, vp]
+        L.wf_trace_commit_sharded_dev.argtypes = [vp, PP, vp, vp, vp, vp, vp, vp, vp]
         _lib = L
     return _lib
 

@@ -1,0 +1,413 @@
+// Multi-GPU layer of libwf_lde.so (included by wf_lde.hip): one process per GPU, the path's exchanges behind the C ABI.
+//
+// The reference has no distributed code (/root/reference/README.md:43 lists a distributed prover as planned only); the
+// sharding follows SURVEY.md §8e:
+//   * independent proofs, one per GPU: no data-path collective, ONE all-gather of the 32-byte roots
+//     (wf_comm_all_gather_roots);
+//   * one STARKPack commitment (commit_to_comb_rows, prover/src/matrix/row_matrix.rs:204-238) sharded by coset:
+//     coset c of the LDE domain owns the rows j = k * blowup + c, a leaf needs only its own row of every trace, so a
+//     rank evaluates and hashes its cosets alone and the ranks exchange DIGESTS, never rows.
+// Transport: RCCL (librccl.so.1, resolved with dlopen so that the library loads on hosts without it and shares the
+// copy a PyTorch process has already mapped), or a caller-supplied table of two collectives (wf_transport) -- a host
+// with its own fabric code (MPI, gloo in the rehearsal tests) drives exactly the same partitioning and kernels.
+#pragma once
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace wfcomm {
+
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllToAll) AllToAll = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+};
+
+static Rccl *rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r.handle ? &r : nullptr;
+    tried = true;
+    const char *names[] = {getenv("WF_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) {
+        if (!n || !*n) continue;
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return nullptr;
+#define WF_SYM(field, sym)                                   \
+    r.field = (decltype(r.field))dlsym(h, #sym);             \
+    if (!r.field) {                                          \
+        dlclose(h);                                          \
+        return nullptr;                                      \
+    }
+    WF_SYM(GetUniqueId, ncclGetUniqueId)
+    WF_SYM(CommInitRank, ncclCommInitRank)
+    WF_SYM(CommDestroy, ncclCommDestroy)
+    WF_SYM(AllGather, ncclAllGather)
+    WF_SYM(AllToAll, ncclAllToAll)
+    WF_SYM(GetErrorString, ncclGetErrorString)
+    WF_SYM(GetVersion, ncclGetVersion)
+#undef WF_SYM
+    r.handle = h;
+    return &r;
+}
+
+}  // namespace wfcomm
+
+struct wf_comm {
+    wf_ctx *ctx = nullptr;
+    int rank = 0, world = 1;
+    ncclComm_t nccl = nullptr;  // RCCL transport
+    bool custom = false;        // caller-supplied transport
+    wf_transport tr{};
+    DevBuf stage;  // receive staging of the leaf exchanges ([world][...] rank-major, before the interleave)
+    DevBuf small;  // barrier / reduction words
+};
+
+#define RCCL_TRY(expr)                                                                                   \
+    do {                                                                                                 \
+        ncclResult_t _r = (expr);                                                                        \
+        if (_r != ncclSuccess) return fail(WF_ERR_COMM, "%s failed: %s", #expr, R->GetErrorString(_r)); \
+    } while (0)
+
+// every rank contributes `bytes` at d_send; d_recv receives world * bytes, rank-major
+static int comm_all_gather(wf_comm *c, const void *d_send, void *d_recv, size_t bytes, hipStream_t st) {
+    if (c->world == 1) {
+        if (d_send != d_recv) HIP_TRY(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, st));
+        return 0;
+    }
+    if (c->custom) {
+        const int rc = c->tr.all_gather(c->tr.user, d_send, d_recv, bytes, (void *)st);
+        return rc ? fail(WF_ERR_COMM, "transport all_gather failed with %d", rc) : 0;
+    }
+    wfcomm::Rccl *R = wfcomm::rccl();
+    RCCL_TRY(R->AllGather(d_send, d_recv, bytes, ncclUint8, c->nccl, st));
+    return 0;
+}
+
+// block s (`bytes` bytes at d_send + s * bytes) of rank r lands at d_recv + r * bytes on rank s
+static int comm_all_to_all(wf_comm *c, const void *d_send, void *d_recv, size_t bytes, hipStream_t st) {
+    if (c->world == 1) {
+        if (d_send != d_recv) HIP_TRY(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, st));
+        return 0;
+    }
+    if (c->custom) {
+        const int rc = c->tr.all_to_all(c->tr.user, d_send, d_recv, bytes, (void *)st);
+        return rc ? fail(WF_ERR_COMM, "transport all_to_all failed with %d", rc) : 0;
+    }
+    wfcomm::Rccl *R = wfcomm::rccl();
+    RCCL_TRY(R->AllToAll(d_send, d_recv, bytes, ncclUint8, c->nccl, st));
+    return 0;
+}
+
+namespace wf {
+
+// Leaf digests as they arrive from an exchange -- src[rank s][k][local coset lc], k < n_k, lc < per -- to the order of the
+// tree: dst[k * world * per + s * per + lc] (natural LDE row order inside the k-range).  One 16-byte half digest per lane,
+// consecutive lanes write consecutive bytes.
+__global__ void __launch_bounds__(256) k_interleave_leaves(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint64_t n_k,
+                                                           uint32_t world, uint32_t per) {
+    const uint64_t total = n_k * world * per * 2;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t leaf = g >> 1;
+        const uint32_t beta = world * per;
+        const uint64_t k = leaf / beta;
+        const uint32_t c = (uint32_t)(leaf - k * beta), s = c / per, lc = c - s * per;
+        dst[g] = src[((s * n_k + k) * per + lc) * 2 + (g & 1)];
+    }
+}
+
+}  // namespace wf
+
+static int run_interleave(hipStream_t st, const void *src, void *dst, uint64_t n_k, uint32_t world, uint32_t per) {
+    const uint64_t total = n_k * world * per * 2;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(wf::k_interleave_leaves, dim3(grid), dim3(256), 0, st, (const uint4 *)src, (uint4 *)dst, n_k, world, per);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static bool pow2_u32(uint32_t v) { return v && !(v & (v - 1)); }
+
+// Segment-sharded interpolation + coset-sharded evaluation of one packed commitment; see wf_trace_commit_sharded_dev.
+template <class F>
+static int trace_commit_sharded(wf_comm *c, const wf_params *p, const void *d_trace, void *d_polys, void *d_lde_shard,
+                                void *d_leaves, void *d_nodes, void *d_top, hipStream_t st) {
+    typedef typename F::T T;
+    wf_ctx *ctx = c->ctx;
+    const uint32_t W = (uint32_t)c->world, r = (uint32_t)c->rank;
+    const uint32_t blowup = 1u << p->log2_blowup, per = blowup / W;
+    const uint64_t R = (uint64_t)1 << p->log2_trace_len, N = R << p->log2_blowup;
+    PathBufs<F> b;
+    int rc = path_buffers<F>(ctx, p, b, per);
+    if (rc) return rc;
+    constexpr uint32_t S = SegCfg<F>::S;
+    const size_t seg_bytes = (size_t)R * S * sizeof(T);
+
+    // K1, sharded by segment when the segments divide evenly: rank r interpolates segments [r * n_seg / W, ..) and the
+    // coefficients are all-gathered straight into the segment layout (rank-major == segment-major: no reordering).
+    // Otherwise (fewer segments than ranks) every rank interpolates everything: no exchange.
+    const bool shard_k1 = W > 1 && b.n_seg % W == 0;
+    const uint32_t seg_cnt = shard_k1 ? b.n_seg / W : b.n_seg, seg0 = shard_k1 ? r * seg_cnt : 0;
+    rc = run_xpose<F>(ctx, st, true, d_trace, b.segA, R, p->ext_degree, b.total_base_cols, b.n_seg, seg0, seg_cnt);
+    if (rc) return rc;
+    SegDesc<F> d;
+    memset(&d, 0, sizeof(d));
+    d.in = b.segA + (size_t)seg0 * R * S;
+    d.work = (T *)d.in;
+    d.out = b.segB + (size_t)seg0 * R * S;
+    d.logN = p->log2_trace_len;
+    d.n_seg = seg_cnt;
+    d.n_cosets = 1;
+    d.rows_out = false;
+    rc = run_seg_transform<F>(ctx, st, d);
+    if (rc) return rc;
+    if (shard_k1) {
+        prof_mark(ctx, st, "exchange.polys");
+        rc = comm_all_gather(c, d.out, b.segB, seg_bytes * seg_cnt, st);
+        if (rc) return rc;
+    }
+    if (d_polys) {
+        rc = run_xpose<F>(ctx, st, false, b.segB, d_polys, R, p->ext_degree, b.total_base_cols, b.n_seg, 0, b.n_seg);
+        if (rc) return rc;
+    }
+
+    // K2 + K3 on this rank's cosets: rows k * per + lc of the shard, leaves in the same order, into the send staging
+    const size_t shard_digests = (size_t)R * per * 32;
+    rc = ensure(c->ctx, c->stage, 2 * shard_digests);
+    if (rc) return rc;
+    uint8_t *send = (uint8_t *)c->stage.p, *recv = send + shard_digests;
+    rc = evaluate_and_commit<F>(ctx, st, p, b, d_lde_shard, send, nullptr, r * per, per);
+    if (rc) return rc;
+
+    // The one exchange of the data path: rank s keeps the tree over the leaf range [s * N / W, (s + 1) * N / W), i.e. the
+    // k-range [s * R / W, ..) of every coset -- a contiguous piece of every rank's shard -- so an all-to-all of
+    // R / W * per digests per pair (1 / W of an all-gather's bytes) brings every rank exactly its leaves.
+    prof_mark(ctx, st, "exchange.leaves");
+    rc = comm_all_to_all(c, send, recv, shard_digests / W, st);
+    if (rc) return rc;
+    prof_mark(ctx, st, "merkle");
+    rc = run_interleave(st, recv, d_leaves, R / W, W, per);
+    if (rc) return rc;
+    const uint64_t n_local = N / W;
+    if (n_local >= 2) {
+        rc = run_merkle(st, d_leaves, n_local, d_nodes);  // local layout: d_nodes[1] = this rank's sub-root
+        if (rc) return rc;
+    }
+    // the top log2(W) levels: all-gather of the W sub-roots (32 * W bytes), folded by every rank
+    uint8_t *top = (uint8_t *)d_top;
+    const void *sub_root = n_local >= 2 ? (const uint8_t *)d_nodes + 32 : (const uint8_t *)d_leaves;
+    prof_mark(ctx, st, "exchange.sub_roots");
+    if (W == 1) {
+        HIP_TRY(hipMemcpyAsync(top, d_nodes, 64, hipMemcpyDeviceToDevice, st));  // [0] = zero digest, [1] = root
+    } else {
+        rc = comm_all_gather(c, sub_root, top + (size_t)W * 32, 32, st);
+        if (rc) return rc;
+        rc = run_merkle(st, top + (size_t)W * 32, W, top);
+        if (rc) return rc;
+    }
+    prof_mark(ctx, st, "between_calls");
+    return 0;
+}
+
+extern "C" {
+
+int wf_comm_unique_id(uint8_t id_out[WF_COMM_ID_BYTES]) {
+    if (!id_out) return fail(WF_ERR_ARG, "id_out is null");
+    wfcomm::Rccl *R = wfcomm::rccl();
+    if (!R) return fail(WF_ERR_COMM, "RCCL (librccl.so.1) could not be loaded: %s", dlerror());
+    static_assert(sizeof(ncclUniqueId) == WF_COMM_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    RCCL_TRY(R->GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return 0;
+}
+
+static int comm_common(wf_ctx *ctx, int rank, int world, wf_comm **out) {
+    if (!ctx || !out) return fail(WF_ERR_ARG, "null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(WF_ERR_ARG, "rank %d is not inside a world of %d", rank, world);
+    return 0;
+}
+
+int wf_comm_create(wf_ctx *ctx, const uint8_t id[WF_COMM_ID_BYTES], int rank, int world, wf_comm **out) {
+    int rc = comm_common(ctx, rank, world, out);
+    if (rc) return rc;
+    if (!id) return fail(WF_ERR_ARG, "id is null");
+    wfcomm::Rccl *R = wfcomm::rccl();
+    if (!R) return fail(WF_ERR_COMM, "RCCL (librccl.so.1) could not be loaded: %s", dlerror());
+    HIP_TRY(hipSetDevice(ctx->device));
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    wf_comm *c = new wf_comm();
+    c->ctx = ctx;
+    c->rank = rank;
+    c->world = world;
+    ncclResult_t e = R->CommInitRank(&c->nccl, world, uid, rank);
+    if (e != ncclSuccess) {
+        delete c;
+        return fail(WF_ERR_COMM, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, R->GetErrorString(e));
+    }
+    *out = c;
+    return 0;
+}
+
+int wf_comm_create_with_transport(wf_ctx *ctx, const wf_transport *t, int rank, int world, wf_comm **out) {
+    int rc = comm_common(ctx, rank, world, out);
+    if (rc) return rc;
+    if (!t || !t->all_gather || !t->all_to_all) return fail(WF_ERR_ARG, "transport table is incomplete");
+    wf_comm *c = new wf_comm();
+    c->ctx = ctx;
+    c->rank = rank;
+    c->world = world;
+    c->custom = true;
+    c->tr = *t;
+    *out = c;
+    return 0;
+}
+
+void wf_comm_destroy(wf_comm *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->nccl) {
+        wfcomm::Rccl *R = wfcomm::rccl();
+        if (R) (void)R->CommDestroy(c->nccl);
+    }
+    if (c->stage.p) (void)hipFree(c->stage.p);
+    if (c->small.p) (void)hipFree(c->small.p);
+    delete c;
+}
+
+int wf_comm_rank(const wf_comm *c) { return c ? c->rank : -1; }
+int wf_comm_world(const wf_comm *c) { return c ? c->world : 0; }
+
+int wf_comm_rccl_version(void) {
+    wfcomm::Rccl *R = wfcomm::rccl();
+    int v = 0;
+    if (!R || R->GetVersion(&v) != ncclSuccess) return 0;
+    return v;
+}
+
+int wf_comm_all_gather(wf_comm *c, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream) {
+    if (!c || !d_send || !d_recv) return fail(WF_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(c->ctx->device));
+    return comm_all_gather(c, d_send, d_recv, bytes_per_rank, stream ? (hipStream_t)stream : c->ctx->stream);
+}
+
+int wf_comm_all_gather_roots(wf_comm *c, const void *d_roots, size_t n_roots, void *d_all, void *stream) {
+    return wf_comm_all_gather(c, d_roots, d_all, n_roots * 32, stream);
+}
+
+// all-gather of one 8-byte word per rank through the device, result on the host (blocking)
+static int comm_gather_words(wf_comm *c, uint64_t mine, std::vector<uint64_t> &all) {
+    HIP_TRY(hipSetDevice(c->ctx->device));
+    int rc = ensure(c->ctx, c->small, 8 * (size_t)(c->world + 1));
+    if (rc) return rc;
+    hipStream_t st = c->ctx->stream;
+    uint64_t *d = (uint64_t *)c->small.p;
+    HIP_TRY(hipMemcpyAsync(d, &mine, 8, hipMemcpyHostToDevice, st));
+    rc = comm_all_gather(c, d, d + 1, 8, st);
+    if (rc) return rc;
+    all.resize(c->world);
+    HIP_TRY(hipMemcpyAsync(all.data(), d + 1, 8 * (size_t)c->world, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int wf_comm_barrier(wf_comm *c) {
+    if (!c) return fail(WF_ERR_ARG, "comm is null");
+    std::vector<uint64_t> all;
+    return comm_gather_words(c, (uint64_t)c->rank, all);
+}
+
+int wf_comm_max_f64(wf_comm *c, double *value) {
+    if (!c || !value) return fail(WF_ERR_ARG, "null argument");
+    uint64_t bits;
+    memcpy(&bits, value, 8);
+    std::vector<uint64_t> all;
+    int rc = comm_gather_words(c, bits, all);
+    if (rc) return rc;
+    double m = *value;
+    for (uint64_t w : all) {
+        double v;
+        memcpy(&v, &w, 8);
+        if (v > m) m = v;
+    }
+    *value = m;
+    return 0;
+}
+
+int wf_shard_proofs(uint32_t n_proofs, uint32_t rank, uint32_t world, uint32_t *first, uint32_t *count) {
+    if (!first || !count || world == 0 || rank >= world) return fail(WF_ERR_ARG, "invalid rank / world");
+    const uint32_t base = n_proofs / world, rem = n_proofs % world;
+    *first = rank * base + std::min(rank, rem);
+    *count = base + (rank < rem ? 1 : 0);
+    return 0;
+}
+
+int wf_shard_cosets(uint32_t blowup, uint32_t rank, uint32_t world, uint32_t *first, uint32_t *count) {
+    if (!first || !count || world == 0 || rank >= world) return fail(WF_ERR_ARG, "invalid rank / world");
+    if (!pow2_u32(blowup) || !pow2_u32(world) || blowup % world)
+        return fail(WF_ERR_ARG, "the world size %u must be a power of two dividing the blowup factor %u", world, blowup);
+    *count = blowup / world;
+    *first = rank * *count;
+    return 0;
+}
+
+int wf_shard_route(uint32_t log2_lde_rows, uint32_t blowup, uint32_t world, uint64_t position, uint32_t *row_rank,
+                   uint64_t *row_local, uint32_t *tree_rank, uint64_t *leaf_local) {
+    if (!pow2_u32(blowup) || !pow2_u32(world) || blowup % world || log2_lde_rows > 40)
+        return fail(WF_ERR_ARG, "the world size %u must be a power of two dividing the blowup factor %u", world, blowup);
+    const uint64_t N = (uint64_t)1 << log2_lde_rows;
+    if (position >= N || N < blowup) return fail(WF_ERR_LEAVES, "position %llu is outside the domain", (unsigned long long)position);
+    const uint32_t per = blowup / world;
+    const uint64_t k = position / blowup;
+    const uint32_t cst = (uint32_t)(position % blowup);
+    if (row_rank) *row_rank = cst / per;
+    if (row_local) *row_local = k * per + cst % per;
+    if (tree_rank) *tree_rank = (uint32_t)(position / (N / world));
+    if (leaf_local) *leaf_local = position % (N / world);
+    return 0;
+}
+
+int wf_comm_all_gather_leaf_shards(wf_comm *c, const void *d_leaves_shard, size_t trace_len, uint32_t cosets_per_rank,
+                                   void *d_leaves, void *stream) {
+    if (!c || !d_leaves_shard || !d_leaves) return fail(WF_ERR_ARG, "null argument");
+    if (trace_len == 0 || cosets_per_rank == 0) return fail(WF_ERR_ARG, "empty shard");
+    HIP_TRY(hipSetDevice(c->ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->ctx->stream;
+    const size_t bytes = trace_len * cosets_per_rank * 32;
+    int rc = ensure(c->ctx, c->stage, bytes * c->world);
+    if (rc) return rc;
+    rc = comm_all_gather(c, d_leaves_shard, c->stage.p, bytes, st);
+    if (rc) return rc;
+    return run_interleave(st, c->stage.p, d_leaves, trace_len, (uint32_t)c->world, cosets_per_rank);
+}
+
+int wf_trace_commit_sharded_dev(wf_comm *c, const wf_params *p, const void *d_trace, void *d_polys, void *d_lde_shard,
+                                void *d_leaves, void *d_nodes, void *d_top, void *stream) {
+    if (!c) return fail(WF_ERR_ARG, "comm is null");
+    int rc = check_params(p, false);
+    if (rc) return rc;
+    if (!d_trace || !d_lde_shard || !d_leaves || !d_nodes || !d_top) return fail(WF_ERR_ARG, "null device buffer");
+    uint32_t c0, cn;
+    rc = wf_shard_cosets(1u << p->log2_blowup, (uint32_t)c->rank, (uint32_t)c->world, &c0, &cn);
+    if (rc) return rc;
+    if (((uint64_t)1 << p->log2_trace_len) < (uint64_t)c->world)
+        return fail(WF_ERR_ARG, "trace too short to split its rows over %d ranks", c->world);
+    HIP_TRY(hipSetDevice(c->ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->ctx->stream;
+    CallGuard guard(c->ctx, st);
+    if (guard.rc) return guard.rc;
+    if (p->field == WF_FIELD_F64) return trace_commit_sharded<F64>(c, p, d_trace, d_polys, d_lde_shard, d_leaves, d_nodes, d_top, st);
+    return trace_commit_sharded<F128>(c, p, d_trace, d_polys, d_lde_shard, d_leaves, d_nodes, d_top, st);
+}
+
+}  // extern "C"

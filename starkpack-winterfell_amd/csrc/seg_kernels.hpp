@@ -1274,6 +1274,7 @@ struct XposeArgs {
     uint64_t R;               // rows
     uint32_t W;               // coordinates per column element
     uint32_t total_base_cols;
+    uint32_t seg0;            // first segment of the launch (a rank's share of a segment-sharded interpolation)
 };
 
 // Both directions stage XPOSE_TILES tiles of (256 / S rows) x (S lanes) through LDS so that the column side is
@@ -1287,7 +1288,7 @@ __global__ void __launch_bounds__(256) k_cols_to_seg(XposeArgs<F> a) {
     constexpr uint32_t S = SegCfg<F>::S, RPT = 256 / S, RPB = RPT * XPOSE_TILES;
     __shared__ T tile[XPOSE_TILES][RPT][S + 1];
     const uint64_t blocks_per_seg = (a.R + RPB - 1) / RPB;
-    const uint32_t g = (uint32_t)(blockIdx.x / blocks_per_seg);
+    const uint32_t g = a.seg0 + (uint32_t)(blockIdx.x / blocks_per_seg);
     const uint64_t r0 = (blockIdx.x % blocks_per_seg) * RPB;
     {
         const uint32_t rl = threadIdx.x % RPT, l = threadIdx.x / RPT;
@@ -1319,7 +1320,7 @@ __global__ void __launch_bounds__(256) k_seg_to_cols(XposeArgs<F> a) {
     constexpr uint32_t S = SegCfg<F>::S, RPT = 256 / S, RPB = RPT * XPOSE_TILES;
     __shared__ T tile[XPOSE_TILES][RPT][S + 1];
     const uint64_t blocks_per_seg = (a.R + RPB - 1) / RPB;
-    const uint32_t g = (uint32_t)(blockIdx.x / blocks_per_seg);
+    const uint32_t g = a.seg0 + (uint32_t)(blockIdx.x / blocks_per_seg);
     const uint64_t r0 = (blockIdx.x % blocks_per_seg) * RPB;
     {
         const uint32_t rl = threadIdx.x / S, l = threadIdx.x % S;

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -71,33 +72,103 @@ struct wf_ctx {
     // Buffers of destroyed resident commitments, kept for the next commitment of the same shape (four hipFree + four
     // hipMalloc of 64..512 MiB cost about as much as the commitment itself); released by wf_ctx_release_cached / destroy.
     std::vector<std::pair<void *, size_t>> pool;
+    size_t pool_bytes = 0, pool_cap = (size_t)64 << 30;
     void *pin = nullptr;  // pinned host staging for uploads of many small columns (upload_columns)
     size_t pin_cap = 0;
+    // One call at a time: the thread inside an entry point (0 = none) and its nesting depth.  A second thread entering
+    // while a call is in progress gets WF_ERR_BUSY instead of corrupting scratch and ticket counters.
+    std::atomic<uintptr_t> owner{0};
+    int depth = 0;
+    // The stream the last asynchronous call was issued on.  Scratch, chunk chaining values and ticket counters belong
+    // to the context, so a call on ANOTHER stream first waits (on the device) for everything queued on that one.
+    hipStream_t last_stream = nullptr;
+    hipEvent_t order_ev = nullptr;
 };
+
+// RAII entry of every ctx-taking entry point (see the two comments above).  Re-entrant for the owning thread: the
+// host-buffer forms call the device-buffer forms.
+struct CallGuard {
+    wf_ctx *ctx = nullptr;
+    int rc = 0;
+    static uintptr_t self() {
+        static thread_local char token;
+        return (uintptr_t)&token;
+    }
+    CallGuard(wf_ctx *c, hipStream_t st) {
+        uintptr_t expected = 0;
+        if (c->owner.compare_exchange_strong(expected, self()))
+            c->depth = 1;
+        else if (expected == self())
+            c->depth++;
+        else {
+            rc = fail(WF_ERR_BUSY, "the context is in use by another thread (a wf_ctx serves one call at a time)");
+            return;
+        }
+        ctx = c;
+        if (c->depth == 1 && st) {
+            if (c->last_stream && c->last_stream != st) {
+                // (a stream the caller has destroyed since is refused by hipEventRecord; ROCm drains a stream when it
+                // destroys it, so there is nothing left to wait for)
+                hipError_t e = hipSuccess;
+                if (!c->order_ev) e = hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventRecord(c->order_ev, c->last_stream);
+                if (e == hipSuccess) e = hipStreamWaitEvent(st, c->order_ev, 0);
+                if (e != hipSuccess) (void)hipGetLastError();
+            }
+            c->last_stream = st;
+        }
+    }
+    void release() {
+        if (ctx && --ctx->depth == 0) ctx->owner.store(0);
+        ctx = nullptr;
+    }
+    ~CallGuard() { release(); }
+};
+// stream == nullptr: the call does not touch the device (or synchronises before it returns on the context's stream)
+#define WF_ENTER(ctx_, st_)              \
+    CallGuard _guard((ctx_), (st_));     \
+    if (_guard.rc) return _guard.rc
+
+// hipMalloc that gives the context's parked buffers back to the driver and retries once when the device is full
+static hipError_t dev_malloc(wf_ctx *ctx, void **p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess && ctx && !ctx->pool.empty()) {
+        (void)hipGetLastError();
+        for (auto &b : ctx->pool) (void)hipFree(b.first);
+        ctx->pool.clear();
+        ctx->pool_bytes = 0;
+        e = hipMalloc(p, bytes);
+    }
+    if (e != hipSuccess) (void)hipGetLastError();  // the failure is reported through the return value; leave no sticky error
+    return e;
+}
 
 static hipError_t pool_alloc(wf_ctx *ctx, void **p, size_t bytes) {
     for (size_t i = 0; i < ctx->pool.size(); i++)
         if (ctx->pool[i].second == bytes) {
             *p = ctx->pool[i].first;
             ctx->pool.erase(ctx->pool.begin() + i);
+            ctx->pool_bytes -= bytes;
             return hipSuccess;
         }
-    hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess && !ctx->pool.empty()) {  // out of memory with buffers of other sizes parked: release them, retry
-        (void)hipGetLastError();
-        for (auto &b : ctx->pool) (void)hipFree(b.first);
-        ctx->pool.clear();
-        e = hipMalloc(p, bytes);
-    }
-    return e;
+    return dev_malloc(ctx, p, bytes);
 }
 
+// Parks a buffer for the next commitment of the same shape.  The pool is bounded by entries and by bytes (a quarter of
+// the device memory): the oldest entries are released first, so buffers of shapes that never come back do not pile up.
 static void pool_free(wf_ctx *ctx, void *p, size_t bytes) {
     if (!p) return;
-    if (bytes && ctx->pool.size() < 16)
-        ctx->pool.emplace_back(p, bytes);
-    else
+    if (!bytes || bytes > ctx->pool_cap) {
         (void)hipFree(p);
+        return;
+    }
+    ctx->pool.emplace_back(p, bytes);
+    ctx->pool_bytes += bytes;
+    while (ctx->pool.size() > 16 || ctx->pool_bytes > ctx->pool_cap) {
+        (void)hipFree(ctx->pool.front().first);
+        ctx->pool_bytes -= ctx->pool.front().second;
+        ctx->pool.erase(ctx->pool.begin());
+    }
 }
 
 // logical kernel of a mark: the text before the first '.', with the layout changes counted as interpolation
@@ -131,14 +202,18 @@ static void prof_mark(wf_ctx *ctx, hipStream_t st, const char *name) {
     ctx->prof_n++;
 }
 
-static int ensure(DevBuf &b, size_t bytes) {
+static int ensure(wf_ctx *ctx, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap) return 0;
     if (b.p) {
         HIP_TRY(hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
     }
-    HIP_TRY(hipMalloc(&b.p, bytes));
+    hipError_t e = dev_malloc(ctx, &b.p, bytes);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(WF_ERR_HIP, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    }
     b.cap = bytes;
     return 0;
 }
@@ -434,7 +509,7 @@ static int run_transform(wf_ctx *ctx, hipStream_t st, const XformDesc<F> &d) {
     // the last pass scatters to natural order and therefore cannot run in place
     T *scratch = nullptr;
     if (plan.n_pass > 1) {
-        rc = ensure(ctx->scratch, (size_t)d.batch * N * d.W * sizeof(T));
+        rc = ensure(ctx, ctx->scratch, (size_t)d.batch * N * d.W * sizeof(T));
         if (rc) return rc;
         scratch = (T *)ctx->scratch.p;
     }
@@ -721,7 +796,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
                                         : (small ? (const void *)k_seg_last_hash<F, true, false, false, true> : (const void *)k_seg_last_hash<F, true, false>))
                         : (a.pad_traces ? (const void *)k_seg_last_hash<F, false, true> : (const void *)k_seg_last_hash<F, false, false>);
             if (chunked) {
-                int rcc = ensure(ctx->hash_tmp, (size_t)launch_rows * n_chunks * 32);
+                int rcc = ensure(ctx, ctx->hash_tmp, (size_t)launch_rows * n_chunks * 32);
                 if (rcc) return rcc;
                 a.chunk_cvs = (uint32_t *)ctx->hash_tmp.p;
                 a.n_chunks = n_chunks;
@@ -730,7 +805,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             const size_t lds_p = lds + 16;  // two ticket words behind the twiddles
             const uint64_t resident = (uint64_t)ctx->num_cus * std::max<size_t>(1, (160 * 1024) / lds_p);
             if (!ctx->tickets.p) {  // zeroed once: the kernel leaves its counters at zero
-                int rcq = ensure(ctx->tickets, 64);
+                int rcq = ensure(ctx, ctx->tickets, 64);
                 if (rcq) return rcq;
                 HIP_TRY(hipMemsetAsync(ctx->tickets.p, 0, 64, st));  // ordered on the launch stream (first use only)
             }
@@ -754,15 +829,17 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
 
 template <class F>
 static int run_xpose(wf_ctx *ctx, hipStream_t st, bool to_seg, const void *src, void *dst, uint64_t R, uint32_t W,
-                     uint32_t total_base_cols, uint32_t n_seg) {
+                     uint32_t total_base_cols, uint32_t n_seg, uint32_t seg0 = 0, uint32_t seg_cnt = 0) {
+    if (seg_cnt == 0) seg_cnt = n_seg - seg0;  // segments [seg0, seg0 + seg_cnt) of the n_seg of the matrix
     XposeArgs<F> x;
+    x.seg0 = seg0;
     x.src = (const typename F::T *)src;
     x.dst = (typename F::T *)dst;
     x.R = R;
     x.W = W;
     x.total_base_cols = total_base_cols;
     constexpr uint32_t RPB = XPOSE_TILES * 256 / SegCfg<F>::S;
-    const uint64_t grid = (uint64_t)n_seg * ((R + RPB - 1) / RPB);
+    const uint64_t grid = (uint64_t)seg_cnt * ((R + RPB - 1) / RPB);
     if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch");
     prof_mark(ctx, st, to_seg ? "layout.cols_to_segments" : "layout.segments_to_cols");
     if (to_seg)
@@ -806,7 +883,7 @@ static int run_hash_rows(wf_ctx *ctx, hipStream_t st, const void *lde, uint64_t 
         const uint64_t chunks = (row_bytes + 1023) / 1024;
         if (chunks > 0xFFFFFFFFull || n_rows * chunks > 0x7FFFFFFFull * threads)
             return fail(WF_ERR_ARG, "rows too long for one launch");
-        int rc = ensure(ctx->hash_tmp, (size_t)n_rows * chunks * 32);
+        int rc = ensure(ctx, ctx->hash_tmp, (size_t)n_rows * chunks * 32);
         if (rc) return rc;
         const uint64_t g2 = (n_rows * chunks + threads - 1) / threads;
         hipLaunchKernelGGL(k_hash_chunks<F>, dim3((uint32_t)g2), dim3(threads), 0, st, h, (uint32_t)chunks,
@@ -901,15 +978,17 @@ struct PathBufs {
     uint32_t n_seg, total_base_cols;
 };
 
+// n_cosets: the cosets this call evaluates (0 = all of them; a rank of a coset-sharded commitment has blowup / W)
 template <class F>
-static int path_buffers(wf_ctx *ctx, const wf_params *p, PathBufs<F> &b) {
+static int path_buffers(wf_ctx *ctx, const wf_params *p, PathBufs<F> &b, uint32_t n_cosets = 0) {
     typedef typename F::T T;
     constexpr uint32_t S = SegCfg<F>::S;
     b.total_base_cols = p->n_cols * p->ext_degree * p->n_traces;
     b.n_seg = (b.total_base_cols + S - 1) / S;
     const size_t seg_vals = (size_t)b.n_seg * S << p->log2_trace_len;
-    const size_t work_vals = seg_plan<F>(p->log2_trace_len, b.n_seg).n_pass > 1 ? seg_vals << p->log2_blowup : 0;
-    int rc = ensure(ctx->scratch, (2 * seg_vals + work_vals) * sizeof(T));
+    if (n_cosets == 0) n_cosets = 1u << p->log2_blowup;
+    const size_t work_vals = seg_plan<F>(p->log2_trace_len, b.n_seg).n_pass > 1 ? seg_vals * n_cosets : 0;
+    int rc = ensure(ctx, ctx->scratch, (2 * seg_vals + work_vals) * sizeof(T));
     if (rc) return rc;
     b.segA = (T *)ctx->scratch.p;
     b.segB = b.segA + seg_vals;
@@ -1100,6 +1179,7 @@ void wf_ctx_destroy(wf_ctx *ctx) {
     for (auto &b : ctx->pool) (void)hipFree(b.first);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (auto e : ctx->prof_ev) (void)hipEventDestroy(e);
+    if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1116,6 +1196,7 @@ int wf_plan_digits(uint32_t field, uint32_t log2_n, uint32_t n_segments, uint32_
 int wf_ctx_release_cached(wf_ctx *ctx) {
     if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
     HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
     for (auto &b : ctx->pool) (void)hipFree(b.first);
     ctx->pool.clear();
     return 0;
@@ -1170,6 +1251,7 @@ int wf_trace_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_trace, vo
     if (!d_trace || !d_polys || !d_lde) return fail(WF_ERR_ARG, "null device buffer");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    WF_ENTER(ctx, st);
     if (p->field == WF_FIELD_F64) return trace_commit_dev<F64>(ctx, p, d_trace, d_polys, d_lde, d_leaves, d_nodes, st);
     return trace_commit_dev<F128>(ctx, p, d_trace, d_polys, d_lde, d_leaves, d_nodes, st);
 }
@@ -1182,6 +1264,7 @@ int wf_constraint_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_poly
     if (!d_polys || !d_lde) return fail(WF_ERR_ARG, "null device buffer");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    WF_ENTER(ctx, st);
     if (p->field == WF_FIELD_F64) return constraint_commit_dev<F64>(ctx, p, d_polys, d_lde, d_leaves, d_nodes, st);
     return constraint_commit_dev<F128>(ctx, p, d_polys, d_lde, d_leaves, d_nodes, st);
 }
@@ -1193,7 +1276,7 @@ template <class F>
 static int trace_commit_shard_dev(wf_ctx *ctx, const wf_params *p, uint32_t coset0, uint32_t n_cosets,
                                   const void *d_trace, void *d_polys, void *d_lde, void *d_leaves, hipStream_t st) {
     PathBufs<F> b;
-    int rc = path_buffers<F>(ctx, p, b);
+    int rc = path_buffers<F>(ctx, p, b, n_cosets);
     if (rc) return rc;
     const uint64_t R = (uint64_t)1 << p->log2_trace_len;
     rc = run_xpose<F>(ctx, st, true, d_trace, b.segA, R, p->ext_degree, b.total_base_cols, b.n_seg);
@@ -1230,6 +1313,7 @@ int wf_trace_commit_shard_dev(wf_ctx *ctx, const wf_params *p, uint32_t coset_be
         return fail(WF_ERR_ARG, "coset range [%u, %u) is not inside [0, %u)", coset_begin, coset_begin + coset_count, blowup);
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    WF_ENTER(ctx, st);
     if (p->field == WF_FIELD_F64)
         return trace_commit_shard_dev<F64>(ctx, p, coset_begin, coset_count, d_trace, d_polys, d_lde_shard, d_leaves_shard, st);
     return trace_commit_shard_dev<F128>(ctx, p, coset_begin, coset_count, d_trace, d_polys, d_lde_shard, d_leaves_shard, st);
@@ -1242,6 +1326,7 @@ int wf_merkle_build_dev(wf_ctx *ctx, const void *d_leaves, size_t n_leaves, void
     if (n_leaves & (n_leaves - 1)) return fail(WF_ERR_LEAVES, "number of leaves must be a power of two");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    WF_ENTER(ctx, st);
     prof_mark(ctx, st, "merkle");
     int rc = run_merkle(st, d_leaves, n_leaves, d_nodes);
     prof_mark(ctx, st, "between_calls");
@@ -1257,15 +1342,16 @@ static int commit_host(wf_ctx *ctx, const wf_params *p, bool constraint, const v
     if (rc) return rc;
     if (!cols_in) return fail(WF_ERR_ARG, "column pointer array is null");
     HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
     const size_t colb = wf_column_bytes(p), ldeb = wf_lde_bytes(p), digb = wf_digests_bytes(p);
     const size_t TC = (size_t)p->n_cols * p->n_traces;
     for (size_t i = 0; i < TC; i++)
         if (!cols_in[i]) return fail(WF_ERR_ARG, "column %zu is null", i);
-    if ((rc = ensure(ctx->io[0], TC * colb))) return rc;
-    if (!constraint && (rc = ensure(ctx->io[1], TC * colb))) return rc;
-    if ((rc = ensure(ctx->io[2], ldeb * p->n_traces))) return rc;
-    if ((rc = ensure(ctx->io[3], digb))) return rc;
-    if ((rc = ensure(ctx->io[4], digb))) return rc;
+    if ((rc = ensure(ctx, ctx->io[0], TC * colb))) return rc;
+    if (!constraint && (rc = ensure(ctx, ctx->io[1], TC * colb))) return rc;
+    if ((rc = ensure(ctx, ctx->io[2], ldeb * p->n_traces))) return rc;
+    if ((rc = ensure(ctx, ctx->io[3], digb))) return rc;
+    if ((rc = ensure(ctx, ctx->io[4], digb))) return rc;
     hipStream_t st = ctx->stream;
     if ((rc = upload_columns(ctx, ctx->io[0].p, cols_in, TC, colb, st))) return rc;
     void *d_polys = constraint ? ctx->io[0].p : ctx->io[1].p;
@@ -1329,6 +1415,7 @@ static int commit_resident(wf_ctx *ctx, const wf_params *p, bool constraint, con
     if (rc) return rc;
     if (!cols_in) return fail(WF_ERR_ARG, "column pointer array is null");
     HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
     const size_t colb = wf_column_bytes(p), ldeb = wf_lde_bytes(p), digb = wf_digests_bytes(p);
     const size_t TC = (size_t)p->n_cols * p->n_traces;
     for (size_t i = 0; i < TC; i++)
@@ -1354,7 +1441,7 @@ static int commit_resident(wf_ctx *ctx, const wf_params *p, bool constraint, con
         free_commitment(c);
         return fail(WF_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
     }
-    rc = ensure(ctx->io[0], TC * colb);
+    rc = ensure(ctx, ctx->io[0], TC * colb);
     if (rc) {
         free_commitment(c);
         return rc;
@@ -1430,10 +1517,11 @@ int wf_commitment_read_rows(const wf_commitment *c, const uint64_t *positions, s
     if (!rows_out) return fail(WF_ERR_ARG, "rows_out is null");
     wf_ctx *ctx = c->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
     const size_t eb = wf_elem_bytes(c->p.field);
     const size_t out_bytes = n * c->row_elems * eb;
-    if ((rc = ensure(ctx->io[3], n * 8))) return rc;
-    if ((rc = ensure(ctx->io[4], out_bytes))) return rc;
+    if ((rc = ensure(ctx, ctx->io[3], n * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->io[4], out_bytes))) return rc;
     hipStream_t st = ctx->stream;
     HIP_TRY(hipMemcpyAsync(ctx->io[3].p, positions, n * 8, hipMemcpyHostToDevice, st));
     const uint64_t trace_elems = c->n_rows * c->row_width;
@@ -1456,8 +1544,8 @@ static int fetch_digests(const wf_commitment *c, const std::vector<uint64_t> &id
     if (ids.empty()) return 0;
     wf_ctx *ctx = c->ctx;
     int rc;
-    if ((rc = ensure(ctx->io[3], ids.size() * 8))) return rc;
-    if ((rc = ensure(ctx->io[4], ids.size() * 32))) return rc;
+    if ((rc = ensure(ctx, ctx->io[3], ids.size() * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->io[4], ids.size() * 32))) return rc;
     hipStream_t st = ctx->stream;
     HIP_TRY(hipMemcpyAsync(ctx->io[3].p, ids.data(), ids.size() * 8, hipMemcpyHostToDevice, st));
     const uint32_t n = (uint32_t)ids.size();
@@ -1473,6 +1561,7 @@ int wf_commitment_prove(const wf_commitment *c, uint64_t index, uint8_t *path_ou
     if (!c || !path_out) return fail(WF_ERR_ARG, "null argument");
     if (index >= c->n_rows) return fail(WF_ERR_LEAVES, "leaf index out of bounds");  // merkle/mod.rs:193-198
     HIP_TRY(hipSetDevice(c->ctx->device));
+    WF_ENTER(c->ctx, c->ctx->stream);
     std::vector<uint64_t> ids{index, index ^ 1};
     for (uint64_t i = (index + c->n_rows) >> 1; i > 1; i >>= 1) ids.push_back(c->n_rows + (i ^ 1));
     return fetch_digests(c, ids, path_out);
@@ -1529,6 +1618,7 @@ static int query_impl(const wf_commitment *c, const uint64_t *positions, size_t 
     if (!leaves_out || !nodes_out || !node_counts || !n_vectors || !n_nodes) return fail(WF_ERR_ARG, "null argument");
     wf_ctx *ctx = c->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
     std::vector<std::vector<uint64_t>> vec_ids;
     size_t total = 0;
     if ((rc = batch_proof_ids(c, positions, n, vec_ids, total))) return rc;
@@ -1538,8 +1628,8 @@ static int query_impl(const wf_commitment *c, const uint64_t *positions, size_t 
     // one upload, the gathers, one download, one synchronisation
     const size_t eb = wf_elem_bytes(c->p.field);
     const size_t rows_bytes = rows_out ? ((n * c->row_elems * eb + 255) & ~(size_t)255) : 0, dig_bytes = ids.size() * 32;
-    if ((rc = ensure(ctx->io[3], ids.size() * 8))) return rc;
-    if ((rc = ensure(ctx->io[4], rows_bytes + dig_bytes))) return rc;
+    if ((rc = ensure(ctx, ctx->io[3], ids.size() * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->io[4], rows_bytes + dig_bytes))) return rc;
     hipStream_t st = ctx->stream;
     HIP_TRY(hipMemcpyAsync(ctx->io[3].p, ids.data(), ids.size() * 8, hipMemcpyHostToDevice, st));
     if (rows_out && n) {
@@ -1683,6 +1773,7 @@ int wf_fri_layer_commit_dev(wf_ctx *ctx, uint32_t field, uint32_t ext, const voi
     if (!d_evals || !d_transposed || !d_leaves || !d_nodes) return fail(WF_ERR_ARG, "null device buffer");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    WF_ENTER(ctx, st);
     return field == WF_FIELD_F64 ? fri_layer_commit_dev<F64>(ctx, st, ext, d_evals, n, folding, d_transposed, d_leaves, d_nodes)
                                  : fri_layer_commit_dev<F128>(ctx, st, ext, d_evals, n, folding, d_transposed, d_leaves, d_nodes);
 }
@@ -1696,6 +1787,7 @@ int wf_fri_apply_drp_dev(wf_ctx *ctx, uint32_t field, uint32_t ext, const void *
     if (!d_transposed || !d_out || !alpha || !domain_offset) return fail(WF_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    WF_ENTER(ctx, st);
     return field == WF_FIELD_F64 ? fri_apply_drp_dev<F64>(ctx, st, ext, d_transposed, rows, folding, domain_offset, alpha, d_out)
                                  : fri_apply_drp_dev<F128>(ctx, st, ext, d_transposed, rows, folding, domain_offset, alpha, d_out);
 }
@@ -1707,11 +1799,12 @@ int wf_fri_layer_commit(wf_ctx *ctx, uint32_t field, uint32_t ext, const void *e
     if (rc) return rc;
     if (!evals) return fail(WF_ERR_ARG, "evaluations pointer is null");
     HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
     const size_t bytes = n * ext * wf_elem_bytes(field), rows = n / folding;
-    if ((rc = ensure(ctx->io[0], bytes))) return rc;
-    if ((rc = ensure(ctx->io[2], bytes))) return rc;
-    if ((rc = ensure(ctx->io[3], rows * 32))) return rc;
-    if ((rc = ensure(ctx->io[4], rows * 32))) return rc;
+    if ((rc = ensure(ctx, ctx->io[0], bytes))) return rc;
+    if ((rc = ensure(ctx, ctx->io[2], bytes))) return rc;
+    if ((rc = ensure(ctx, ctx->io[3], rows * 32))) return rc;
+    if ((rc = ensure(ctx, ctx->io[4], rows * 32))) return rc;
     hipStream_t st = ctx->stream;
     HIP_TRY(hipMemcpyAsync(ctx->io[0].p, evals, bytes, hipMemcpyHostToDevice, st));
     rc = wf_fri_layer_commit_dev(ctx, field, ext, ctx->io[0].p, n, folding, ctx->io[2].p, ctx->io[3].p, ctx->io[4].p, st);
@@ -1731,9 +1824,10 @@ int wf_fri_apply_drp(wf_ctx *ctx, uint32_t field, uint32_t ext, const void *tran
     if (rc) return rc;
     if (!transposed || !out) return fail(WF_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
     const size_t eb = ext * wf_elem_bytes(field);
-    if ((rc = ensure(ctx->io[0], rows * folding * eb))) return rc;
-    if ((rc = ensure(ctx->io[1], rows * eb))) return rc;
+    if ((rc = ensure(ctx, ctx->io[0], rows * folding * eb))) return rc;
+    if ((rc = ensure(ctx, ctx->io[1], rows * eb))) return rc;
     hipStream_t st = ctx->stream;
     HIP_TRY(hipMemcpyAsync(ctx->io[0].p, transposed, rows * folding * eb, hipMemcpyHostToDevice, st));
     rc = wf_fri_apply_drp_dev(ctx, field, ext, ctx->io[0].p, rows, folding, domain_offset, alpha, ctx->io[1].p, st);
@@ -1759,7 +1853,7 @@ static int eval_columns_at_dev(wf_ctx *ctx, hipStream_t st, const void *d_polys,
     for (uint32_t w = 0; w < ext_z; w++)
         if (!F::is_valid(a.z[w])) return fail(WF_ERR_ARG, "z is not a valid field element");
     a.n_blocks = (uint32_t)((n + EVAL_BLOCK - 1) / EVAL_BLOCK);
-    int rcp = ensure(ctx->hash_tmp, n_cols * a.n_blocks * ext_z * sizeof(T));  // (block values; no hashing runs alongside)
+    int rcp = ensure(ctx, ctx->hash_tmp, n_cols * a.n_blocks * ext_z * sizeof(T));  // (block values; no hashing runs alongside)
     if (rcp) return rcp;
     a.partial = (T *)ctx->hash_tmp.p;
     const dim3 grid(a.n_blocks, (uint32_t)n_cols), grid2((uint32_t)n_cols), block(256);
@@ -1798,9 +1892,10 @@ int wf_commitment_evaluate_polys_at(const wf_commitment *c, const void *z, uint3
     if (!c->polys) return fail(WF_ERR_ARG, "this commitment holds no polynomials (FRI layer)");
     wf_ctx *ctx = c->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
     const size_t n_cols = (size_t)c->p.n_cols * c->p.n_traces, n = (size_t)1 << c->p.log2_trace_len;
     const size_t out_bytes = n_cols * z_ext_degree * wf_elem_bytes(c->p.field);
-    int rc = ensure(ctx->io[4], out_bytes);
+    int rc = ensure(ctx, ctx->io[4], out_bytes);
     if (rc) return rc;
     hipStream_t st = ctx->stream;
     rc = c->p.field == WF_FIELD_F64
@@ -1820,9 +1915,10 @@ int wf_evaluate_columns_at(wf_ctx *ctx, uint32_t field, uint32_t ext_degree, con
     if (!poly_cols || !z || !out || n_cols == 0) return fail(WF_ERR_ARG, "null argument");
     int rc;
     HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
     const size_t colb = n * ext_degree * wf_elem_bytes(field), out_bytes = n_cols * z_ext_degree * wf_elem_bytes(field);
-    if ((rc = ensure(ctx->io[0], n_cols * colb))) return rc;
-    if ((rc = ensure(ctx->io[4], out_bytes))) return rc;
+    if ((rc = ensure(ctx, ctx->io[0], n_cols * colb))) return rc;
+    if ((rc = ensure(ctx, ctx->io[4], out_bytes))) return rc;
     hipStream_t st = ctx->stream;
     for (size_t i = 0; i < n_cols; i++)
         if (!poly_cols[i]) return fail(WF_ERR_ARG, "column %zu is null", i);
@@ -1862,8 +1958,8 @@ static int fft_host(wf_ctx *ctx, uint32_t ext, void *buf, uint32_t logn, bool in
     typedef typename F::T T;
     const size_t bytes = ((size_t)1 << logn) * ext * sizeof(T);
     int rc;
-    if ((rc = ensure(ctx->io[0], bytes))) return rc;
-    if ((rc = ensure(ctx->io[1], bytes))) return rc;
+    if ((rc = ensure(ctx, ctx->io[0], bytes))) return rc;
+    if ((rc = ensure(ctx, ctx->io[1], bytes))) return rc;
     hipStream_t st = ctx->stream;
     HIP_TRY(hipMemcpyAsync(ctx->io[0].p, buf, bytes, hipMemcpyHostToDevice, st));
     XformDesc<F> d;
@@ -1903,6 +1999,7 @@ int wf_fft_evaluate_poly(wf_ctx *ctx, uint32_t field, uint32_t ext, void *poly, 
     int rc = check_fft_args(ctx, field, ext, poly, n, &l);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
     return field == WF_FIELD_F64 ? fft_host<F64>(ctx, ext, poly, l, false, nullptr) : fft_host<F128>(ctx, ext, poly, l, false, nullptr);
 }
 
@@ -1911,6 +2008,7 @@ int wf_fft_interpolate_poly(wf_ctx *ctx, uint32_t field, uint32_t ext, void *eva
     int rc = check_fft_args(ctx, field, ext, evals, n, &l);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
     return field == WF_FIELD_F64 ? fft_host<F64>(ctx, ext, evals, l, true, nullptr) : fft_host<F128>(ctx, ext, evals, l, true, nullptr);
 }
 
@@ -1921,6 +2019,7 @@ int wf_fft_interpolate_poly_with_offset(wf_ctx *ctx, uint32_t field, uint32_t ex
     if (rc) return rc;
     if (!domain_offset) return fail(WF_ERR_ARG, "domain offset is null");
     HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
     return field == WF_FIELD_F64 ? fft_host<F64>(ctx, ext, evals, l, true, domain_offset)
                                  : fft_host<F128>(ctx, ext, evals, l, true, domain_offset);
 }
@@ -1957,9 +2056,10 @@ int wf_fft_evaluate_poly_with_offset(wf_ctx *ctx, uint32_t field, uint32_t ext, 
     p.digest_bytes = 32;
     memcpy(p.domain_offset, domain_offset, 16);
     HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
     const size_t eb = wf_elem_bytes(field), ldeb = wf_lde_bytes(&p), colb = wf_column_bytes(&p);
-    if ((rc = ensure(ctx->io[0], colb))) return rc;
-    if ((rc = ensure(ctx->io[2], ldeb))) return rc;
+    if ((rc = ensure(ctx, ctx->io[0], colb))) return rc;
+    if ((rc = ensure(ctx, ctx->io[2], ldeb))) return rc;
     hipStream_t st = ctx->stream;
     HIP_TRY(hipMemcpyAsync(ctx->io[0].p, poly, colb, hipMemcpyHostToDevice, st));
     const bool dense = field == WF_FIELD_F64 ? dense_column_ok<F64>(&p) : dense_column_ok<F128>(&p);
@@ -1981,10 +2081,11 @@ int wf_hash_rows(wf_ctx *ctx, uint32_t field, const void *rows, size_t n_rows, s
     if (!digests_out || (!rows && n_rows * row_elems)) return fail(WF_ERR_ARG, "null argument");
     if (n_rows == 0) return 0;
     HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
     const size_t bytes = n_rows * row_elems * wf_elem_bytes(field);
     int rc;
-    if ((rc = ensure(ctx->io[2], bytes ? bytes : 16))) return rc;
-    if ((rc = ensure(ctx->io[3], n_rows * 32))) return rc;
+    if ((rc = ensure(ctx, ctx->io[2], bytes ? bytes : 16))) return rc;
+    if ((rc = ensure(ctx, ctx->io[3], n_rows * 32))) return rc;
     hipStream_t st = ctx->stream;
     if (bytes) HIP_TRY(hipMemcpyAsync(ctx->io[2].p, rows, bytes, hipMemcpyHostToDevice, st));
     if (field == WF_FIELD_F64)
@@ -2003,9 +2104,10 @@ int wf_merkle_build(wf_ctx *ctx, const uint8_t *leaves, size_t n_leaves, uint8_t
     if (n_leaves < 2) return fail(WF_ERR_LEAVES, "a tree must have at least 2 leaves");           // merkle/mod.rs:118-120
     if (n_leaves & (n_leaves - 1)) return fail(WF_ERR_LEAVES, "number of leaves must be a power of two");  // :121-123
     HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
     int rc;
-    if ((rc = ensure(ctx->io[3], n_leaves * 32))) return rc;
-    if ((rc = ensure(ctx->io[4], n_leaves * 32))) return rc;
+    if ((rc = ensure(ctx, ctx->io[3], n_leaves * 32))) return rc;
+    if ((rc = ensure(ctx, ctx->io[4], n_leaves * 32))) return rc;
     hipStream_t st = ctx->stream;
     HIP_TRY(hipMemcpyAsync(ctx->io[3].p, leaves, n_leaves * 32, hipMemcpyHostToDevice, st));
     rc = run_merkle(st, ctx->io[3].p, n_leaves, ctx->io[4].p);
@@ -2049,7 +2151,7 @@ static int fri_arena_reserve(wf_fri_prover *pr, size_t n) {
         total += (m * eb + 256) + 2 * (rows * 32 + 256) + (rows * eb + 256);
     }
     pr->arena_used = 0;
-    return ensure(pr->arena, total);
+    return ensure(pr->ctx, pr->arena, total);
 }
 
 static void fri_prover_clear(wf_fri_prover *pr) {
@@ -2142,6 +2244,7 @@ static int fri_prover_begin(wf_fri_prover *pr, const void *src, size_t n, bool o
     if (l > (pr->field == WF_FIELD_F64 ? F64::TWO_ADICITY : F128::TWO_ADICITY))
         return fail(WF_ERR_DOMAIN, "no multiplicative subgroup of size 2^%u in this field", l);
     HIP_TRY(hipSetDevice(pr->ctx->device));
+    WF_ENTER(pr->ctx, pr->ctx->stream);
     const size_t bytes = n * pr->ext * wf_elem_bytes(pr->field);
     int rca = fri_arena_reserve(pr, n);
     if (rca) return rca;
@@ -2182,10 +2285,11 @@ int wf_fri_prover_begin_poly(wf_fri_prover *pr, const void *poly, size_t n, size
     int rc = check_params(&p, true);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
     const size_t eb = wf_elem_bytes(pr->field), rows = n * lde_blowup, rw = wf_row_width(&p);
-    if ((rc = ensure(ctx->io[0], wf_column_bytes(&p)))) return rc;
+    if ((rc = ensure(ctx, ctx->io[0], wf_column_bytes(&p)))) return rc;
     const bool dense = pr->field == WF_FIELD_F64 ? dense_column_ok<F64>(&p) : dense_column_ok<F128>(&p);
-    if (!dense && (rc = ensure(ctx->io[2], wf_lde_bytes(&p)))) return rc;
+    if (!dense && (rc = ensure(ctx, ctx->io[2], wf_lde_bytes(&p)))) return rc;
     if ((rc = fri_arena_reserve(pr, rows))) return rc;
     HIP_TRY(hipMalloc(&pr->evals, rows * pr->ext * eb));
     pr->evals_borrowed = false;
@@ -2219,6 +2323,7 @@ int wf_fri_prover_commit_layer(wf_fri_prover *pr, uint8_t root_out[32]) {
     if (rc) return rc;
     wf_ctx *ctx = pr->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
     const size_t eb = wf_elem_bytes(pr->field), rows = pr->n / pr->folding;
     wf_commitment *c = new wf_commitment();
     memset(c, 0, sizeof(*c));
@@ -2270,6 +2375,7 @@ int wf_fri_prover_fold(wf_fri_prover *pr, const void *alpha) {
     if (!pr->pending) return fail(WF_ERR_ARG, "no committed layer to fold: call wf_fri_prover_commit_layer first");
     wf_ctx *ctx = pr->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
     const size_t rows = pr->n / pr->folding;
     void *next = fri_arena_take(pr, rows * pr->ext * wf_elem_bytes(pr->field));
     const bool next_borrowed = next != nullptr;
@@ -2304,6 +2410,7 @@ int wf_fri_prover_set_remainder(wf_fri_prover *pr, void *remainder_out, size_t c
     if (len > capacity) return fail(WF_ERR_ARG, "remainder has %zu coefficients, buffer holds %zu", len, capacity);
     wf_ctx *ctx = pr->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
     const size_t eb = wf_elem_bytes(pr->field), bytes = pr->n * pr->ext * eb;
     std::vector<unsigned char> host(bytes);
     HIP_TRY(hipMemcpyAsync(host.data(), pr->evals, bytes, hipMemcpyDeviceToHost, ctx->stream));  // (after the last fold)
@@ -2333,3 +2440,4 @@ int wf_fri_prover_layer(const wf_fri_prover *pr, size_t i, const wf_commitment *
 
 }  // extern "C"
 
+#include "comm.hpp"

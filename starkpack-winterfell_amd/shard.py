@@ -1,21 +1,33 @@
-"""Multi-GPU layout of the path: independent proofs, one commitment per GPU, roots assembled by ONE all-gather.
+"""Multi-GPU layout of the path -- a thin caller of the wf_comm part of the C ABI (include/wf_lde.h, csrc/comm.hpp).
 
-The reference has no distributed code ("Distributed communication backend: none").  BASELINE.json
-configs[3] shards independent 2^20-row proofs one per GPU and assembles their Merkle roots with a single
-all-gather (RCCL over xGMI; `gloo` in the CPU tests).  There is no data-path collective: a commitment never
-needs another rank's rows.
+The reference has no distributed code ("Distributed communication backend: none").  One process per
+GPU; the partition rules (wf_shard_*), the exchanges (RCCL inside libwf_lde.so) and the kernels around them all
+live behind the C ABI, so a Rust host binds exactly what this module binds:
+
+  * independent proofs, one per GPU (BASELINE.json configs[3]): no data-path collective, ONE all-gather of the
+    32-byte roots -- `Comm.all_gather_roots`;
+  * one STARKPack commitment sharded by coset -- `Comm.trace_commit_sharded_dev`.
+
+Rendezvous: rank 0 draws the RCCL unique id (`wf_comm_unique_id`) and publishes it through a key-value store (the
+TCPStore that `torch.distributed.run` sets up is used here; any channel of the host will do).  For rehearsals on
+machines without one GPU per rank, `Comm.with_process_group` plugs a `torch.distributed` group (gloo) into the
+library as a caller-supplied transport (`wf_transport`): partitioning, staging and kernels are the ones RCCL runs
+with, only the bytes travel differently.
 """
 from __future__ import annotations
 
-import torch
-import torch.distributed as dist
+import ctypes as C
+import os
+
+from . import capi
 
 
+# ---- partition rules (wf_shard_*: no device needed) ---------------------------------------------------------------
 def proofs_of_rank(n_proofs: int, rank: int, world: int):
     """Contiguous block partition of proof ids over ranks (first ranks take the remainder)."""
-    base, rem = divmod(n_proofs, world)
-    lo = rank * base + min(rank, rem)
-    return list(range(lo, lo + base + (1 if rank < rem else 0)))
+    first, count = C.c_uint32(), C.c_uint32()
+    capi._check(capi.load().wf_shard_proofs(n_proofs, rank, world, C.byref(first), C.byref(count)))
+    return list(range(first.value, first.value + count.value))
 
 
 def seed_of_proof(base_seed: int, proof_id: int) -> int:
@@ -25,40 +37,191 @@ def seed_of_proof(base_seed: int, proof_id: int) -> int:
 
 def cosets_of_rank(blowup: int, rank: int, world: int):
     """(first coset, count) of a rank when ONE packed commitment is sharded by coset (world must divide blowup)."""
-    if blowup % world:
-        raise ValueError(f"world size {world} must divide the blowup factor {blowup}")
-    per = blowup // world
-    return rank * per, per
+    first, count = C.c_uint32(), C.c_uint32()
+    rc = capi.load().wf_shard_cosets(blowup, rank, world, C.byref(first), C.byref(count))
+    if rc:
+        raise ValueError(capi.load().wf_last_error().decode())
+    return first.value, count.value
 
 
-def interleave_leaf_shards(gathered: torch.Tensor, world: int, trace_len: int, per_rank: int) -> torch.Tensor:
-    """gathered: [world * trace_len * per_rank, 32] digests, rank-major, each shard ordered (k, local coset).
-    Returns the leaves in natural order j = k * blowup + coset, blowup = world * per_rank."""
-    g = gathered.view(world, trace_len, per_rank, 32)
-    return g.permute(1, 0, 2, 3).reshape(world * trace_len * per_rank, 32).contiguous()
+def route(log2_lde_rows: int, blowup: int, world: int, position: int):
+    """(row_rank, row_local, tree_rank, leaf_local) of an LDE row of a sharded commitment (wf_shard_route)."""
+    rr, tr = C.c_uint32(), C.c_uint32()
+    rl, ll = C.c_uint64(), C.c_uint64()
+    capi._check(capi.load().wf_shard_route(log2_lde_rows, blowup, world, position, C.byref(rr), C.byref(rl),
+                                           C.byref(tr), C.byref(ll)))
+    return rr.value, rl.value, tr.value, ll.value
 
 
-def all_gather_leaf_shards(local_leaves: torch.Tensor, trace_len: int, per_rank: int, group=None) -> torch.Tensor:
-    """The one exchange of a coset-sharded commitment: all-gather of the leaf digests (32 B x R x cosets per rank),
-    then interleave to natural order.  local_leaves: uint8 [trace_len * per_rank, 32]."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return local_leaves.clone()
-    world = dist.get_world_size(group)
-    if dist.get_backend(group) != "nccl" and local_leaves.is_cuda:  # gloo rehearsal: collectives on host copies
-        return all_gather_leaf_shards(local_leaves.cpu(), trace_len, per_rank, group).to(local_leaves.device)
-    out = torch.empty((world * local_leaves.shape[0], 32), dtype=torch.uint8, device=local_leaves.device)
-    dist.all_gather_into_tensor(out, local_leaves.contiguous(), group=group)
-    return interleave_leaf_shards(out, world, trace_len, per_rank)
+# ---- rendezvous ---------------------------------------------------------------------------------------------------
+def store_from_env(rank: int, world: int, timeout_s: float = 300.0):
+    """The TCP key-value store at MASTER_ADDR:MASTER_PORT (rank 0 hosts it) -- the env torch.distributed.run sets."""
+    import datetime
+    from torch.distributed import TCPStore
+    # under torch.distributed.run the launcher already hosts the store on MASTER_PORT: every rank is a client then
+    agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "False") == "True"
+    return TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")), world,
+                    rank == 0 and not agent_store, timeout=datetime.timedelta(seconds=timeout_s), wait_for_workers=False)
 
 
-def all_gather_roots(local_roots: torch.Tensor, group=None) -> torch.Tensor:
-    """local_roots: uint8 [k, 32] on this rank's device (k equal on all ranks).  Returns [world*k, 32], rank-major:
-    the one collective of the path."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return local_roots.clone()
-    world = dist.get_world_size(group)
-    if dist.get_backend(group) != "nccl" and local_roots.is_cuda:  # gloo rehearsal: collectives on host copies
-        return all_gather_roots(local_roots.cpu(), group).to(local_roots.device)
-    out = torch.empty((world * local_roots.shape[0], 32), dtype=torch.uint8, device=local_roots.device)
-    dist.all_gather_into_tensor(out, local_roots.contiguous(), group=group)
-    return out
+class Comm:
+    """wf_comm wrapper: one per (context, rank)."""
+
+    def __init__(self, handle, ctx, keep=()):
+        self._h = handle
+        self.ctx = ctx
+        self._keep = keep  # callback objects of a custom transport must outlive the communicator
+        self.rank = capi.load().wf_comm_rank(self._h)
+        self.world = capi.load().wf_comm_world(self._h)
+        self.transport = "transport" if keep else "rccl"
+
+    @classmethod
+    def with_store(cls, ctx, store, rank: int, world: int, key: str = "wf_comm_id"):
+        """RCCL communicator; the unique id travels through `store` (set/get of bytes)."""
+        L = capi.load()
+        if rank == 0:
+            uid = (C.c_uint8 * 128)()
+            capi._check(L.wf_comm_unique_id(uid))
+            store.set(key, bytes(uid))
+        raw = bytes(store.get(key))
+        uid = (C.c_uint8 * 128).from_buffer_copy(raw[:128])
+        h = C.c_void_p()
+        capi._check(L.wf_comm_create(ctx._h, uid, rank, world, C.byref(h)))
+        return cls(h, ctx)
+
+    @classmethod
+    def with_transport(cls, ctx, rank: int, world: int, all_gather, all_to_all):
+        """Caller-supplied transport (wf_transport).  `all_gather(mine)` takes this rank's bytes (numpy uint8 [n]) and
+        returns everybody's, rank-major [world * n]; `all_to_all(mine)` takes [world * n] (block s is for rank s) and
+        returns [world * n] (block s came from rank s).  The device bytes are staged through the host."""
+        cbs = transport_callbacks(world, all_gather, all_to_all)
+        tr = capi.Transport(None, cbs[0], cbs[1])
+        h = C.c_void_p()
+        capi._check(capi.load().wf_comm_create_with_transport(ctx._h, C.byref(tr), rank, world, C.byref(h)))
+        return cls(h, ctx, keep=(cbs, tr))
+
+    @classmethod
+    def with_process_group(cls, ctx, group=None):
+        """The same over a torch.distributed group whose backend handles host tensors (gloo).  Rehearsal / bring-up
+        of the multi-rank control flow on machines without one GPU per rank."""
+        import torch.distributed as dist
+        ag, a2a = process_group_collectives(group)
+        return cls.with_transport(ctx, dist.get_rank(group), dist.get_world_size(group), ag, a2a)
+
+    def close(self):
+        if self._h:
+            capi.load().wf_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- collectives (device pointers: e.g. torch.Tensor.data_ptr()) ---------------------------------------------------
+    def barrier(self):
+        capi._check(capi.load().wf_comm_barrier(self._h))
+
+    def max_f64(self, value: float) -> float:
+        v = C.c_double(value)
+        capi._check(capi.load().wf_comm_max_f64(self._h, C.byref(v)))
+        return v.value
+
+    def all_gather_roots(self, d_roots: int, n_roots: int, d_all: int, stream: int = 0):
+        """The one collective of the independent-proofs sharding: [n_roots][32] per rank -> [world][n_roots][32]."""
+        capi._check(capi.load().wf_comm_all_gather_roots(self._h, d_roots, n_roots, d_all, stream or None))
+
+    def all_gather_leaf_shards(self, d_shard: int, trace_len: int, per_rank: int, d_leaves: int, stream: int = 0):
+        capi._check(capi.load().wf_comm_all_gather_leaf_shards(self._h, d_shard, trace_len, per_rank, d_leaves,
+                                                               stream or None))
+
+    def trace_commit_sharded_dev(self, params, d_trace: int, d_polys: int, d_lde_shard: int, d_leaves: int,
+                                 d_nodes: int, d_top: int, stream: int = 0):
+        capi._check(capi.load().wf_trace_commit_sharded_dev(self._h, C.byref(params), d_trace, d_polys or None,
+                                                            d_lde_shard, d_leaves, d_nodes, d_top, stream or None))
+
+
+def process_group_collectives(group=None):
+    """(all_gather, all_to_all) on numpy byte arrays over a torch.distributed group (host tensors: gloo)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+    def all_gather(mine):
+        out = torch.empty(world * mine.size, dtype=torch.uint8)
+        dist.all_gather_into_tensor(out, torch.from_numpy(np.ascontiguousarray(mine)), group=group)
+        return out.numpy()
+
+    def all_to_all(mine):
+        # gloo has no all_to_all on every build: all-gather everything, keep the blocks addressed to this rank
+        n = mine.size // world
+        return all_gather(mine).reshape(world, world, n)[:, rank, :].reshape(-1)
+
+    return all_gather, all_to_all
+
+
+def transport_callbacks(world: int, all_gather, all_to_all, host_memory: bool = False):
+    """The two C callbacks of a wf_transport around byte-array collectives.  host_memory: the pointers are host
+    pointers (CPU tests of the callbacks themselves); otherwise device pointers, staged with hipMemcpy."""
+    import numpy as np
+
+    def fetch(ptr, n, stream):
+        buf = np.empty(n, dtype=np.uint8)
+        if host_memory:
+            C.memmove(buf.ctypes.data, ptr, n)
+        else:
+            hip = _hip_runtime()
+            _hip_check(hip.hipStreamSynchronize(C.c_void_p(stream)))
+            _hip_check(hip.hipMemcpy(C.c_void_p(buf.ctypes.data), C.c_void_p(ptr), C.c_size_t(n), 2))  # DeviceToHost
+        return buf
+
+    def store(ptr, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.uint8)
+        if host_memory:
+            C.memmove(ptr, arr.ctypes.data, arr.size)
+        else:
+            _hip_check(_hip_runtime().hipMemcpy(C.c_void_p(ptr), C.c_void_p(arr.ctypes.data), C.c_size_t(arr.size), 1))  # HostToDevice
+
+    def cb_all_gather(_user, d_send, d_recv, nbytes, stream):
+        try:  # never let an exception cross the C boundary
+            out = all_gather(fetch(d_send, nbytes, stream))
+            assert out.size == world * nbytes
+            store(d_recv, out)
+            return 0
+        except Exception as e:
+            print("wf_transport.all_gather:", repr(e), flush=True)
+            return 1
+
+    def cb_all_to_all(_user, d_send, d_recv, nbytes, stream):
+        try:
+            out = all_to_all(fetch(d_send, world * nbytes, stream))
+            assert out.size == world * nbytes
+            store(d_recv, out)
+            return 0
+        except Exception as e:
+            print("wf_transport.all_to_all:", repr(e), flush=True)
+            return 1
+
+    return capi.TRANSPORT_FN(cb_all_gather), capi.TRANSPORT_FN(cb_all_to_all)
+
+
+_hip = None
+
+
+def _hip_runtime():
+    """The HIP runtime this process already holds (libwf_lde.so is linked against it), for the staging copies of the
+    rehearsal transport."""
+    global _hip
+    if _hip is None:
+        capi.load()
+        _hip = C.CDLL("libamdhip64.so.7")
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    return _hip
+
+
+def _hip_check(rc: int):
+    if rc != 0:
+        raise RuntimeError(f"HIP runtime call failed with {rc}")

@@ -1,0 +1,65 @@
+"""bench.py --gpus N as a PLAIN command: the parent starts the ranks (torch.distributed.run as a child) before it touches
+the GPU and passes their JSON line and exit code through.
+
+CPU: without a GPU the ranks must fail loudly (no CPU fallback) and the launcher must report it.
+GPU: two ranks sharing the one device of the test box, WF_BENCH_BACKEND=gloo (RCCL refuses two ranks on one device):
+the multi-rank control flow, the wf_comm calls and both sharding modes run end to end."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_USE_AGENT_STORE"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True,
+                          text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_plain_multi_gpu_command_starts_ranks_and_fails_loudly_without_gpus(capi):
+    if capi.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    out = run_bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert out.returncode != 0
+    assert "must be launched with" not in out.stderr + out.stdout      # the round-1 refusal is gone
+    assert "torch.distributed" in out.stderr or "ChildFailedError" in out.stderr, out.stderr[-2000:]
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]  # no number without a GPU
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["proofs", "packed"])
+def test_two_ranks_on_one_device_gloo_rehearsal(capi, mode):
+    capi.load()
+    out = run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--mode", mode, "--no-cpu-baseline",
+                    env_extra={"WF_BENCH_BACKEND": "gloo"})
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                              # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["config"]["mode"] == mode
+    assert j["scaling"] == ("weak" if mode == "proofs" else "strong")
+    assert j["roots_gathered"] == (4 if mode == "proofs" else 2)
+    assert "gloo" in j["collective"]["transport"]
+    assert j["value"] > 0 and j["ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_packed_mode_single_gpu_root_matches_sharded(capi):
+    """The packed workload on one rank (plain wf_trace_commit_dev) and on two (wf_trace_commit_sharded_dev) commit the
+    same traces: the roots must agree."""
+    capi.load()
+    one = run_bench("--gpus", "1", "--steps", "1", "--warmup", "1", "--mode", "packed", "--no-cpu-baseline")
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+    two = run_bench("--gpus", "2", "--steps", "1", "--warmup", "1", "--mode", "packed", "--no-cpu-baseline",
+                    env_extra={"WF_BENCH_BACKEND": "gloo"})
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
+    r1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])["root"]
+    r2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])["root"]
+    assert r1 == r2

@@ -1,6 +1,8 @@
 """GPU: one packed (STARKPack) commitment sharded by coset, as W ranks would compute it.
-All "ranks" run one after the other on the single test GPU; the exchange step is the same code the multi-GPU path
-uses (shard.interleave_leaf_shards), so the result must equal the unsharded commitment bit for bit."""
+All "ranks" run one after the other on the single test GPU (the replicated-tree form: wf_trace_commit_shard_dev per
+rank, leaf shards concatenated rank-major as an all-gather returns them, reordered, wf_merkle_build_dev); the result
+must equal the unsharded commitment bit for bit.  The exchange itself and the distributed-tree form
+(wf_trace_commit_sharded_dev) run with real ranks in tests/test_gpu_comm.py."""
 import numpy as np
 import pytest
 
@@ -49,7 +51,8 @@ def test_coset_sharded_commitment(ctx, orc, capi, field, logR, logB, n_cols, n_t
                 assert np.array_equal(lde[t], full[:, c0:c0 + nc])
             shards.append(d_leaves)
         gathered = torch.cat(shards, dim=0)          # what all_gather_into_tensor returns (rank-major)
-        leaves = shard.interleave_leaf_shards(gathered, world, R, blowup // world)
+        per = blowup // world                        # natural order j = k * blowup + rank * per + local coset
+        leaves = gathered.view(world, R, per, 32).permute(1, 0, 2, 3).reshape(R * blowup, 32).contiguous()
         nodes = torch.empty_like(leaves)
         ctx.merkle_build_dev(leaves.data_ptr(), R * blowup, nodes.data_ptr(), stream.cuda_stream)
         torch.cuda.synchronize()

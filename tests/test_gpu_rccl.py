@@ -1,6 +1,5 @@
-"""GPU: the RCCL leg of the multi-GPU helpers on the one device this box has -- a world of one rank over the "nccl"
-backend (= RCCL on ROCm): communicator creation, the uint8 all-gathers `shard.py` issues, and bench.py's
-distributed control flow.  The N > 1 exchange itself is covered by the gloo tests (tests/test_shard_gloo.py)."""
+"""GPU: sanity of the box's RCCL through torch.distributed ("nccl" backend, a world of one) next to the library's own
+RCCL binding (tests/test_gpu_comm.py), and bench.py's line contract."""
 import json
 import os
 import socket
@@ -14,18 +13,13 @@ pytestmark = pytest.mark.gpu
 
 SCRIPT = r"""
 import os, sys, torch, torch.distributed as dist
-sys.path.insert(0, os.environ["WF_ROOT"])
-from starkpack_winterfell_amd import shard
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", device_id=dev)
 x = torch.arange(3 * 32, dtype=torch.uint8, device=dev).reshape(3, 32)
 out = torch.empty((3, 32), dtype=torch.uint8, device=dev)
-dist.all_gather_into_tensor(out, x)          # the call shard.all_gather_roots makes for world > 1
+dist.all_gather_into_tensor(out, x)
 assert torch.equal(out, x)
-leaves = torch.arange(8 * 32, dtype=torch.uint8, device=dev).reshape(8, 32)
-full = shard.all_gather_leaf_shards(leaves, 8, 1)
-assert torch.equal(full, leaves)
 t = torch.tensor([1.5], dtype=torch.float64, device=dev)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 dist.barrier()
