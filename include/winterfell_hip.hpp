@@ -358,7 +358,8 @@ class TraceCommitment {
         size_t n_vec = 0, n_nodes = 0;
         uint32_t d = 0;
         // rows and proof in one host round trip
-        wf_check(wf_commitment_query(h_, pos.data(), n, flat.data(), proof.leaves[0].data(), nodes[0].data(), nodes.size(),
+        // (no positions: the library reports the reference's TooFewLeafIndexes; nothing is dereferenced here)
+        wf_check(wf_commitment_query(h_, pos.data(), n, flat.data(), n ? proof.leaves[0].data() : nullptr, n ? nodes[0].data() : nullptr, nodes.size(),
                                      counts.data(), &n_vec, &n_nodes, &d));
         std::vector<std::vector<typename E::BaseField>> rows;
         for (size_t i = 0; i < n; i++) rows.emplace_back(flat.begin() + i * row_elems, flat.begin() + (i + 1) * row_elems);
@@ -505,7 +506,7 @@ class FriProver {
             std::vector<uint32_t> counts(m);
             size_t n_vec = 0, n_nodes = 0;
             uint32_t d = 0;
-            wf_check(wf_commitment_query(layer, folded.data(), m, flat.data(), pl.proof.leaves[0].data(), nodes[0].data(),
+            wf_check(wf_commitment_query(layer, folded.data(), m, flat.data(), m ? pl.proof.leaves[0].data() : nullptr, m ? nodes[0].data() : nullptr,
                                          nodes.size(), counts.data(), &n_vec, &n_nodes, &d));
             for (size_t j = 0; j < m; j++) pl.values.emplace_back(flat.begin() + j * words, flat.begin() + (j + 1) * words);
             size_t k = 0;

@@ -2244,14 +2244,23 @@ static int fri_prover_begin(wf_fri_prover *pr, const void *src, size_t n, bool o
     if (l > (pr->field == WF_FIELD_F64 ? F64::TWO_ADICITY : F128::TWO_ADICITY))
         return fail(WF_ERR_DOMAIN, "no multiplicative subgroup of size 2^%u in this field", l);
     HIP_TRY(hipSetDevice(pr->ctx->device));
-    WF_ENTER(pr->ctx, pr->ctx->stream);
+    WF_ENTER(pr->ctx, st);
     const size_t bytes = n * pr->ext * wf_elem_bytes(pr->field);
     int rca = fri_arena_reserve(pr, n);
     if (rca) return rca;
-    HIP_TRY(hipMalloc(&pr->evals, bytes));
+    hipError_t e = dev_malloc(pr->ctx, &pr->evals, bytes);
+    if (e != hipSuccess) {
+        pr->evals = nullptr;
+        return fail(WF_ERR_HIP, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    }
     pr->evals_borrowed = false;
-    HIP_TRY(hipMemcpyAsync(pr->evals, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    e = hipMemcpyAsync(pr->evals, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {  // leave the prover as it was: no half-started proof
+        (void)hipFree(pr->evals);
+        pr->evals = nullptr;
+        return fail(WF_ERR_HIP, "copying the evaluations failed: %s", hipGetErrorString(e));
+    }
     pr->n = n;
     return 0;
 }
@@ -2291,7 +2300,13 @@ int wf_fri_prover_begin_poly(wf_fri_prover *pr, const void *poly, size_t n, size
     const bool dense = pr->field == WF_FIELD_F64 ? dense_column_ok<F64>(&p) : dense_column_ok<F128>(&p);
     if (!dense && (rc = ensure(ctx, ctx->io[2], wf_lde_bytes(&p)))) return rc;
     if ((rc = fri_arena_reserve(pr, rows))) return rc;
-    HIP_TRY(hipMalloc(&pr->evals, rows * pr->ext * eb));
+    {
+        hipError_t e = dev_malloc(ctx, &pr->evals, rows * pr->ext * eb);
+        if (e != hipSuccess) {
+            pr->evals = nullptr;
+            return fail(WF_ERR_HIP, "hipMalloc of %zu bytes failed: %s", rows * pr->ext * eb, hipGetErrorString(e));
+        }
+    }
     pr->evals_borrowed = false;
     hipStream_t st = ctx->stream;
     rc = hipMemcpyAsync(ctx->io[0].p, poly, wf_column_bytes(&p), hipMemcpyHostToDevice, st) == hipSuccess ? 0 : fail(WF_ERR_HIP, "upload failed");
@@ -2346,9 +2361,9 @@ int wf_fri_prover_commit_layer(wf_fri_prover *pr, uint8_t root_out[32]) {
     if (!c->borrowed) {  // (arena too small: cannot happen after fri_arena_reserve, kept as a fallback)
         pr->arena_used = used0;
         c->lde = c->leaves = c->nodes = nullptr;
-        hipError_t e = hipMalloc(&c->lde, pr->n * pr->ext * eb);
-        if (e == hipSuccess) e = hipMalloc(&c->leaves, rows * 32);
-        if (e == hipSuccess) e = hipMalloc(&c->nodes, rows * 32);
+        hipError_t e = dev_malloc(ctx, &c->lde, pr->n * pr->ext * eb);
+        if (e == hipSuccess) e = dev_malloc(ctx, &c->leaves, rows * 32);
+        if (e == hipSuccess) e = dev_malloc(ctx, &c->nodes, rows * 32);
         if (e != hipSuccess) {
             free_commitment(c);
             return fail(WF_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
@@ -2379,7 +2394,8 @@ int wf_fri_prover_fold(wf_fri_prover *pr, const void *alpha) {
     const size_t rows = pr->n / pr->folding;
     void *next = fri_arena_take(pr, rows * pr->ext * wf_elem_bytes(pr->field));
     const bool next_borrowed = next != nullptr;
-    if (!next) HIP_TRY(hipMalloc(&next, rows * pr->ext * wf_elem_bytes(pr->field)));
+    if (!next && dev_malloc(ctx, &next, rows * pr->ext * wf_elem_bytes(pr->field)) != hipSuccess)
+        return fail(WF_ERR_HIP, "hipMalloc failed for the folded layer");
     hipStream_t st = ctx->stream;
     // (asynchronous: the folded layer is consumed by the next call on the same stream; alpha is copied at launch)
     int rc = pr->field == WF_FIELD_F64
