@@ -13,8 +13,21 @@ When the leaves are hashed inside the last evaluation pass (one segment, one tra
 entry is zero and the evaluate entry carries the 256 MiB of leaf writes."""
 import collections
 import csv
+import hashlib
 import json
+import os
 import sys
+
+
+def csrc_sha():
+    """As bench.py: the digest of the kernel sources the counters were collected on."""
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "starkpack-winterfell_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 LOGICAL = [
     ("interpolate", ["k_cols_to_seg", "k_seg_strided<wf::F64, 0,", "k_seg_last<wf::F64, 0,", "k_seg_to_cols"]),
@@ -40,7 +53,7 @@ def main():
     write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
     steps = fcalls[next(k for k in fcalls if "k_cols_to_seg" in k)]  # one launch per commitment
     out = {"_note": "HBM bytes per commitment (cfg 2) from rocprofv3 PMC; see scripts/traffic_from_pmc.py for the "
-                    "gfx950 corrections", "_round": sys.argv[3], "_steps_profiled": steps}
+                    "gfx950 corrections", "_round": sys.argv[3], "_steps_profiled": steps, "_csrc_sha": csrc_sha()}
     for name, pats in LOGICAL:
         rd = wr = 0.0
         for k in fetch:

@@ -49,3 +49,29 @@ def test_blake3_golden_through_hash_rows(ctx, capi):
     m = g["merge"]
     two = np.frombuffer(bytes.fromhex(m["left"]) + bytes.fromhex(m["right"]), dtype=np.uint8).reshape(2, 32)
     assert bytes(ctx.merkle_build(two)[1]).hex() == m["digest"]
+
+
+def test_reference_literal_inputs_golden(ctx, capi):
+    """The reference's own literal test inputs through the HIP path: LEAVES4 / LEAVES8 (crypto/src/merkle/tests.rs:13-65)
+    -> wf_merkle_build and resident proofs; the FRI test polynomial (fri/src/prover/tests.rs:58-69) -> wf_fft_evaluate_poly
+    and the first layer commitment.  Expected values: tests/golden/reference_inputs.json (see tests/golden/README.md)."""
+    g = G.load("reference_inputs.json")
+    for t in g["trees"]:
+        leaves = np.frombuffer(b"".join(bytes.fromhex(x) for x in t["leaves"]), dtype=np.uint8).reshape(-1, 32)
+        nodes = ctx.merkle_build(leaves)
+        assert G.hexrows(nodes) == t["nodes"] and bytes(nodes[1]).hex() == t["root"]
+    f = g["fri"]
+    tl, blowup, folding = f["trace_length"], f["lde_blowup"], f["folding"]
+    n = tl * blowup
+    p = np.zeros((n, 2), dtype=np.uint64)
+    p[:tl, 0] = np.arange(tl, dtype=np.uint64)
+    ev = ctx.fft_evaluate_poly(capi.F128, 1, p.reshape(-1))
+    want = G.to_mem("f128", f["evaluations"])
+    assert np.array_equal(ev.reshape(-1, 2), want)
+    layer = ctx.fri_layer_commit(capi.F128, 1, ev, folding)
+    assert np.array_equal(layer["transposed"].reshape(-1, 2), G.to_mem("f128", [v for r in f["transposed"] for v in r]))
+    assert G.hexrows(layer["leaves"]) == f["leaves"] and layer["root"].hex() == f["root"]
+    pr = capi.FriProver(ctx, capi.F128, 1, folding, blowup, 7, 3)
+    pr.begin(ev)
+    assert pr.commit_layer().hex() == f["root"]
+    pr.close()

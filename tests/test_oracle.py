@@ -311,3 +311,36 @@ def test_extension_products(orc):
     r = mem([5, 9])
     assert np.array_equal(orc.ext_mul(F64, 2, r, mem([1, 0])), r)
     assert not orc.ext_mul(F64, 2, r, mem([0, 0])).any()
+
+
+# ------------------------------------------------------------------------------------ golden: the reference's own inputs
+def test_reference_literal_inputs_golden(orc):
+    """LEAVES4 / LEAVES8 of crypto/src/merkle/tests.rs:13-65 and the polynomial of fri/src/prover/tests.rs:58-69 as
+    inputs; expected values from Python big integers + the official BLAKE3 (tests/golden/README.md)."""
+    g = G.load("reference_inputs.json")
+    for t in g["trees"]:
+        leaves = np.frombuffer(b"".join(bytes.fromhex(x) for x in t["leaves"]), dtype=np.uint8).reshape(-1, 32)
+        nodes = orc.build_merkle_nodes(leaves)
+        assert G.hexrows(nodes) == t["nodes"] and bytes(nodes[1]).hex() == t["root"]
+        n = len(t["leaves"])
+        # the structure the reference's new_tree test asserts (tests.rs:67-92): root = nested hash_2x1
+        lv = [bytes.fromhex(x) for x in t["leaves"]]
+        level = lv
+        while len(level) > 1:
+            level = [orc.merge(level[2 * i], level[2 * i + 1]) for i in range(len(level) // 2)]
+        assert level[0].hex() == t["root"]
+        for idx in range(n):                                   # prove (tests.rs:94-135) and verify
+            proof = orc.merkle_prove(nodes, leaves, idx)
+            assert [x.hex() for x in proof] == t["proofs"][str(idx)]
+            assert orc.merkle_verify(bytes(nodes[1]), idx, proof)
+    f = g["fri"]
+    tl, blowup, folding = f["trace_length"], f["lde_blowup"], f["folding"]
+    n = tl * blowup
+    p = np.zeros((n, 2), dtype=np.uint64)
+    p[:tl, 0] = np.arange(tl, dtype=np.uint64)                  # build_evaluations: coefficients 0..trace_length-1
+    ev = p.reshape(-1).copy()
+    orc.evaluate_poly(orc.F128, ev, n, 1, orc.get_twiddles(orc.F128, n))
+    assert orc.f128_to_ints(ev.reshape(-1, 2)) == [int(v) for v in f["evaluations"]]
+    layer = orc.fri_layer_commit(orc.F128, ev, n, 1, folding)
+    assert orc.f128_to_ints(layer["transposed"].reshape(-1, 2)) == [int(v) for r in f["transposed"] for v in r]
+    assert G.hexrows(layer["leaves"]) == f["leaves"] and layer["root"].hex() == f["root"]
