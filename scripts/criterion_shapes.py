@@ -28,18 +28,22 @@ def say(s):
     out.flush()
 
 
+stream = torch.cuda.Stream(device=dev)  # the launches and the events that bracket them share this stream
+
+
 def dev_time(fn, reps=7, warm=2):
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        fn()
-        e1.record()
+    with torch.cuda.stream(stream):
+        for _ in range(warm):
+            fn()
         torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            fn()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
     return sorted(ts)[len(ts) // 2]
 
 
@@ -62,7 +66,6 @@ def rand_dev(n):
 
 say("# reference criterion shapes on one MI355X (scripts/criterion_shapes.py)")
 say("# prover/benches/row_matrix.rs matrix_evaluate_matrix (RowMatrix::evaluate_polys::<8>), 2^19 rows, f64, device-resident")
-stream = torch.cuda.current_stream()
 for n_poly in (32, 64, 96):
     polys = rand_dev(n_poly << 19)
     for blowup in (2, 4, 8):

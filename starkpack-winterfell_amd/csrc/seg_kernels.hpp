@@ -88,6 +88,17 @@ __device__ __forceinline__ Pair<U128> pair_from<F128>(const uint4 &qa, const uin
 
 enum : int { SEG_OUT_SEG = 0, SEG_OUT_ROWS = 1 };
 
+// Tile-size specialisation of the pass kernels: LOGD != 0 instantiates a kernel for tiles of exactly 2^LOGD rows run by
+// 2^(LOGD-1) threads (what the launcher uses for that tile size).  Digit, round and work-item loops then have constant
+// trip counts, LDS offsets become instruction immediates and the index arithmetic of every round folds away; LOGD == 0
+// is the generic kernel (any tile size).  Same arithmetic, same outputs.
+template <int LOGD>
+__device__ __forceinline__ uint32_t tile_threads() {
+    return LOGD ? (1u << (LOGD ? LOGD - 1 : 0)) : blockDim.x;
+}
+// (second argument: waves per SIMD the register allocation must allow -- two 512-thread work-groups per CU = 4)
+#define WF_TILE_BOUNDS(LOGD, GENERIC) __launch_bounds__((LOGD) ? (1 << ((LOGD) ? (LOGD) - 1 : 0)) : (GENERIC), (LOGD) ? 4 : 1)
+
 // Work-groups are dispatched to the 8 XCDs round-robin (blockIdx % 8), each XCD with its own L2.  This maps blockIdx
 // to a logical index such that 8 consecutive logical indices run back to back on ONE XCD: the kernels make those the
 // work-groups that write neighbouring 64-byte pieces of the same 512 bytes (adjacent inner positions of a strided pass,
@@ -252,8 +263,9 @@ __device__ __forceinline__ void radix16(typename F::T (&v)[16], const typename F
 // `first` != nullptr: the first radix-16 round takes its 16 inputs from there instead of LDS -- the pass kernels load
 // them straight from global memory (work item wk = threadIdx.x: lane wk % S of rows a * D/16 + wk / S, a = 0..15;
 // needs logD >= 4, RADIX16 and blockDim >= D/2), which saves the tile's trip through LDS before the first round.
+// `nthr` = blockDim.x, passed in so that the tile-size-specialised kernels (LOGD != 0, below) make it a constant.
 template <class F, int DIR = 0>
-__device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::T *twd, uint32_t logD,
+__device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::T *twd, uint32_t logD, uint32_t nthr,
                                             const typename F::T *first = nullptr) {
     typedef typename F::T T;
     typedef Pair<T> P2;
@@ -271,7 +283,7 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
             const uint32_t nwork = (D >> 4) * S;
             const uint32_t tshift = logD - cur;
             const uint32_t st = m * S;
-            for (uint32_t wk = threadIdx.x; wk < nwork; wk += blockDim.x) {
+            for (uint32_t wk = threadIdx.x; wk < nwork; wk += nthr) {
                 const uint32_t l = wk & (S - 1), u = wk >> s_shift;
                 const uint32_t jp = u & (m - 1), p = u >> mlog;
                 const uint32_t base = (((p << cur) + jp) * S) + l;
@@ -304,7 +316,7 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
             const uint32_t nwork = (D >> 2) * HP;
             const uint32_t tshift = logD - cur;
             const uint32_t st = m * S;
-            for (uint32_t wk = threadIdx.x; wk < nwork; wk += blockDim.x) {
+            for (uint32_t wk = threadIdx.x; wk < nwork; wk += nthr) {
                 const uint32_t lp = wk & (HP - 1), u = wk >> hp_shift;
                 const uint32_t jp = u & (m - 1), p = u >> mlog;
                 const uint32_t base = (((p << cur) + jp) * S) + 2 * lp;
@@ -347,7 +359,7 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
             cur -= 2;
         } else {
             const uint32_t nwork = (D >> 1) * HP;
-            for (uint32_t wk = threadIdx.x; wk < nwork; wk += blockDim.x) {
+            for (uint32_t wk = threadIdx.x; wk < nwork; wk += nthr) {
                 const uint32_t lp = wk & (HP - 1), u = wk >> hp_shift;
                 const uint32_t base = (u << 1) * S + 2 * lp;
                 P2 x0 = *reinterpret_cast<P2 *>(x + base);
@@ -370,9 +382,11 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
 // Strided pass.  grid.x = n_cosets * n_seg * O * I ; work-group = (coset c, segment g, outer o, inner i)
 // EVAL = 0: interpolation (inverse transform), 1: coset evaluation (forward transform); like k_seg_last<F, OUT> the two
 // uses appear under different kernel names in profiles, and the direction selects the shift twiddles of radix16.
-template <class F, int EVAL, bool PACKED = false>
-__global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
+template <class F, int EVAL, bool PACKED = false, int LOGD = 0>
+__global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_strided(SegArgs<F> a) {
     typedef typename F::T T;
+    if (LOGD) a.logD = LOGD;
+    const uint32_t NT = tile_threads<LOGD>();
     typedef Pair<T> P2;
     constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;
     constexpr uint32_t hp_shift = HP == 4 ? 2 : 1;
@@ -415,7 +429,7 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
     // The first LOAD_BATCH row pieces of every thread (the whole tile up to D = 2^10) are requested before the tables
     // are built, so that their latency runs under the table arithmetic.  The rows are I apart: every load is its own
     // 64-byte gather, the load phase lives on memory-level parallelism.
-    const uint32_t step = blockDim.x;
+    const uint32_t step = NT;
     const bool from_regs = !(PACKED && a.pre_on);
     // ---- prologue: every global read of the tile's setup is issued before the first one is used -- the operands of the
     // output factors start * (w_N^(i * N/(D*I)))^k (start = h_c^i for an evaluation, 1/n for an interpolation), the digit
@@ -429,7 +443,7 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
     T fo_a[2], fo_b[2], tw_q[2], fi_a[2], fi_b[2];
 #pragma unroll
     for (uint32_t q = 0; q < 2; q++) {
-        const uint32_t k = threadIdx.x + q * blockDim.x;
+        const uint32_t k = threadIdx.x + q * NT;
         kq[q] = k < D ? k : D - 1;
         a.tw.fetch(((uint64_t)kq[q] * i) << tw_shift, fo_a[q], fo_b[q]);
         tw_q[q] = a.digit_tw[kq[q]];
@@ -503,7 +517,7 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
             T f = F::mul(fo_a[q], fo_b[q]);
             if (!trivial) f = F::mul(f, start);
             fo[q] = f;
-            if (threadIdx.x + q * blockDim.x < D) {
+            if (threadIdx.x + q * NT < D) {
                 twd[kq[q]] = tw_q[q];
                 if (scale_in) aux[kq[q]] = F::mul(fi_a[q], fi_b[q]);  // h_c^(d*I); h_c^i goes into the output factors
             }
@@ -517,7 +531,7 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
             for (uint32_t q = 0; q < 16; q++) vr[q] = F::mul(vr[q], aux[q * m16 + j16]);
         }
     } else if (PACKED && a.pre_on) {  // replicate the polynomial's lanes into every coset group of the row
-        for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
+        for (uint32_t wk = threadIdx.x; wk < nitems; wk += NT) {
             const uint32_t lp = wk & (HP - 1), d = wk >> hp_shift;
             P2 v;
             const uint32_t lgm = (1u << a.lg_log) - 1, cola = lane_a & lgm, colb = lane_b & lgm;
@@ -565,11 +579,11 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
     // `aux` now takes the output factors (visible after the transform's barriers)
 #pragma unroll
     for (uint32_t q = 0; q < 2; q++) {
-        const uint32_t k = threadIdx.x + q * blockDim.x;
+        const uint32_t k = threadIdx.x + q * NT;
         if (k < D) aux[k] = fo[q];
     }
 #ifndef WF_EXP_SKIP_NTT  // tuning experiment: memory phases only (scripts/exp_variants.sh)
-    seg_lds_ntt<F, EVAL ? 1 : -1>(x, twd, a.logD, direct ? vr : nullptr);
+    seg_lds_ntt<F, EVAL ? 1 : -1>(x, twd, a.logD, NT, direct ? vr : nullptr);
 #else
     if (direct && has16) {
 #pragma unroll
@@ -584,7 +598,7 @@ __global__ void __launch_bounds__(1024) k_seg_strided(SegArgs<F> a) {
         start_b = pre_b.get(i);
     }
     // this thread's row positions are pos0 + j * pstride (see k_seg_last): rev(pos) = rev(pos0) | rev(j * pstride)
-    const uint32_t pstride = blockDim.x >> hp_shift, pos0 = threadIdx.x >> hp_shift;
+    const uint32_t pstride = NT >> hp_shift, pos0 = threadIdx.x >> hp_shift;
     if (pos0 >= D) return;
     const uint32_t k0 = seg_digit_reverse<F>(pos0, a.logD);
     T *dst_lane = dst + row0 * S + lane_a;
@@ -673,9 +687,11 @@ __device__ __forceinline__ void store_rows_narrow(const typename F::T *x, const 
 
 // ---------------------------------------------------------------------------------------------------------------
 // Last pass.  grid.x = n_cosets * n_seg * O ; work-group = (coset c, segment g, row block o) of D contiguous rows.
-template <class F, int OUT, bool PACKED = false>
-__global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
+template <class F, int OUT, bool PACKED = false, int LOGD = 0>
+__global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
     typedef typename F::T T;
+    if (LOGD) a.logD = LOGD;
+    const uint32_t NT = tile_threads<LOGD>();
     typedef Pair<T> P2;
     constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;
     constexpr uint32_t hp_shift = HP == 4 ? 2 : 1;
@@ -726,7 +742,7 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
     const uint32_t nitems = D * HP;
     // prologue as in k_seg_strided: the digit twiddles, the operands of the input factors (single-pass evaluation only)
     // and the tile's rows are all requested before the first of them is used
-    const uint32_t step = blockDim.x;
+    const uint32_t step = NT;
     const bool from_regs = !(PACKED && a.pre_on);
     const bool scale_in = !PACKED && a.pre_on;
     const Pow2L<F> pin = scale_in ? pre : a.tw;
@@ -734,7 +750,7 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
     T tw_q[2], fi_a[2], fi_b[2];
 #pragma unroll
     for (uint32_t q = 0; q < 2; q++) {
-        const uint32_t k = threadIdx.x + q * blockDim.x;  // blockDim >= D / 2
+        const uint32_t k = threadIdx.x + q * NT;  // blockDim >= D / 2
         kq[q] = k < D ? k : D - 1;
         tw_q[q] = a.digit_tw[kq[q]];
         pin.fetch(kq[q], fi_a[q], fi_b[q]);  // single-pass evaluation: row index = coefficient index
@@ -779,7 +795,7 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
 #undef WF_ITEM_PTR
 #pragma unroll
     for (uint32_t q = 0; q < 2; q++) {
-        if (threadIdx.x + q * blockDim.x < D) {
+        if (threadIdx.x + q * NT < D) {
             if (scale_in)
                 aux[kq[q]] = F::mul(fi_a[q], fi_b[q]);  // (in the twiddles' place until the tile is filled)
             else
@@ -788,7 +804,7 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
     }
     __syncthreads();
     if (PACKED && a.pre_on) {  // single pass: replicate the polynomial row into the coset groups, scaled per lane
-        for (uint32_t wk = threadIdx.x; wk < nitems; wk += blockDim.x) {
+        for (uint32_t wk = threadIdx.x; wk < nitems; wk += NT) {
             P2 v;
             const uint32_t d = wk >> hp_shift;
             const uint32_t lgm = (1u << a.lg_log) - 1, cola = lane_a & lgm, colb = lane_b & lgm;
@@ -834,11 +850,11 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
         __syncthreads();
 #pragma unroll
         for (uint32_t q = 0; q < 2; q++)
-            if (threadIdx.x + q * blockDim.x < D) twd[kq[q]] = tw_q[q];
+            if (threadIdx.x + q * NT < D) twd[kq[q]] = tw_q[q];
     }
     __syncthreads();
 #ifndef WF_EXP_SKIP_NTT
-    seg_lds_ntt<F, OUT == SEG_OUT_ROWS ? 1 : -1>(x, twd, a.logD);
+    seg_lds_ntt<F, OUT == SEG_OUT_ROWS ? 1 : -1>(x, twd, a.logD, NT);
 #endif
 
     // Store.  Work item = (row position pos, lane pair); this thread's positions are pos0 + j * pstride, j = 0, 1, ..
@@ -846,7 +862,7 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
     // part is computed once, the per-iteration part is wave-uniform (scalar ALU), and everything that depends only on
     // the lane (column, trace, destination base) is hoisted out of the loop.
     const uint32_t out_shift = a.logN - a.logD;
-    const uint32_t pstride = blockDim.x >> hp_shift, pos0 = threadIdx.x >> hp_shift;
+    const uint32_t pstride = NT >> hp_shift, pos0 = threadIdx.x >> hp_shift;
     const uint32_t k0 = seg_digit_reverse<F>(pos0 < D ? pos0 : 0, a.logD);
     const bool has_rows = pos0 < D;  // more threads than work items in tiny transforms
     if (OUT == SEG_OUT_SEG) {
@@ -896,10 +912,10 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
         }
         if (!has_rows) pa = pb = pz = pz2 = nullptr;
         if (!PACKED && a.pad_traces && (a.row_width == 8 || (F::BYTES == 8 && a.row_width == 16 && a.store_cols <= 10))) {
-            store_rows_narrow<F>(x, a, g, c, rev_o, out_shift, k_stride, threadIdx.x, blockDim.x);
+            store_rows_narrow<F>(x, a, g, c, rev_o, out_shift, k_stride, threadIdx.x, NT);
             pa = pb = nullptr;
         } else if (!PACKED && F::BYTES == 16) {
-            store_rows_by_element<F>(x, a, g, c, rev_o, out_shift, k_stride, threadIdx.x, blockDim.x,
+            store_rows_by_element<F>(x, a, g, c, rev_o, out_shift, k_stride, threadIdx.x, NT,
                                      a.tail_pad && g + 1 == a.n_seg, a.pad_traces);
             pa = pb = nullptr;
         }
@@ -913,7 +929,7 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
             constexpr uint32_t EPU = 16 / F::BYTES;                   // elements per 16-byte unit: 2 (f64) or 1 (f128)
             const uint32_t upr = (uint32_t)a.row_width / EPU;          // units per row: 4 (f64) or 8 (f128) -- a power of two
             const uint32_t n_items = (D << cpr) * upr;
-            for (uint32_t idx = threadIdx.x; idx < n_items; idx += blockDim.x) {
+            for (uint32_t idx = threadIdx.x; idx < n_items; idx += NT) {
                 const uint32_t u = idx & (upr - 1), rj = idx / upr, j = rj & ((1u << cpr) - 1), pos = rj >> cpr;
                 const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << out_shift);
                 T *row = a.dst + (uint64_t)(uint32_t)k * k_stride + (((uint64_t)c << cpr) + j) * a.row_width + EPU * u;
@@ -957,7 +973,7 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
         // like the rest of the 64-byte block, are zero)
         constexpr uint32_t WPE = F::BYTES / 4;
         const uint32_t lg = a.lg_log, ncos = 1u << a.cpr_log;
-        for (uint32_t pos = threadIdx.x; pos < D; pos += blockDim.x) {
+        for (uint32_t pos = threadIdx.x; pos < D; pos += NT) {
             const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << (a.logN - a.logD));
             uint32_t *leaf = a.leaves + ((uint64_t)(uint32_t)k * a.rows_per_k + ((uint64_t)c << a.cpr_log)) * 8;
 #pragma unroll 1
@@ -982,7 +998,7 @@ __global__ void __launch_bounds__(1024) k_seg_last(SegArgs<F> a) {
     }
     if (OUT == SEG_OUT_ROWS && !PACKED && a.leaves) {
         constexpr uint32_t WPE = F::BYTES / 4;
-        for (uint32_t pos = threadIdx.x; pos < D; pos += blockDim.x) {
+        for (uint32_t pos = threadIdx.x; pos < D; pos += NT) {
             T ev[S];
             uint4 *evq = reinterpret_cast<uint4 *>(ev);
             const uint4 *q = reinterpret_cast<const uint4 *>(x + (size_t)pos * S);
@@ -1026,9 +1042,11 @@ __device__ __forceinline__ uint32_t opaque_tid() {
 // 16 segments of that chunk and writes the rows' chunk chaining values; k_hash_merge_chunks folds them into the leaves.
 // SMALL: tiles of at most 2^9 rows (<= 256 threads): compiled without the 128-VGPR cap that 1024-thread work-groups impose
 // (the multi-segment variants spill a few registers under it)
-template <class F, bool MULTI, bool PADT = false, bool CHUNKED = false, bool SMALL = false>  // PADT: SegArgs::pad_traces (kept out of the other instantiations' registers)
-__global__ void __launch_bounds__(SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512)) k_seg_last_hash(SegArgs<F> a) {  // f128 tiles: D <= 2^10
+template <class F, bool MULTI, bool PADT = false, bool CHUNKED = false, bool SMALL = false, int LOGD = 0>  // PADT: SegArgs::pad_traces (kept out of the other instantiations' registers)
+__global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512)) k_seg_last_hash(SegArgs<F> a) {  // f128 tiles: D <= 2^10
     typedef typename F::T T;
+    if (LOGD) a.logD = LOGD;
+    const uint32_t NT = tile_threads<LOGD>();
     typedef Pair<T> P2;
     constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;
     constexpr uint32_t hp_shift = HP == 4 ? 2 : 1;
@@ -1040,7 +1058,7 @@ __global__ void __launch_bounds__(SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512)) k_
     const uint32_t n_chunks = CHUNKED ? a.n_chunks : 1;
     const uint64_t total = (uint64_t)a.n_cosets * a.O * n_chunks;  // tickets: (coset, row block[, chunk])
     const uint64_t seg_elems = ((uint64_t)1 << a.logN) * S;
-    const uint32_t step = blockDim.x;
+    const uint32_t step = NT;
     const uint32_t out_shift = a.logN - a.logD;
     const uint32_t k_stride = a.rows_per_k * (uint32_t)a.row_width;  // < 2^19
     const uint32_t hash_bytes = a.hash_epr * F::BYTES;             // <= 1024 (one chunk) unless CHUNKED
@@ -1083,6 +1101,10 @@ __global__ void __launch_bounds__(SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512)) k_
         __syncthreads();
         return ticket_sh[slot];
     };
+    // The ticket of the NEXT tile is requested at the top of the current one (thread 0 keeps the returning value in a
+    // register) and only handed to the work-group after the row stores: the atomic's round trip to L2 (~1-2 us, during
+    // which every wave of the work-group sat in the barrier of next_ticket) runs under the transform.
+    uint32_t ticket_ahead = 0;
     uint64_t ticket = next_ticket(0);
     // Counters reset themselves: every work-group takes exactly one ticket past the end, then signs off on the exit
     // counter of its XCD (words 8..15); the last one to sign off zeroes both for the next launch.  No memset between
@@ -1139,7 +1161,9 @@ __global__ void __launch_bounds__(SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512)) k_
             d_[7 * step] = q7;
         }
         __syncthreads();
-        seg_lds_ntt<F, 1>(x, twd, a.logD);
+        if ((!MULTI || g + 1 == (CHUNKED ? min(16 * ch + 16, a.n_seg) : a.n_seg)) && threadIdx.x == 0)
+            ticket_ahead = atomicAdd(a.tile_counters + xcd, 1u);  // (uniform condition: the last segment of this ticket)
+        seg_lds_ntt<F, 1>(x, twd, a.logD, NT);
 
         // row stores: lane pair (2l, 2l+1) of row position pos -> its place in LDE row k * rows_per_k + c of its trace
         {
@@ -1149,7 +1173,7 @@ __global__ void __launch_bounds__(SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512)) k_
             T *pa = nullptr, *pb = nullptr, *pz = nullptr, *pz2 = nullptr;  // pz*: first padding element after a trace's last column
             bool pair = false;
             if (F::BYTES == 16 && !(PADT && a.row_width == 8)) {  // (f128 rows of 8: thread quads below)
-                store_rows_by_element<F>(x, a, g, c, rev_o, out_shift, k_stride, tid, blockDim.x, a.tail_pad && g + 1 == a.n_seg, PADT);
+                store_rows_by_element<F>(x, a, g, c, rev_o, out_shift, k_stride, tid, NT, a.tail_pad && g + 1 == a.n_seg, PADT);
             } else if (!MULTI) {
                 if (pos0 < D && lane_a < a.store_cols) {
                     pa = a.dst + (uint64_t)c * a.row_width + lane_a;
@@ -1157,7 +1181,7 @@ __global__ void __launch_bounds__(SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512)) k_
                     if (PADT && lane_a + 2 >= a.store_cols) pz = pa + (a.store_cols - lane_a);
                 }
             } else if (PADT && (a.row_width == 8 || (F::BYTES == 8 && a.row_width == 16 && a.store_cols <= 10))) {
-                store_rows_narrow<F>(x, a, g, c, rev_o, out_shift, k_stride, tid, blockDim.x);
+                store_rows_narrow<F>(x, a, g, c, rev_o, out_shift, k_stride, tid, NT);
             } else if (pos0 < D && B < a.total_store_cols) {
                 const uint32_t t0 = B / a.store_cols, c0 = B - t0 * a.store_cols;
                 pa = a.dst + (uint64_t)t0 * a.trace_lde_elems + (uint64_t)c * a.row_width + c0;
@@ -1196,7 +1220,9 @@ __global__ void __launch_bounds__(SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512)) k_
         uint64_t on = o, rev_on = rev_o;
         const uint32_t g_end = CHUNKED ? min(16 * ch + 16, a.n_seg) : a.n_seg;  // one past the last segment of this ticket
         if (!MULTI || gn == g_end) {
-            ticket = next_ticket(1);
+            if (threadIdx.x == 0) ticket_sh[1] = ticket_ahead;
+            __syncthreads();
+            ticket = ticket_sh[1];
             more = ticket < per_xcd;
             if (more) decode(ticket * 8 + xcd, cn, on, rev_on, chn);
             gn = 16 * chn;

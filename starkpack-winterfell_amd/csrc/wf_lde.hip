@@ -603,6 +603,9 @@ static int seg_launch_dims(uint32_t logD, uint32_t &threads, size_t &lds, bool l
         HIP_TRY(hipFuncSetAttribute((const void *)k_seg_last<F, SEG_OUT_ROWS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_TRY(hipFuncSetAttribute((const void *)k_seg_last<F, SEG_OUT_SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_TRY(hipFuncSetAttribute((const void *)k_seg_last<F, SEG_OUT_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        constexpr int L10 = F::BYTES == 8 ? 10 : 0;  // the tile-size-specialised instantiation whose tile exceeds 64 KiB
+        HIP_TRY(hipFuncSetAttribute((const void *)k_seg_strided<F, 0, false, L10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_seg_strided<F, 1, false, L10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     return 0;
 }
@@ -724,7 +727,23 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         const uint64_t grid = (uint64_t)n_groups * d.n_seg * a.O * a.I;
         if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
         prof_mark(ctx, st, tag_s);
-        if (d.rows_out && packed)
+        // f64 tiles of 2^10 rows (the digits of the 2^19 .. 2^21 plans) run the tile-size-specialised instantiation
+        // (seg_kernels.hpp, WF_TILE_BOUNDS: strided pass of cfg 2 0.347 -> 0.324 ms); everything else the generic kernel.
+        // Measured and left out: 2^7 / 2^8-row tiles (2^22 x 64: 36.8 -> 37.5 ms, no gain), and the last passes, which
+        // specialised for the tile size need more registers than two work-groups per CU allow (scratch spills).
+        const bool spec_ok = F::BYTES == 8 && !packed && threads * 2 == (1u << a.logD) && getenv("WF_EXP_NO_SPECIALIZED") == nullptr;
+        const void *kern = nullptr;
+        if (spec_ok) {
+            constexpr bool F8 = F::BYTES == 8;  // (the specialised instantiations exist for f64 only)
+            switch (a.logD) {
+                case 10: kern = d.rows_out ? (const void *)k_seg_strided<F, 1, false, F8 ? 10 : 0> : (const void *)k_seg_strided<F, 0, false, F8 ? 10 : 0>; break;
+                default: break;
+            }
+        }
+        if (kern) {
+            void *kargs[] = {&a};
+            HIP_TRY(hipLaunchKernel(kern, dim3((uint32_t)grid), dim3(threads), kargs, lds, st));
+        } else if (d.rows_out && packed)
             hipLaunchKernelGGL((k_seg_strided<F, 1, true>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
         else if (d.rows_out)
             hipLaunchKernelGGL((k_seg_strided<F, 1>), dim3((uint32_t)grid), dim3(threads), lds, st, a);

@@ -87,7 +87,7 @@ def test_allocation_failure_is_reported_and_survivable(ctx, orc, capi):
     want = orc.build_trace_commitment(F64, [cols], 1, 12, 3, 7)
     com, _ = ctx.trace_commit_resident(params, cols)
     com.close()                                                 # its buffers are parked in the context now
-    huge = capi.make_params(F64, 1, 30, 7, 255, 1)              # 2 TiB of segment scratch alone
+    huge = capi.make_params(F64, 1, 25, 7, 255, 1)              # 128 GiB of segment scratch + 8 TiB of intermediate
     with pytest.raises(capi.WfError) as e:
         ctx.trace_commit_dev(huge, 256, 256, 256, 256, 256)     # never dereferenced: the scratch allocation fails first
     assert e.value.code == -30 and "hipMalloc" in str(e.value)
