@@ -264,14 +264,124 @@ __device__ __forceinline__ void radix16(typename F::T (&v)[16], const typename F
 // them straight from global memory (work item wk = threadIdx.x: lane wk % S of rows a * D/16 + wk / S, a = 0..15;
 // needs logD >= 4, RADIX16 and blockDim >= D/2), which saves the tile's trip through LDS before the first round.
 // `nthr` = blockDim.x, passed in so that the tile-size-specialised kernels (LOGD != 0, below) make it a constant.
-template <class F, int DIR = 0>
-__device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::T *twd, uint32_t logD, uint32_t nthr,
-                                            const typename F::T *first = nullptr) {
+// One radix-16 round of seg_lds_ntt at `cur` remaining bits (no trailing barrier): work item wk = lane wk % S of the
+// 16 rows base + a * 2^(cur-4), a = 0..15.  w16[j] = w_16^j.
+template <class F, int DIR>
+__device__ __forceinline__ void seg_round16(typename F::T *x, const typename F::T *twd, const typename F::T (&w16)[8],
+                                            uint32_t logD, uint32_t cur, uint32_t nthr, const typename F::T *first,
+                                            uint32_t tid) {  // tid: threadIdx.x (persistent kernels pass opaque_tid())
+    typedef typename F::T T;
+    constexpr uint32_t S = SegCfg<F>::S;
+    constexpr uint32_t s_shift = S == 8 ? 3 : 2;
+    const uint32_t D = 1u << logD;
+    const uint32_t mlog = cur - 4, m = 1u << mlog;
+    const uint32_t nwork = (D >> 4) * S;
+    const uint32_t tshift = logD - cur;
+    const uint32_t st = m * S;
+    for (uint32_t wk = tid; wk < nwork; wk += nthr) {
+        const uint32_t l = wk & (S - 1), u = wk >> s_shift;
+        const uint32_t jp = u & (m - 1), p = u >> mlog;
+        const uint32_t base = (((p << cur) + jp) * S) + l;
+        T v[16];
+        if (first) {  // uniform
+#pragma unroll
+            for (int a = 0; a < 16; a++) v[a] = first[a];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 16; a++) v[a] = x[base + a * st];
+        }
+        radix16<F, DIR>(v, w16);
+        if (jp != 0) {
+            const uint32_t e = jp << tshift;
+#pragma unroll
+            for (int k = 1; k < 16; k++) v[bitrev4(k)] = F::mul(v[bitrev4(k)], twd[e * k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[base + k * st] = v[bitrev4(k)];
+    }
+}
+
+// One radix-4 round (two lanes per work item, 16-byte LDS accesses for f64); w4 = w_4.
+template <class F>
+__device__ __forceinline__ void seg_round4(typename F::T *x, const typename F::T *twd, typename F::T w4, uint32_t logD,
+                                           uint32_t cur, uint32_t nthr, uint32_t tid) {
     typedef typename F::T T;
     typedef Pair<T> P2;
     constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;
     constexpr uint32_t hp_shift = HP == 4 ? 2 : 1;
-    constexpr uint32_t s_shift = S == 8 ? 3 : 2;
+    const uint32_t D = 1u << logD;
+    const uint32_t mlog = cur - 2, m = 1u << mlog;
+    const uint32_t nwork = (D >> 2) * HP;
+    const uint32_t tshift = logD - cur;
+    const uint32_t st = m * S;
+    for (uint32_t wk = tid; wk < nwork; wk += nthr) {
+        const uint32_t lp = wk & (HP - 1), u = wk >> hp_shift;
+        const uint32_t jp = u & (m - 1), p = u >> mlog;
+        const uint32_t base = (((p << cur) + jp) * S) + 2 * lp;
+        P2 x0 = *reinterpret_cast<P2 *>(x + base);
+        P2 x1 = *reinterpret_cast<P2 *>(x + base + st);
+        P2 x2 = *reinterpret_cast<P2 *>(x + base + 2 * st);
+        P2 x3 = *reinterpret_cast<P2 *>(x + base + 3 * st);
+        P2 y0, y1, y2, y3;
+        {
+            T a = F::add(x0.a, x2.a), b = F::sub(x0.a, x2.a), c = F::add(x1.a, x3.a);
+            T d = F::mul(F::sub(x1.a, x3.a), w4);
+            y0.a = F::add(a, c);
+            y2.a = F::sub(a, c);
+            y1.a = F::add(b, d);
+            y3.a = F::sub(b, d);
+        }
+        {
+            T a = F::add(x0.b, x2.b), b = F::sub(x0.b, x2.b), c = F::add(x1.b, x3.b);
+            T d = F::mul(F::sub(x1.b, x3.b), w4);
+            y0.b = F::add(a, c);
+            y2.b = F::sub(a, c);
+            y1.b = F::add(b, d);
+            y3.b = F::sub(b, d);
+        }
+        if (jp != 0) {
+            const uint32_t e = jp << tshift;
+            const T t1 = twd[e], t2 = twd[2 * e], t3 = twd[3 * e];
+            y1.a = F::mul(y1.a, t1);
+            y1.b = F::mul(y1.b, t1);
+            y2.a = F::mul(y2.a, t2);
+            y2.b = F::mul(y2.b, t2);
+            y3.a = F::mul(y3.a, t3);
+            y3.b = F::mul(y3.b, t3);
+        }
+        *reinterpret_cast<P2 *>(x + base) = y0;
+        *reinterpret_cast<P2 *>(x + base + st) = y1;
+        *reinterpret_cast<P2 *>(x + base + 2 * st) = y2;
+        *reinterpret_cast<P2 *>(x + base + 3 * st) = y3;
+    }
+}
+
+template <class F>
+__device__ __forceinline__ void seg_round2(typename F::T *x, uint32_t logD, uint32_t nthr, uint32_t tid) {
+    typedef typename F::T T;
+    typedef Pair<T> P2;
+    constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;
+    constexpr uint32_t hp_shift = HP == 4 ? 2 : 1;
+    const uint32_t nwork = (1u << (logD - 1)) * HP;
+    for (uint32_t wk = tid; wk < nwork; wk += nthr) {
+        const uint32_t lp = wk & (HP - 1), u = wk >> hp_shift;
+        const uint32_t base = (u << 1) * S + 2 * lp;
+        P2 x0 = *reinterpret_cast<P2 *>(x + base);
+        P2 x1 = *reinterpret_cast<P2 *>(x + base + S);
+        P2 y0, y1;
+        y0.a = F::add(x0.a, x1.a);
+        y1.a = F::sub(x0.a, x1.a);
+        y0.b = F::add(x0.b, x1.b);
+        y1.b = F::sub(x0.b, x1.b);
+        *reinterpret_cast<P2 *>(x + base) = y0;
+        *reinterpret_cast<P2 *>(x + base + S) = y1;
+    }
+}
+
+template <class F, int DIR = 0>
+__device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::T *twd, uint32_t logD, uint32_t nthr,
+                                            const typename F::T *first = nullptr) {
+    typedef typename F::T T;
     const uint32_t D = 1u << logD;
     uint32_t cur = logD;
     if (SegCfg<F>::RADIX16 && logD >= 4) {
@@ -279,31 +389,7 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
 #pragma unroll
         for (int j = 0; j < 8; j++) w16[j] = twd[j * (D >> 4)];
         while (cur >= 4) {
-            const uint32_t mlog = cur - 4, m = 1u << mlog;
-            const uint32_t nwork = (D >> 4) * S;
-            const uint32_t tshift = logD - cur;
-            const uint32_t st = m * S;
-            for (uint32_t wk = threadIdx.x; wk < nwork; wk += nthr) {
-                const uint32_t l = wk & (S - 1), u = wk >> s_shift;
-                const uint32_t jp = u & (m - 1), p = u >> mlog;
-                const uint32_t base = (((p << cur) + jp) * S) + l;
-                T v[16];
-                if (first && cur == logD) {  // uniform
-#pragma unroll
-                    for (int a = 0; a < 16; a++) v[a] = first[a];
-                } else {
-#pragma unroll
-                    for (int a = 0; a < 16; a++) v[a] = x[base + a * st];
-                }
-                radix16<F, DIR>(v, w16);
-                if (jp != 0) {
-                    const uint32_t e = jp << tshift;
-#pragma unroll
-                    for (int k = 1; k < 16; k++) v[bitrev4(k)] = F::mul(v[bitrev4(k)], twd[e * k]);
-                }
-#pragma unroll
-                for (int k = 0; k < 16; k++) x[base + k * st] = v[bitrev4(k)];
-            }
+            seg_round16<F, DIR>(x, twd, w16, logD, cur, nthr, cur == logD ? first : nullptr, threadIdx.x);
             cur -= 4;
             __syncthreads();
         }
@@ -312,70 +398,22 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
     if (logD >= 2) w4 = twd[D >> 2];
     while (cur > 0) {
         if (cur >= 2) {
-            const uint32_t mlog = cur - 2, m = 1u << mlog;
-            const uint32_t nwork = (D >> 2) * HP;
-            const uint32_t tshift = logD - cur;
-            const uint32_t st = m * S;
-            for (uint32_t wk = threadIdx.x; wk < nwork; wk += nthr) {
-                const uint32_t lp = wk & (HP - 1), u = wk >> hp_shift;
-                const uint32_t jp = u & (m - 1), p = u >> mlog;
-                const uint32_t base = (((p << cur) + jp) * S) + 2 * lp;
-                P2 x0 = *reinterpret_cast<P2 *>(x + base);
-                P2 x1 = *reinterpret_cast<P2 *>(x + base + st);
-                P2 x2 = *reinterpret_cast<P2 *>(x + base + 2 * st);
-                P2 x3 = *reinterpret_cast<P2 *>(x + base + 3 * st);
-                P2 y0, y1, y2, y3;
-                {
-                    T a = F::add(x0.a, x2.a), b = F::sub(x0.a, x2.a), c = F::add(x1.a, x3.a);
-                    T d = F::mul(F::sub(x1.a, x3.a), w4);
-                    y0.a = F::add(a, c);
-                    y2.a = F::sub(a, c);
-                    y1.a = F::add(b, d);
-                    y3.a = F::sub(b, d);
-                }
-                {
-                    T a = F::add(x0.b, x2.b), b = F::sub(x0.b, x2.b), c = F::add(x1.b, x3.b);
-                    T d = F::mul(F::sub(x1.b, x3.b), w4);
-                    y0.b = F::add(a, c);
-                    y2.b = F::sub(a, c);
-                    y1.b = F::add(b, d);
-                    y3.b = F::sub(b, d);
-                }
-                if (jp != 0) {
-                    const uint32_t e = jp << tshift;
-                    const T t1 = twd[e], t2 = twd[2 * e], t3 = twd[3 * e];
-                    y1.a = F::mul(y1.a, t1);
-                    y1.b = F::mul(y1.b, t1);
-                    y2.a = F::mul(y2.a, t2);
-                    y2.b = F::mul(y2.b, t2);
-                    y3.a = F::mul(y3.a, t3);
-                    y3.b = F::mul(y3.b, t3);
-                }
-                *reinterpret_cast<P2 *>(x + base) = y0;
-                *reinterpret_cast<P2 *>(x + base + st) = y1;
-                *reinterpret_cast<P2 *>(x + base + 2 * st) = y2;
-                *reinterpret_cast<P2 *>(x + base + 3 * st) = y3;
-            }
+            seg_round4<F>(x, twd, w4, logD, cur, nthr, threadIdx.x);
             cur -= 2;
         } else {
-            const uint32_t nwork = (D >> 1) * HP;
-            for (uint32_t wk = threadIdx.x; wk < nwork; wk += nthr) {
-                const uint32_t lp = wk & (HP - 1), u = wk >> hp_shift;
-                const uint32_t base = (u << 1) * S + 2 * lp;
-                P2 x0 = *reinterpret_cast<P2 *>(x + base);
-                P2 x1 = *reinterpret_cast<P2 *>(x + base + S);
-                P2 y0, y1;
-                y0.a = F::add(x0.a, x1.a);
-                y1.a = F::sub(x0.a, x1.a);
-                y0.b = F::add(x0.b, x1.b);
-                y1.b = F::sub(x0.b, x1.b);
-                *reinterpret_cast<P2 *>(x + base) = y0;
-                *reinterpret_cast<P2 *>(x + base + S) = y1;
-            }
+            seg_round2<F>(x, logD, nthr, threadIdx.x);
             cur = 0;
         }
         __syncthreads();
     }
+}
+
+__device__ __forceinline__ uint32_t opaque_tid() {
+    // everything derived from the thread index is recomputed inside every iteration of the tile loop from this opaque
+    // copy: otherwise the compiler hoists dozens of loop-invariant addresses out of the loop and holds them in VGPRs
+    uint32_t t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1029,13 +1067,6 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
 // transform itself needs ~80 of the 128 that two resident work-groups per CU allow).  Same tiles, arithmetic and
 // outputs as k_seg_last<F, ROWS> + k_hash_rows; a static tile walk (t += gridDim) measured 10 % slower than the
 // one-tile-per-work-group kernel, the dynamic one 5 % faster.
-__device__ __forceinline__ uint32_t opaque_tid() {
-    // everything derived from the thread index is recomputed inside every iteration of the tile loop from this opaque
-    // copy: otherwise the compiler hoists dozens of loop-invariant addresses out of the loop and holds them in VGPRs
-    uint32_t t = threadIdx.x;
-    asm volatile("" : "+v"(t));
-    return t;
-}
 
 // MULTI = false: one segment of one trace (the bench workload) -- no chaining values to carry, one lane pair mapping.
 // CHUNKED (with MULTI): rows longer than one BLAKE3 chunk -- a ticket is (coset, row block, chunk): the work-group walks the
@@ -1101,10 +1132,6 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512))
         __syncthreads();
         return ticket_sh[slot];
     };
-    // The ticket of the NEXT tile is requested at the top of the current one (thread 0 keeps the returning value in a
-    // register) and only handed to the work-group after the row stores: the atomic's round trip to L2 (~1-2 us, during
-    // which every wave of the work-group sat in the barrier of next_ticket) runs under the transform.
-    uint32_t ticket_ahead = 0;
     uint64_t ticket = next_ticket(0);
     // Counters reset themselves: every work-group takes exactly one ticket past the end, then signs off on the exit
     // counter of its XCD (words 8..15); the last one to sign off zeroes both for the next launch.  No memset between
@@ -1161,8 +1188,6 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512))
             d_[7 * step] = q7;
         }
         __syncthreads();
-        if ((!MULTI || g + 1 == (CHUNKED ? min(16 * ch + 16, a.n_seg) : a.n_seg)) && threadIdx.x == 0)
-            ticket_ahead = atomicAdd(a.tile_counters + xcd, 1u);  // (uniform condition: the last segment of this ticket)
         seg_lds_ntt<F, 1>(x, twd, a.logD, NT);
 
         // row stores: lane pair (2l, 2l+1) of row position pos -> its place in LDE row k * rows_per_k + c of its trace
@@ -1220,9 +1245,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512))
         uint64_t on = o, rev_on = rev_o;
         const uint32_t g_end = CHUNKED ? min(16 * ch + 16, a.n_seg) : a.n_seg;  // one past the last segment of this ticket
         if (!MULTI || gn == g_end) {
-            if (threadIdx.x == 0) ticket_sh[1] = ticket_ahead;
-            __syncthreads();
-            ticket = ticket_sh[1];
+            ticket = next_ticket(1);
             more = ticket < per_xcd;
             if (more) decode(ticket * 8 + xcd, cn, on, rev_on, chn);
             gn = 16 * chn;
