@@ -191,32 +191,74 @@ def with_transfers(ctx, capi, params, trace_host, gpu_root):
     # under the other's kernels -- a single commitment cannot hide its own 64 MiB upload: every evaluation tile needs
     # the coefficients of whole columns.
     import threading
-    n_each, roots, walls = 6, [], []
 
-    def worker():
-        c2 = capi.Context(ctx.device)
-        com, _ = c2.trace_commit_resident(params, cols)  # warm-up: scratch, tables
-        com.close()
-        barrier.wait()
-        for _ in range(n_each):
-            com, _ = c2.trace_commit_resident(params, cols)
-            roots.append(com.root().hex())
+    def pipelined(columns, n_each=6):
+        roots = []
+
+        def worker():
+            c2 = capi.Context(ctx.device)
+            com, _ = c2.trace_commit_resident(params, columns)  # warm-up: scratch, tables
             com.close()
-        c2.close()
+            barrier.wait()
+            for _ in range(n_each):
+                com, _ = c2.trace_commit_resident(params, columns)
+                roots.append(com.root().hex())
+                com.close()
+            c2.close()
 
-    barrier = threading.Barrier(3)
-    th = [threading.Thread(target=worker) for _ in range(2)]
-    for t in th:
-        t.start()
-    barrier.wait()
-    t0 = time.perf_counter()
-    for t in th:
-        t.join()
-    out["resident_pipelined_ms_per_commit"] = (time.perf_counter() - t0) * 1e3 / (2 * n_each)
-    out["resident_pipelined_roots_match"] = all(x == gpu_root for x in roots) and len(roots) == 2 * n_each
-    out["note"] = ("wall clock around the C call, host columns pageable numpy arrays, PCIe included; median of 3; pipelined = "
-                   "two host threads with a context each committing back to back, wall / commitments")
+        barrier = threading.Barrier(3)
+        th = [threading.Thread(target=worker) for _ in range(2)]
+        for t in th:
+            t.start()
+        barrier.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        ms = (time.perf_counter() - t0) * 1e3 / (2 * n_each)
+        return ms, all(x == gpu_root for x in roots) and len(roots) == 2 * n_each
+
+    out["resident_pipelined_ms_per_commit"], out["resident_pipelined_roots_match"] = pipelined(cols)
+    # the same with the host columns in PINNED memory (what a host gets from hipHostMalloc): asynchronous DMA
+    try:
+        import torch
+        pinned = [torch.from_numpy(c.view(np.int64)).pin_memory().numpy().view(np.uint64) for c in cols]
+        ts = []
+        for i in range(4):
+            t0 = time.perf_counter()
+            com, _ = ctx.trace_commit_resident(params, pinned)
+            ts.append((time.perf_counter() - t0) * 1e3)
+            com.close()
+        out["resident_from_pinned_host_ms"] = sorted(ts[1:])[1]
+        out["resident_pipelined_pinned_ms_per_commit"], _ = pipelined(pinned)
+    except Exception as e:  # noqa: BLE001 -- an optional figure
+        out["resident_from_pinned_host_ms"] = f"not measured: {e}"
+    out["note"] = ("wall clock around the C call, PCIe included; median of 3; host columns pageable numpy arrays unless 'pinned'; "
+                   "pipelined = two host threads with a context each committing back to back, wall / commitments")
     return out
+
+
+class TorchRcclComm:
+    """Fallback collective for --mode proofs when wf_comm could not be created: torch.distributed over RCCL."""
+    transport = "torch"
+
+    def __init__(self, torch, device, reason):
+        import torch.distributed as dist
+        self.torch, self.dist, self.device, self.reason = torch, dist, device, reason
+        dist.init_process_group("nccl", device_id=device)
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def max_f64(self, value):
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_gather_tensors(self, mine, out):
+        self.dist.all_gather_into_tensor(out, mine.contiguous())
+
+    def close(self):
+        self.dist.destroy_process_group()
 
 
 def free_port():
@@ -275,7 +317,24 @@ def main():
             dist.init_process_group("gloo")
             comm = shard.Comm.with_process_group(ctx)
         else:
-            comm = shard.Comm.with_store(ctx, shard.store_from_env(rank, world), rank, world)
+            # RCCL inside libwf_lde.so (wf_comm).  The ranks agree through the store on whether every one of them got its
+            # communicator; if not (nothing like that has been seen, but this path cannot be rehearsed with N > 1 on the
+            # one-GPU boxes it was built on) the roots travel through torch.distributed's RCCL binding instead and the
+            # JSON line says so -- a measured run with the fallback named beats no run.
+            store = shard.store_from_env(rank, world)
+            err = ""
+            try:
+                comm = shard.Comm.with_store(ctx, store, rank, world)
+            except Exception as e:  # noqa: BLE001 -- reported in the JSON line
+                err = f"{type(e).__name__}: {e}"
+            store.set(f"wf_comm_status_{rank}", err.encode() or b"ok")
+            status = [bytes(store.get(f"wf_comm_status_{r}")).decode() for r in range(world)]
+            if any(x != "ok" for x in status):
+                if comm is not None:
+                    comm.close()
+                if args.mode == "packed":
+                    raise SystemExit("wf_comm could not be created on every rank: " + "; ".join(status))
+                comm = TorchRcclComm(torch, device, next(x for x in status if x != "ok"))
 
     packed = args.mode == "packed"
     n_traces = PACKED_TRACES if packed else 1
@@ -315,7 +374,10 @@ def main():
 
     def gather(k):
         if comm is not None and not packed:
-            comm.all_gather_roots(roots.data_ptr(), k, all_roots.data_ptr(), stream.cuda_stream)
+            if comm.transport == "torch":
+                comm.all_gather_tensors(roots[:k], all_roots[:world * k])
+            else:
+                comm.all_gather_roots(roots.data_ptr(), k, all_roots.data_ptr(), stream.cuda_stream)
 
     with torch.cuda.stream(stream):
         for k in range(args.warmup):
@@ -411,6 +473,7 @@ def main():
             "commits_per_s": commits / elapsed,
             "collective": (None if comm is None else
                            {"transport": "RCCL inside libwf_lde.so (wf_comm, C ABI)" if comm.transport == "rccl"
+                            else ("FALLBACK: torch.distributed nccl (= RCCL), wf_comm failed: " + comm.reason) if comm.transport == "torch"
                             else "wf_transport over torch.distributed gloo (rehearsal)",
                             "rccl_version": capi.load().wf_comm_rccl_version() if comm.transport == "rccl" else None,
                             "calls": "all-to-all of leaf digests + all-gather of sub-roots per step" if packed
