@@ -246,6 +246,24 @@ int wf_comm_all_gather_leaf_shards(wf_comm *comm, const void *d_leaves_shard, si
 int wf_trace_commit_sharded_dev(wf_comm *comm, const wf_params *p, const void *d_trace, void *d_polys, void *d_lde_shard,
                                 void *d_leaves, void *d_nodes, void *d_top, void *stream);
 
+/* Resident form of the sharded commitment: host columns in (the same on every rank), everything stays in HBM of the
+ * rank that owns it.  COLLECTIVE calls (every rank of the communicator, same arguments): ..._resident and ..._query. */
+typedef struct wf_sharded_commitment wf_sharded_commitment;
+int wf_trace_commit_sharded_resident(wf_comm *comm, const wf_params *p, const void *const *trace_cols,
+                                     wf_sharded_commitment **out);
+void wf_sharded_commitment_destroy(wf_sharded_commitment *c);
+int wf_sharded_commitment_root(const wf_sharded_commitment *c, uint8_t root_out[32]);
+/* TraceCommitment::query (prover/src/trace/commitment.rs:87-111) on the sharded commitment: same arguments and outputs as
+ * wf_commitment_query, the same on every rank -- each rank gathers the rows of its cosets and the digests of its leaf
+ * range / sub-tree at the queried positions, ONE all-gather of a few KiB merges them, the top log2 W levels are local. */
+int wf_sharded_commitment_query(wf_sharded_commitment *c, const uint64_t *positions, size_t n, void *rows_out,
+                                uint8_t *leaves_out, uint8_t *nodes_out, size_t nodes_capacity, uint32_t *node_counts,
+                                size_t *n_vectors, size_t *n_nodes, uint32_t *depth_out);
+/* The polynomials (complete on every rank) as a wf_commitment for wf_commitment_evaluate_polys_at -- the out-of-domain
+ * frame needs no exchange.  Owned by the sharded commitment; holds no rows (row queries on it fail with WF_ERR_LEAVES). */
+struct wf_commitment;
+int wf_sharded_commitment_polys(const wf_sharded_commitment *c, const struct wf_commitment **out);
+
 /* ---- the path, resident form: commitment stays in HBM, queries are served from there -------------------------------- */
 
 /* Opaque device-resident commitment: the LDE matrices of all traces, the leaves and the tree nodes (what

@@ -31,7 +31,8 @@ SYMBOLS = [
     "wf_comm_unique_id", "wf_comm_create", "wf_comm_create_with_transport", "wf_comm_destroy", "wf_comm_rank",
     "wf_comm_world", "wf_comm_rccl_version", "wf_comm_all_gather", "wf_comm_all_gather_roots", "wf_comm_barrier",
     "wf_comm_max_f64", "wf_shard_proofs", "wf_shard_cosets", "wf_shard_route", "wf_comm_all_gather_leaf_shards",
-    "wf_trace_commit_sharded_dev",
+    "wf_trace_commit_sharded_dev", "wf_trace_commit_sharded_resident", "wf_sharded_commitment_destroy",
+    "wf_sharded_commitment_root", "wf_sharded_commitment_query", "wf_sharded_commitment_polys",
 ]
 
 
@@ -189,6 +190,12 @@ def load():
         L.wf_shard_route.argtypes = [u32, u32, u32, C.c_uint64, pu32, pu64, pu32, pu64]
         L.wf_comm_all_gather_leaf_shards.argtypes = [vp, vp, sz, u32, vp, vp]
         L.wf_trace_commit_sharded_dev.argtypes = [vp, PP, vp, vp, vp, vp, vp, vp, vp]
+        L.wf_trace_commit_sharded_resident.argtypes = [vp, PP, vp, C.POINTER(vp)]
+        L.wf_sharded_commitment_destroy.argtypes = [vp]
+        L.wf_sharded_commitment_destroy.restype = None
+        L.wf_sharded_commitment_root.argtypes = [vp, vp]
+        L.wf_sharded_commitment_query.argtypes = [vp, vp, sz, vp, vp, vp, sz, vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(u32)]
+        L.wf_sharded_commitment_polys.argtypes = [vp, C.POINTER(vp)]
         _lib = L
     return _lib
 

@@ -411,3 +411,247 @@ int wf_trace_commit_sharded_dev(wf_comm *c, const wf_params *p, const void *d_tr
 }
 
 }  // extern "C"
+
+// ---- resident form of the sharded commitment + its query service -------------------------------------------------------
+struct wf_sharded_commitment {
+    wf_comm *comm;
+    wf_params p;
+    void *lde_shard, *leaves, *nodes, *polys;  // this rank's rows (its cosets), leaf range, sub-tree; all polynomials
+    size_t lde_bytes, dig_bytes, polys_bytes;
+    uint64_t n_rows, row_width, epr, row_elems;  // of the WHOLE commitment
+    uint32_t depth, per;
+    std::vector<uint8_t> top;  // nodes 0 .. 2 W - 1 of the whole tree (host copy, identical on every rank)
+    wf_commitment polys_view;  // the polynomials as a wf_commitment (out-of-domain evaluation); holds no rows
+};
+
+static void free_sharded(wf_sharded_commitment *c) {
+    if (!c) return;
+    wf_ctx *ctx = c->comm->ctx;
+    (void)hipSetDevice(ctx->device);
+    pool_free(ctx, c->lde_shard, c->lde_bytes);
+    pool_free(ctx, c->leaves, c->dig_bytes);
+    pool_free(ctx, c->nodes, c->dig_bytes);
+    pool_free(ctx, c->polys, c->polys_bytes);
+    delete c;
+}
+
+// where digest `id` of the whole tree lives (id < N: leaf id; else node id - N): owner rank and its index in that rank's
+// gather space (index < N / W: its leaves; else its sub-tree nodes + N / W), or owner = -1: a top node, replicated
+static void locate_digest(uint64_t id, uint64_t N, uint32_t W, int *owner, uint64_t *local) {
+    const uint64_t nl = N / W;
+    if (id < N) {
+        *owner = (int)(id / nl);
+        *local = id % nl;
+        return;
+    }
+    const uint64_t i = id - N;  // node index, 1 <= i < N
+    uint64_t n = 1;
+    while (2 * n <= i) n *= 2;  // level of n nodes: n <= i < 2 n
+    if (n < W) {
+        *owner = -1;
+        *local = i;
+        return;
+    }
+    const uint64_t r = (i - n) / (n / W);
+    *owner = (int)r;
+    *local = nl + (i - n - r * (n / W)) + n / W;
+}
+
+extern "C" {
+
+int wf_trace_commit_sharded_resident(wf_comm *comm, const wf_params *p, const void *const *trace_cols,
+                                     wf_sharded_commitment **out) {
+    if (!comm || !out) return fail(WF_ERR_ARG, "null argument");
+    int rc = check_params(p, false);
+    if (rc) return rc;
+    if (!trace_cols) return fail(WF_ERR_ARG, "column pointer array is null");
+    uint32_t c0, per;
+    rc = wf_shard_cosets(1u << p->log2_blowup, (uint32_t)comm->rank, (uint32_t)comm->world, &c0, &per);
+    if (rc) return rc;
+    const uint32_t W = (uint32_t)comm->world;
+    const uint64_t R = (uint64_t)1 << p->log2_trace_len, N = R << p->log2_blowup;
+    if (N / W < 2 || R < W) return fail(WF_ERR_ARG, "trace too short to split over %u ranks", W);
+    wf_ctx *ctx = comm->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
+    const size_t colb = wf_column_bytes(p), TC = (size_t)p->n_cols * p->n_traces;
+    for (size_t i = 0; i < TC; i++)
+        if (!trace_cols[i]) return fail(WF_ERR_ARG, "column %zu is null", i);
+    wf_sharded_commitment *c = new wf_sharded_commitment();
+    c->comm = comm;
+    c->p = *p;
+    c->lde_shard = c->leaves = c->nodes = c->polys = nullptr;
+    c->n_rows = N;
+    c->row_width = wf_row_width(p);
+    c->epr = (uint64_t)p->n_cols * p->ext_degree;
+    c->row_elems = c->epr * p->n_traces;
+    c->depth = p->log2_trace_len + p->log2_blowup;
+    c->per = per;
+    c->lde_bytes = (size_t)p->n_traces * R * per * c->row_width * wf_elem_bytes(p->field);
+    c->dig_bytes = (size_t)(N / W) * 32;
+    c->polys_bytes = TC * colb;
+    hipError_t e;
+    if ((e = pool_alloc(ctx, &c->lde_shard, c->lde_bytes)) != hipSuccess || (e = pool_alloc(ctx, &c->leaves, c->dig_bytes)) != hipSuccess ||
+        (e = pool_alloc(ctx, &c->nodes, c->dig_bytes)) != hipSuccess || (e = pool_alloc(ctx, &c->polys, c->polys_bytes)) != hipSuccess) {
+        free_sharded(c);
+        return fail(WF_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    if ((rc = ensure(ctx, ctx->io[0], TC * colb)) || (rc = ensure(ctx, ctx->io[4], (size_t)2 * W * 32))) {
+        free_sharded(c);
+        return rc;
+    }
+    hipStream_t st = ctx->stream;
+    if ((rc = upload_columns(ctx, ctx->io[0].p, trace_cols, TC, colb, st))) {
+        free_sharded(c);
+        return rc;
+    }
+    rc = p->field == WF_FIELD_F64
+             ? trace_commit_sharded<F64>(comm, p, ctx->io[0].p, c->polys, c->lde_shard, c->leaves, c->nodes, ctx->io[4].p, st)
+             : trace_commit_sharded<F128>(comm, p, ctx->io[0].p, c->polys, c->lde_shard, c->leaves, c->nodes, ctx->io[4].p, st);
+    c->top.resize((size_t)2 * W * 32);
+    if (rc == 0 && (hipMemcpyAsync(c->top.data(), ctx->io[4].p, c->top.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess))
+        rc = fail(WF_ERR_HIP, "commitment failed: %s", hipGetErrorString(hipGetLastError()));
+    if (rc) {
+        free_sharded(c);
+        return rc;
+    }
+    memset(&c->polys_view, 0, sizeof(c->polys_view));
+    c->polys_view.ctx = ctx;
+    c->polys_view.p = *p;
+    c->polys_view.polys = c->polys;
+    c->polys_view.borrowed = true;
+    memcpy(c->polys_view.root, c->top.data() + 32, 32);
+    *out = c;
+    return 0;
+}
+
+void wf_sharded_commitment_destroy(wf_sharded_commitment *c) { free_sharded(c); }
+
+int wf_sharded_commitment_root(const wf_sharded_commitment *c, uint8_t root_out[32]) {
+    if (!c || !root_out) return fail(WF_ERR_ARG, "null argument");
+    memcpy(root_out, c->top.data() + 32, 32);
+    return 0;
+}
+
+int wf_sharded_commitment_polys(const wf_sharded_commitment *c, const wf_commitment **out) {
+    if (!c || !out) return fail(WF_ERR_ARG, "null argument");
+    *out = &c->polys_view;
+    return 0;
+}
+
+int wf_sharded_commitment_query(wf_sharded_commitment *c, const uint64_t *positions, size_t n, void *rows_out,
+                                uint8_t *leaves_out, uint8_t *nodes_out, size_t nodes_capacity, uint32_t *node_counts,
+                                size_t *n_vectors, size_t *n_nodes, uint32_t *depth_out) {
+    if (!c || !positions) return fail(WF_ERR_ARG, "null argument");
+    if (!rows_out || !leaves_out || !nodes_out || !node_counts || !n_vectors || !n_nodes) return fail(WF_ERR_ARG, "null argument");
+    // the position checks and the digest ids of the batch proof are those of the unsharded commitment
+    wf_commitment shape;
+    memset(&shape, 0, sizeof(shape));
+    shape.n_rows = c->n_rows;
+    shape.depth = c->depth;
+    int rc = check_positions(&shape, positions, n);
+    if (rc) return rc;
+    std::vector<std::vector<uint64_t>> vec_ids;
+    size_t total = 0;
+    if ((rc = batch_proof_ids(&shape, positions, n, vec_ids, total))) return rc;
+    if (total > nodes_capacity) return fail(WF_ERR_ARG, "nodes_out too small: %zu digests needed", total);
+    std::vector<uint64_t> ids(positions, positions + n);
+    for (auto &v : vec_ids) ids.insert(ids.end(), v.begin(), v.end());
+
+    wf_comm *comm = c->comm;
+    wf_ctx *ctx = comm->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
+    const uint32_t W = (uint32_t)comm->world, me = (uint32_t)comm->rank, blowup = 1u << c->p.log2_blowup;
+    const uint64_t N = c->n_rows, nl = N / W;
+    const size_t eb = wf_elem_bytes(c->p.field), row_bytes = c->row_elems * eb;
+
+    // what this rank owns: digests (gathered from its leaves / sub-tree) and rows (its cosets)
+    std::vector<uint64_t> my_dig_local, my_row_local;
+    std::vector<size_t> my_dig_at, my_row_at;
+    for (size_t k = 0; k < ids.size(); k++) {
+        int owner;
+        uint64_t local;
+        locate_digest(ids[k], N, W, &owner, &local);
+        if (owner == (int)me) {
+            my_dig_local.push_back(local);
+            my_dig_at.push_back(k);
+        }
+    }
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t k = positions[i] / blowup;
+        const uint32_t cst = (uint32_t)(positions[i] % blowup);
+        if (cst / c->per == me) {
+            my_row_local.push_back(k * c->per + cst % c->per);
+            my_row_at.push_back(i);
+        }
+    }
+    // message of a rank: [ids.size()][32] digests then [n] rows, zero where it owns nothing; exchanged with one all-gather
+    const size_t msg = ((ids.size() * 32 + n * row_bytes + 255) / 256) * 256;
+    std::vector<uint8_t> mine(msg, 0), all(msg * W);
+    const size_t nd = my_dig_local.size(), nr = my_row_local.size();
+    const size_t idx_bytes = (nd + nr) * 8, dig_off = (idx_bytes + 255) / 256 * 256, row_off = dig_off + (nd * 32 + 255) / 256 * 256;
+    if ((rc = ensure(ctx, ctx->io[3], row_off + nr * row_bytes + 256))) return rc;
+    if ((rc = ensure(ctx, ctx->io[4], msg * (W + 1)))) return rc;
+    hipStream_t st = ctx->stream;
+    char *work = (char *)ctx->io[3].p;
+    if (nd + nr) {
+        std::vector<uint64_t> idx(my_dig_local);
+        idx.insert(idx.end(), my_row_local.begin(), my_row_local.end());
+        HIP_TRY(hipMemcpyAsync(work, idx.data(), idx_bytes, hipMemcpyHostToDevice, st));
+        if (nd) {
+            hipLaunchKernelGGL(k_gather_digests, dim3((uint32_t)((2 * nd + 255) / 256)), dim3(256), 0, st, (const uint4 *)c->leaves,
+                               (const uint4 *)c->nodes, nl, (const uint64_t *)work, (uint32_t)nd, (uint4 *)(work + dig_off));
+            HIP_TRY(hipGetLastError());
+        }
+        if (nr) {
+            const uint64_t trace_elems = (N / blowup) * c->per * c->row_width;  // one trace's shard
+            if (c->p.field == WF_FIELD_F64)
+                hipLaunchKernelGGL(k_gather_rows<F64>, dim3((uint32_t)nr, c->p.n_traces), dim3(64), 0, st, (const uint64_t *)c->lde_shard,
+                                   trace_elems, (uint32_t)c->row_width, (uint32_t)c->epr, (const uint64_t *)work + nd,
+                                   (uint64_t *)(work + row_off));
+            else
+                hipLaunchKernelGGL(k_gather_rows<F128>, dim3((uint32_t)nr, c->p.n_traces), dim3(64), 0, st, (const U128 *)c->lde_shard,
+                                   trace_elems, (uint32_t)c->row_width, (uint32_t)c->epr, (const uint64_t *)work + nd,
+                                   (U128 *)(work + row_off));
+            HIP_TRY(hipGetLastError());
+        }
+        std::vector<uint8_t> got(nd * 32 + nr * row_bytes);
+        if (nd) HIP_TRY(hipMemcpyAsync(got.data(), work + dig_off, nd * 32, hipMemcpyDeviceToHost, st));
+        if (nr) HIP_TRY(hipMemcpyAsync(got.data() + nd * 32, work + row_off, nr * row_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (size_t q = 0; q < nd; q++) memcpy(&mine[my_dig_at[q] * 32], &got[q * 32], 32);
+        for (size_t q = 0; q < nr; q++) memcpy(&mine[ids.size() * 32 + my_row_at[q] * row_bytes], &got[nd * 32 + q * row_bytes], row_bytes);
+    }
+    char *d_msg = (char *)ctx->io[4].p;
+    HIP_TRY(hipMemcpyAsync(d_msg, mine.data(), msg, hipMemcpyHostToDevice, st));
+    if ((rc = comm_all_gather(comm, d_msg, d_msg + msg, msg, st))) return rc;
+    HIP_TRY(hipMemcpyAsync(all.data(), d_msg + msg, msg * W, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+
+    // every entry from its owner's message
+    std::vector<uint8_t> dig(ids.size() * 32);
+    for (size_t k = 0; k < ids.size(); k++) {
+        int owner;
+        uint64_t local;
+        locate_digest(ids[k], N, W, &owner, &local);
+        if (owner < 0)
+            memcpy(&dig[k * 32], &c->top[local * 32], 32);
+        else
+            memcpy(&dig[k * 32], &all[(size_t)owner * msg + k * 32], 32);
+    }
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t owner = (uint32_t)(positions[i] % blowup) / c->per;
+        memcpy((char *)rows_out + i * row_bytes, &all[(size_t)owner * msg + ids.size() * 32 + i * row_bytes], row_bytes);
+    }
+    memcpy(leaves_out, dig.data(), n * 32);
+    memcpy(nodes_out, dig.data() + n * 32, total * 32);
+    for (size_t i = 0; i < vec_ids.size(); i++) node_counts[i] = (uint32_t)vec_ids[i].size();
+    *n_vectors = vec_ids.size();
+    *n_nodes = total;
+    if (depth_out) *depth_out = c->depth;
+    return 0;
+}
+
+}  // extern "C"

@@ -136,10 +136,71 @@ class Comm:
         capi._check(capi.load().wf_comm_all_gather_leaf_shards(self._h, d_shard, trace_len, per_rank, d_leaves,
                                                                stream or None))
 
+    def trace_commit_sharded_resident(self, params, trace_cols) -> "ShardedCommitment":
+        """Collective: host columns (the same on every rank) -> a resident sharded commitment."""
+        import numpy as np
+        cols = [np.ascontiguousarray(c, dtype=np.uint64) for c in trace_cols]
+        h = C.c_void_p()
+        capi._check(capi.load().wf_trace_commit_sharded_resident(self._h, C.byref(params), capi._ptr_array(cols), C.byref(h)))
+        return ShardedCommitment(h, self, params)
+
     def trace_commit_sharded_dev(self, params, d_trace: int, d_polys: int, d_lde_shard: int, d_leaves: int,
                                  d_nodes: int, d_top: int, stream: int = 0):
         capi._check(capi.load().wf_trace_commit_sharded_dev(self._h, C.byref(params), d_trace, d_polys or None,
                                                             d_lde_shard, d_leaves, d_nodes, d_top, stream or None))
+
+
+class ShardedCommitment:
+    """wf_sharded_commitment wrapper: one packed commitment resident on the ranks of a communicator."""
+
+    def __init__(self, handle, comm, params):
+        self._h, self.comm, self.params = handle, comm, params
+        self.n_rows = 1 << (params.log2_trace_len + params.log2_blowup)
+        self.depth = params.log2_trace_len + params.log2_blowup
+        self.row_elems = params.n_cols * params.ext_degree * params.n_traces
+
+    def close(self):
+        if self._h:
+            capi.load().wf_sharded_commitment_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def root(self) -> bytes:
+        out = (C.c_uint8 * 32)()
+        capi._check(capi.load().wf_sharded_commitment_root(self._h, out))
+        return bytes(out)
+
+    def query(self, positions):
+        """Collective: (rows, (leaves, nodes, depth)) -- the answer of Commitment.query on the unsharded commitment."""
+        import numpy as np
+        pos = np.ascontiguousarray(positions, dtype=np.uint64)
+        n = len(pos)
+        w = capi.ELEM_WORDS[self.params.field]
+        rows = np.empty((n, self.row_elems, w) if w > 1 else (n, self.row_elems), dtype=np.uint64)
+        cap = max(1, n) * (self.depth + 1)
+        leaves = np.empty((max(1, n), 32), dtype=np.uint8)
+        nodes = np.empty((cap, 32), dtype=np.uint8)
+        counts = np.zeros(max(1, n), dtype=np.uint32)
+        n_vec, n_nodes, depth = C.c_size_t(), C.c_size_t(), C.c_uint32()
+        capi._check(capi.load().wf_sharded_commitment_query(self._h, capi._p(pos), n, capi._p(rows), capi._p(leaves),
+                                                            capi._p(nodes), cap, capi._p(counts), C.byref(n_vec),
+                                                            C.byref(n_nodes), C.byref(depth)))
+        out, k = [], 0
+        for i in range(n_vec.value):
+            out.append([bytes(nodes[k + j]) for j in range(int(counts[i]))])
+            k += int(counts[i])
+        return rows, ([bytes(x) for x in leaves[:n]], out, depth.value)
+
+    def polys(self):
+        """The polynomials as a capi.Commitment (evaluate_polys_at); owned by this object."""
+        h = C.c_void_p()
+        capi._check(capi.load().wf_sharded_commitment_polys(self._h, C.byref(h)))
+        return capi.Commitment(h, self.params.field, owned=False, keep_alive=self)
 
 
 def process_group_collectives(group=None):

@@ -232,3 +232,55 @@ def test_failing_transport_is_reported(capi):
         return code
 
     assert run_ranks(world, rank_fn) == [-32, -32]
+
+
+@pytest.mark.parametrize("field,logR,logB,n_cols,n_traces,world", [
+    (F64, 10, 3, 8, 2, 4), (F64, 9, 3, 3, 3, 8), (F64, 10, 2, 8, 1, 2), (F128, 9, 3, 4, 2, 4), (F64, 8, 3, 8, 1, 1)])
+def test_sharded_resident_commitment_and_collective_queries(orc, capi, field, logR, logB, n_cols, n_traces, world):
+    """wf_trace_commit_sharded_resident + wf_sharded_commitment_query on W ranks (threads): every rank gets the rows and
+    the batch proof the unsharded commitment answers with (TraceCommitment::query), the reference's error cases come back
+    as status codes, and the out-of-domain frame is evaluated locally from the complete polynomials."""
+    from starkpack_winterfell_amd import shard
+    rng = np.random.default_rng(31 * world + logR)
+    R, N = 1 << logR, 1 << (logR + logB)
+    traces = [rand_cols(rng, field, n_cols, R) for _ in range(n_traces)]
+    want = orc.build_trace_commitment(field, traces, 1, logR, logB, 7 if field == F64 else 3)
+    params = capi.make_params(field, 1, logR, logB, n_cols, n_traces)
+    cols = [c for t in traces for c in t]
+    positions = np.union1d(rng.integers(0, N, size=24), [0, N - 1]).astype(np.uint64)   # distinct, both ends included
+    rng.shuffle(positions)
+    z = rand_cols(rng, field, 1, 1)[0]
+    lb = Loopback(world)
+
+    def rank_fn(r):
+        ctx = capi.Context(0)
+        comm = shard.Comm.with_transport(ctx, r, world, *lb.collectives(r))
+        com = comm.trace_commit_sharded_resident(params, cols)
+        root = com.root()
+        rows, proof = com.query(positions)
+        rows1, proof1 = com.query(positions[:1])
+        codes = []
+        for bad in (np.array([], dtype=np.uint64), np.array([N], dtype=np.uint64), np.array([3, 3], dtype=np.uint64)):
+            try:
+                com.query(bad)
+                codes.append(0)
+            except capi.WfError as e:
+                codes.append(e.code)
+        ood = com.polys().evaluate_polys_at(z, 1, n_cols * n_traces)
+        com.close()
+        comm.close()
+        ctx.close()
+        return root, rows, proof, rows1, proof1, codes, ood
+
+    pos = positions.astype(np.int64)
+    want_rows = np.concatenate([want["lde"][t][pos][:, :n_cols] for t in range(n_traces)], axis=1)
+    want_proof = orc.merkle_prove_batch(want["nodes"], want["leaves"], [int(p) for p in positions])
+    want_proof1 = orc.merkle_prove_batch(want["nodes"], want["leaves"], [int(positions[0])])
+    want_ood = np.stack([orc.eval_column_at(field, c, 1, z, 1) for t in want["polys"] for c in t])
+    for root, rows, proof, rows1, proof1, codes, ood in run_ranks(world, rank_fn):
+        assert root == want["root"]
+        assert np.array_equal(rows.reshape(want_rows.shape), want_rows)
+        assert proof == want_proof
+        assert np.array_equal(rows1.reshape(-1), want_rows[0].reshape(-1)) and proof1 == want_proof1
+        assert codes == [-19, -18, -18]
+        assert np.array_equal(ood.reshape(want_ood.shape), want_ood)
