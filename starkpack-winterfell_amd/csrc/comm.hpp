@@ -13,6 +13,8 @@
 #pragma once
 
 #include <dlfcn.h>
+
+#include <mutex>
 #include <rccl/rccl.h>
 
 namespace wfcomm {
@@ -28,11 +30,7 @@ struct Rccl {
     decltype(&ncclGetVersion) GetVersion = nullptr;
 };
 
-static Rccl *rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r.handle ? &r : nullptr;
-    tried = true;
+static bool rccl_load(Rccl &r) {
     const char *names[] = {getenv("WF_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
     for (const char *n : names) {
@@ -40,12 +38,12 @@ static Rccl *rccl() {
         h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (h) break;
     }
-    if (!h) return nullptr;
+    if (!h) return false;
 #define WF_SYM(field, sym)                                   \
     r.field = (decltype(r.field))dlsym(h, #sym);             \
     if (!r.field) {                                          \
         dlclose(h);                                          \
-        return nullptr;                                      \
+        return false;                                        \
     }
     WF_SYM(GetUniqueId, ncclGetUniqueId)
     WF_SYM(CommInitRank, ncclCommInitRank)
@@ -56,7 +54,15 @@ static Rccl *rccl() {
     WF_SYM(GetVersion, ncclGetVersion)
 #undef WF_SYM
     r.handle = h;
-    return &r;
+    return true;
+}
+
+// loaded once, by whichever thread needs it first (several host threads may create communicators at the same time)
+static Rccl *rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] { (void)rccl_load(r); });
+    return r.handle ? &r : nullptr;
 }
 
 }  // namespace wfcomm
