@@ -79,7 +79,9 @@ typedef struct wf_params {
  * device by the library: a call first makes its stream wait for everything queued on the stream of the previous call
  * (keep that stream alive until then); calls on one stream run back to back without any host synchronisation.
  * Commitments and FRI provers created on a context use it until they are destroyed: destroy them first, the context
- * last. */
+ * last.  (A handle destroyed AFTER its context -- garbage-collected hosts do that at shutdown -- is released safely: the
+ * library knows which contexts exist and frees the handle's device buffers without touching the dead context; every other
+ * use of such a handle is an error.  Destroying a context twice is ignored.) */
 int wf_ctx_create(int device, wf_ctx **out);
 void wf_ctx_destroy(wf_ctx *ctx);
 /* A context parks the device buffers of destroyed resident commitments (up to 16) for the next commitment of the same

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -217,6 +218,19 @@ def _off16(offset: int):
     return (C.c_uint8 * 16).from_buffer_copy(int(offset).to_bytes(16, "little"))
 
 
+def _alive(owner) -> bool:
+    """Is the object a handle lives in (a Context, or something that itself lives in one) still open?"""
+    seen = 0
+    while owner is not None and seen < 4:
+        if isinstance(owner, Context):
+            return bool(owner._h)
+        if not getattr(owner, "_h", True):
+            return False
+        owner = getattr(owner, "_ctx", None) or getattr(owner, "ctx", None) or getattr(owner, "_keep_alive", None) or getattr(owner, "comm", None)
+        seen += 1
+    return True
+
+
 def device_count() -> int:
     return load().wf_device_count()
 
@@ -228,6 +242,16 @@ class Context:
         self._h = C.c_void_p()
         _check(load().wf_ctx_create(device, C.byref(self._h)))
         self.device = device
+        # Handles created on this context (commitments, FRI provers, communicators): the C ABI wants them destroyed
+        # before it.  References from the children keep the context alive in normal operation, but the interpreter's
+        # final garbage collection runs the finalisers of a dead cycle in no particular order -- so close() takes the
+        # children down first, newest first, and their own close() afterwards is a no-op.
+        self._children = []
+
+    def _adopt(self, child):
+        self._children.append(weakref.ref(child))
+        if len(self._children) > 64:
+            self._children = [r for r in self._children if r() is not None]
 
     def release_cached(self):
         """Return the parked buffers of destroyed resident commitments to the driver (wf_ctx_release_cached)."""
@@ -235,6 +259,11 @@ class Context:
 
     def close(self):
         if self._h:
+            for ref in reversed(self._children):
+                child = ref()
+                if child is not None:
+                    child.close()
+            self._children = []
             load().wf_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -427,13 +456,17 @@ class Commitment:
         self.field = field
         self._owned = owned  # layers of a FriProver belong to the prover
         self._keep_alive = keep_alive  # the Context (or FriProver) this handle lives in: destroyed after it, never before
+        if owned and isinstance(keep_alive, Context):
+            keep_alive._adopt(self)
         n_rows, row_elems, depth = C.c_uint64(), C.c_uint64(), C.c_uint32()
         _check(load().wf_commitment_info(self._h, C.byref(n_rows), C.byref(row_elems), C.byref(depth)))
         self.n_rows, self.row_elems, self.depth = n_rows.value, row_elems.value, depth.value
 
     def close(self):
         if self._h:
-            if self._owned:
+            # (a context that is already gone took its scratch and pool with it: touching the handle now would be a use
+            # after free -- this happens only when the interpreter's final collection finalises the context first)
+            if self._owned and _alive(self._keep_alive):
                 load().wf_commitment_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -533,10 +566,12 @@ class FriProver:
         self._h = C.c_void_p()
         _check(load().wf_fri_prover_create(ctx._h, field, ext, folding, blowup, remainder_max_degree, _off16(offset),
                                            C.byref(self._h)))
+        ctx._adopt(self)
 
     def close(self):
         if self._h:
-            load().wf_fri_prover_destroy(self._h)
+            if _alive(self._ctx):
+                load().wf_fri_prover_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -280,8 +280,10 @@ int wf_comm_create_with_transport(wf_ctx *ctx, const wf_transport *t, int rank, 
 
 void wf_comm_destroy(wf_comm *c) {
     if (!c) return;
-    (void)hipSetDevice(c->ctx->device);
-    (void)hipStreamSynchronize(c->ctx->stream);
+    if (ctx_alive(c->ctx)) {
+        (void)hipSetDevice(c->ctx->device);
+        (void)hipStreamSynchronize(c->ctx->stream);
+    }
     if (c->nccl) {
         wfcomm::Rccl *R = wfcomm::rccl();
         if (R) (void)R->CommDestroy(c->nccl);
@@ -432,8 +434,8 @@ struct wf_sharded_commitment {
 
 static void free_sharded(wf_sharded_commitment *c) {
     if (!c) return;
-    wf_ctx *ctx = c->comm->ctx;
-    (void)hipSetDevice(ctx->device);
+    wf_ctx *ctx = c->comm->ctx;  // (the communicator outlives its commitments: wf_comm_destroy comes after)
+    if (ctx_alive(ctx)) (void)hipSetDevice(ctx->device);
     pool_free(ctx, c->lde_shard, c->lde_bytes);
     pool_free(ctx, c->leaves, c->dig_bytes);
     pool_free(ctx, c->nodes, c->dig_bytes);

@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <set>
 #include <string>
 #include <thread>
 #include <tuple>
@@ -130,6 +132,16 @@ struct CallGuard {
     CallGuard _guard((ctx_), (st_));     \
     if (_guard.rc) return _guard.rc
 
+// Contexts that exist.  The rule of the ABI is "destroy commitments and provers first, their context last"; a handle
+// destroyed after its context (hosts with garbage collectors do this at shutdown) must not touch the dead context's
+// pool or stream: its destroy function checks here and frees its device buffers directly.
+static std::mutex g_ctx_mutex;
+static std::set<const wf_ctx *> g_live_ctx;
+static bool ctx_alive(const wf_ctx *ctx) {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    return g_live_ctx.count(ctx) != 0;
+}
+
 // hipMalloc that gives the context's parked buffers back to the driver and retries once when the device is full
 static hipError_t dev_malloc(wf_ctx *ctx, void **p, size_t bytes) {
     hipError_t e = hipMalloc(p, bytes);
@@ -159,13 +171,17 @@ static hipError_t pool_alloc(wf_ctx *ctx, void **p, size_t bytes) {
 // the device memory): the oldest entries are released first, so buffers of shapes that never come back do not pile up.
 static void pool_free(wf_ctx *ctx, void *p, size_t bytes) {
     if (!p) return;
+    if (!ctx_alive(ctx)) {  // (see g_live_ctx)
+        (void)hipFree(p);
+        return;
+    }
     if (!bytes || bytes > ctx->pool_cap) {
         (void)hipFree(p);
         return;
     }
     ctx->pool.emplace_back(p, bytes);
     ctx->pool_bytes += bytes;
-    while (ctx->pool.size() > 16 || ctx->pool_bytes > ctx->pool_cap) {
+    while (!ctx->pool.empty() && (ctx->pool.size() > 16 || ctx->pool_bytes > ctx->pool_cap)) {
         (void)hipFree(ctx->pool.front().first);
         ctx->pool_bytes -= ctx->pool.front().second;
         ctx->pool.erase(ctx->pool.begin());
@@ -1179,12 +1195,20 @@ int wf_ctx_create(int device, wf_ctx **out) {
         delete c;
         return fail(WF_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     }
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        g_live_ctx.insert(c);
+    }
     *out = c;
     return 0;
 }
 
 void wf_ctx_destroy(wf_ctx *ctx) {
     if (!ctx) return;
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        if (!g_live_ctx.erase(ctx)) return;  // not a live context (destroyed twice)
+    }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->tables) {
@@ -1219,6 +1243,7 @@ int wf_ctx_release_cached(wf_ctx *ctx) {
     WF_ENTER(ctx, ctx->stream);
     for (auto &b : ctx->pool) (void)hipFree(b.first);
     ctx->pool.clear();
+    ctx->pool_bytes = 0;
     return 0;
 }
 
@@ -1417,7 +1442,7 @@ struct wf_commitment {
 
 static void free_commitment(wf_commitment *c) {
     if (!c) return;
-    (void)hipSetDevice(c->ctx->device);
+    if (ctx_alive(c->ctx)) (void)hipSetDevice(c->ctx->device);
     if (!c->borrowed) {
         pool_free(c->ctx, c->lde, c->lde_bytes);
         pool_free(c->ctx, c->leaves, c->dig_bytes);
@@ -2175,8 +2200,10 @@ static int fri_arena_reserve(wf_fri_prover *pr, size_t n) {
 }
 
 static void fri_prover_clear(wf_fri_prover *pr) {
-    (void)hipSetDevice(pr->ctx->device);
-    (void)hipStreamSynchronize(pr->ctx->stream);
+    if (ctx_alive(pr->ctx)) {
+        (void)hipSetDevice(pr->ctx->device);
+        (void)hipStreamSynchronize(pr->ctx->stream);
+    }
     if (pr->evals && !pr->evals_borrowed) (void)hipFree(pr->evals);
     pr->evals = nullptr;
     pr->evals_borrowed = false;

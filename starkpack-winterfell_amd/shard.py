@@ -74,6 +74,7 @@ class Comm:
         self.rank = capi.load().wf_comm_rank(self._h)
         self.world = capi.load().wf_comm_world(self._h)
         self.transport = "transport" if keep else "rccl"
+        ctx._adopt(self)  # closed before the context (capi.Context.close), whatever order finalisers run in
 
     @classmethod
     def with_store(cls, ctx, store, rank: int, world: int, key: str = "wf_comm_id"):
@@ -110,7 +111,8 @@ class Comm:
 
     def close(self):
         if self._h:
-            capi.load().wf_comm_destroy(self._h)
+            if capi._alive(self.ctx):
+                capi.load().wf_comm_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -158,10 +160,12 @@ class ShardedCommitment:
         self.n_rows = 1 << (params.log2_trace_len + params.log2_blowup)
         self.depth = params.log2_trace_len + params.log2_blowup
         self.row_elems = params.n_cols * params.ext_degree * params.n_traces
+        comm.ctx._adopt(self)  # after its communicator in the context's list: closed before it
 
     def close(self):
         if self._h:
-            capi.load().wf_sharded_commitment_destroy(self._h)
+            if capi._alive(self.comm):
+                capi.load().wf_sharded_commitment_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -111,3 +111,32 @@ def test_every_thread_its_own_context_is_fine(orc, capi):
         return roots
 
     assert run_ranks(4, fn) == [[want["root"]] * 5] * 4
+
+
+def test_handles_destroyed_after_their_context_do_not_touch_it(orc, capi):
+    """The rule is commitments and provers first, the context last -- but a host with a garbage collector may finalise in
+    any order at shutdown.  Destroying late must not write into the dead context (the library keeps a registry of live
+    contexts and frees the buffers directly); destroying a context twice is ignored."""
+    import ctypes as C
+    L = capi.load()
+    rng = np.random.default_rng(5)
+    cols = rand_cols(rng, F64, 4, 1 << 9)
+    params = capi.make_params(F64, 1, 9, 2, 4, 1)
+    c = capi.Context(0)
+    com, _ = c.trace_commit_resident(params, cols)
+    pr = capi.FriProver(c, F64, 1, 4, 4, 7, 7)
+    pr.begin(rand_cols(rng, F64, 1, 1 << 9)[0])
+    pr.commit_layer()
+    h_ctx, h_com, h_pr = c._h, com._h, pr._h
+    c._children = []                       # take the Python-side ordering out of the picture
+    c._h = C.c_void_p()
+    com._h = C.c_void_p()
+    pr._h = C.c_void_p()
+    L.wf_ctx_destroy(h_ctx)
+    L.wf_ctx_destroy(h_ctx)                # twice: ignored
+    L.wf_commitment_destroy(h_com)
+    L.wf_fri_prover_destroy(h_pr)
+    c2 = capi.Context(0)                   # the heap is intact: a full commitment on a fresh context
+    want = orc.build_trace_commitment(F64, [cols], 1, 9, 2, 7)
+    assert c2.trace_commit(params, cols)["root"] == want["root"]
+    c2.close()
