@@ -1094,7 +1094,10 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512))
     const uint32_t k_stride = a.rows_per_k * (uint32_t)a.row_width;  // < 2^19
     const uint32_t hash_bytes = a.hash_epr * F::BYTES;             // <= 1024 (one chunk) unless CHUNKED
 
-    for (uint32_t e = threadIdx.x; e < D; e += step) twd[e] = a.digit_tw[e];
+    // (twd[D - 1] is never read: the largest exponent a round uses is (D / 16 - 1) * 15, or (D / 4 - 1) * 3 without
+    // radix-16 rounds -- its 8 / 16 bytes hold the two ticket words, so that a 2^10-row f128 tile (64 KiB + 16 KiB of
+    // twiddles) stays at exactly half a CU's LDS: two work-groups per CU)
+    for (uint32_t e = threadIdx.x; e < D - 1; e += step) twd[e] = a.digit_tw[e];
 
     auto decode = [&](uint64_t t, uint32_t &c, uint64_t &o, uint64_t &rev_o, uint32_t &ch) {
         uint64_t bid = xcd_group_index(t, total);  // coset fastest, 8 consecutive tickets on one XCD
@@ -1124,7 +1127,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512))
     // Tickets are handed out dynamically, per XCD (work-groups are dispatched to XCD blockIdx % 8): ticket index =
     // 8 * n + xcd, so that the order within an XCD -- 8 consecutive tickets = the cosets of one row block -- is kept and
     // a slow work-group does not hold back a fixed share of the work.  total is a multiple of 8.
-    uint32_t *ticket_sh = reinterpret_cast<uint32_t *>(twd + D);  // two words behind the twiddles (dynamic LDS)
+    uint32_t *ticket_sh = reinterpret_cast<uint32_t *>(twd + (D - 1));  // two words in the unused last twiddle slot
     const uint32_t xcd = blockIdx.x & 7;
     const uint64_t per_xcd = total >> 3;
     auto next_ticket = [&](uint32_t slot) -> uint64_t {  // uniform result; includes a barrier

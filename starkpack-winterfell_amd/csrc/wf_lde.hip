@@ -838,7 +838,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
                 a.n_chunks = n_chunks;
             }
             if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            const size_t lds_p = lds + 16;  // two ticket words behind the twiddles
+            const size_t lds_p = lds;  // (the two ticket words live in the unused last twiddle slot)
             const uint64_t resident = (uint64_t)ctx->num_cus * std::max<size_t>(1, (160 * 1024) / lds_p);
             if (!ctx->tickets.p) {  // zeroed once: the kernel leaves its counters at zero
                 int rcq = ensure(ctx, ctx->tickets, 64);
