@@ -288,6 +288,12 @@ int wf_commitment_info(const wf_commitment *c, uint64_t *n_rows, uint64_t *row_e
  * ConstraintCommitment::query, constraints/commitment.rs:54-69): rows_out receives n * row_elems base elements,
  * row i = row positions[i] of trace 0 || trace 1 || .. (the "comb_states" that are hashed into leaf positions[i]). */
 int wf_commitment_read_rows(const wf_commitment *c, const uint64_t *positions, size_t n, void *rows_out);
+/* A contiguous range of rows of ONE trace's matrix as it is stored (RowMatrix::data: row_width base elements per row,
+ * padding lanes included; *row_width_out receives that width -- narrow resident constraint commitments keep dense rows) --
+ * for hosts that evaluate constraints on the CPU and stream the extended trace in pieces (TraceLde::read_main_trace_frame_into,
+ * prover/src/trace/trace_lde.rs:78-98, reads rows i and i + blowup of the same data).  n_rows == 0: only the width. */
+int wf_commitment_read_lde(const wf_commitment *c, uint32_t trace, uint64_t row_begin, uint64_t n_rows, void *rows_out,
+                           uint64_t *row_width_out);
 /* MerkleTree::prove (merkle/mod.rs:192-212): path_out receives (depth + 1) digests: leaf, sibling leaf, siblings
  * bottom-up. */
 int wf_commitment_prove(const wf_commitment *c, uint64_t index, uint8_t *path_out);

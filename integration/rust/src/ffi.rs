@@ -74,6 +74,9 @@ extern "C" {
         nodes_out: *mut u8, nodes_capacity: usize, node_counts: *mut u32, n_vectors: *mut usize, n_nodes: *mut usize,
         depth_out: *mut u32,
     ) -> c_int;
+    pub fn wf_commitment_read_lde(
+        c: *const WfCommitment, trace: u32, row_begin: u64, n_rows: u64, rows_out: *mut c_void, row_width_out: *mut u64,
+    ) -> c_int;
     pub fn wf_commitment_evaluate_polys_at(
         c: *const WfCommitment, z: *const c_void, z_ext_degree: u32, out: *mut c_void,
     ) -> c_int;

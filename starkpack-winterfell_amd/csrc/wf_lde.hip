@@ -1584,6 +1584,27 @@ int wf_commitment_read_rows(const wf_commitment *c, const uint64_t *positions, s
     return 0;
 }
 
+int wf_commitment_read_lde(const wf_commitment *c, uint32_t trace, uint64_t row_begin, uint64_t n_rows, void *rows_out,
+                           uint64_t *row_width_out) {
+    if (!c) return fail(WF_ERR_ARG, "commitment is null");
+    if (row_width_out) *row_width_out = c->row_width;
+    if (n_rows == 0) return 0;
+    if (!rows_out) return fail(WF_ERR_ARG, "rows_out is null");
+    if (!c->lde) return fail(WF_ERR_ARG, "this commitment holds no rows");
+    if (trace >= c->p.n_traces) return fail(WF_ERR_TRACES, "trace %u of %u", trace, c->p.n_traces);
+    if (row_begin >= c->n_rows || n_rows > c->n_rows - row_begin)
+        return fail(WF_ERR_LEAVES, "rows [%llu, %llu) are outside the %llu rows of the matrix", (unsigned long long)row_begin,
+                    (unsigned long long)(row_begin + n_rows), (unsigned long long)c->n_rows);
+    wf_ctx *ctx = c->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
+    const size_t rb = c->row_width * wf_elem_bytes(c->p.field);
+    const char *src = (const char *)c->lde + ((size_t)trace * c->n_rows + row_begin) * rb;
+    HIP_TRY(hipMemcpyAsync(rows_out, src, n_rows * rb, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 // fetch digests by id (id < n_rows: leaf; else node id - n_rows) into host memory
 static int fetch_digests(const wf_commitment *c, const std::vector<uint64_t> &ids, uint8_t *out) {
     if (ids.empty()) return 0;

@@ -131,3 +131,27 @@ def test_many_small_columns_are_staged(ctx, orc, capi):
         for c in (0, 7):
             assert np.array_equal(polys[t * n_cols + c], want["polys"][t][c])
     com.close()
+
+
+def test_read_lde_ranges(ctx, orc, capi):
+    """wf_commitment_read_lde: contiguous row ranges of one trace's matrix exactly as RowMatrix stores it (padding lanes
+    included), for trace and constraint commitments; out-of-range requests come back as status codes."""
+    rng = np.random.default_rng(8)
+    logR, logB = 9, 3
+    N = 1 << (logR + logB)
+    traces = [rand_cols(rng, 1, 5, 1 << logR) for _ in range(2)]
+    want = orc.build_trace_commitment(1, traces, 1, logR, logB, 7)
+    com, _ = ctx.trace_commit_resident(capi.make_params(1, 1, logR, logB, 5, 2), [c for t in traces for c in t])
+    for t, r0, n in ((0, 0, N), (1, 17, 300), (1, N - 1, 1), (0, 5, 0)):
+        assert np.array_equal(com.read_lde(t, r0, n), want["lde"][t][r0:r0 + n])
+    for t, r0, n, code in ((2, 0, 1, -16), (0, N, 1, -18), (0, N - 1, 2, -18)):
+        with pytest.raises(capi.WfError) as e:
+            com.read_lde(t, r0, n)
+        assert e.value.code == code
+    com.close()
+    polys = rand_cols(rng, 1, 1, (1 << logR) * 2)                       # one column of the quadratic extension: dense rows
+    wantc = orc.build_constraint_commitment(1, polys, 2, logR, logB, 7)
+    comc = ctx.constraint_commit_resident(capi.make_params(1, 2, logR, logB, 1, 1), polys)
+    got = comc.read_lde(0, 40, 64)
+    assert np.array_equal(got[:, :2], wantc["lde"][40:104, :2]) and got.shape[1] in (2, 8)
+    comc.close()
