@@ -394,6 +394,34 @@ int wf_evaluate_columns_at(wf_ctx *ctx, uint32_t field, uint32_t ext_degree, con
 /* The same on the polynomials a resident commitment keeps in HBM ([n_traces][n_cols] columns). */
 int wf_commitment_evaluate_polys_at(const wf_commitment *c, const void *z, uint32_t z_ext_degree, void *out);
 
+/* ---- DEEP composition polynomial (the caller between the out-of-domain frame and the DEEP LDE + FRI) ------------------ */
+
+/* DeepCompositionPoly::add_trace_polys + add_composition_poly (prover/src/composer/mod.rs:62-193) on the polynomials the
+ * resident commitments keep in HBM:
+ *     T(x) = sum_i cc_i [ (T_i(x) - T_i(z)) / (x - z) + (T_i(x) - T_i(z g)) / (x - z g) ]   over every column of every trace
+ *     H(x) = sum_i cc'_i (H_i(x) - H_i(z)) / (x - z)                                         over the composition columns
+ * with g the generator of the trace domain; result T + H: n = trace-length coefficients of E (the top one is zero:
+ * degree n - 2, composer/mod.rs:151,192).
+ *   trace_commitments   [n_trace_commitments] resident trace commitments of THIS context, all of one field and trace
+ *                       length: main segments (ext_degree 1) and auxiliary segments (ext_degree == `ext_degree`), each with
+ *                       its n_traces x n_cols columns; `trace_coeffs` holds one element of E per column in that order
+ *                       (DeepCompositionCoefficients::traces, air/src/air/coefficients.rs) -- for STARKPack's packed
+ *                       traces: handle by handle, trace by trace, column by column.
+ *   constraint_commitment  resident constraint commitment (columns of E) or NULL; `constraint_coeffs` one element of E per
+ *                       composition column (DeepCompositionCoefficients::constraints).
+ *   z                   the out-of-domain point, one element of E (ext_degree coordinates), non-zero.
+ * The out-of-domain VALUES the reference's methods are handed (ood_traces_states, ood_evaluations) are not parameters:
+ * they are subtracted from coefficient 0 of each accumulator, and syn_div_in_place (math/src/polynom/mod.rs:535-542)
+ * never reads coefficient 0 of its dividend for the quotient -- the reference's result does not depend on them.
+ *   poly_out            host memory for n elements of E, or NULL.
+ *   fri                 NULL, or a FRI prover of this context over (field, ext_degree): the polynomial is evaluated over the
+ *                       LDE domain of n * lde_blowup points (DeepCompositionPoly::evaluate, composer/mod.rs:198-205) and
+ *                       becomes the prover's first layer without leaving HBM, exactly as wf_fri_prover_begin_poly does
+ *                       with a host polynomial.  At least one of poly_out / fri. */
+int wf_deep_compose(wf_ctx *ctx, const wf_commitment *const *trace_commitments, size_t n_trace_commitments,
+                    const wf_commitment *constraint_commitment, const void *z, uint32_t ext_degree, const void *trace_coeffs,
+                    const void *constraint_coeffs, void *poly_out, wf_fri_prover *fri, size_t lde_blowup);
+
 /* ---- building blocks (each mirrors one reference function; host buffers) ---------------------------------------- */
 
 /* fft::evaluate_poly (math/src/fft/mod.rs:85): in place, n elements of ext_degree coordinates, natural order. */

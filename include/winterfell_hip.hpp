@@ -372,6 +372,8 @@ class TraceCommitment {
         return {std::move(rows), std::move(proof)};
     }
 
+    const wf_commitment *handle() const { return h_; }  // for wf_deep_compose / wf_commitment_evaluate_polys_at
+
   private:
     wf_commitment *h_;
     size_t n_traces_, epr_;
@@ -408,6 +410,31 @@ inline std::pair<std::unique_ptr<TraceCommitment<E>>, std::vector<ColMatrix<E>>>
     return {std::make_unique<TraceCommitment<E>>(h, traces.size(), cols * E::EXTENSION_DEGREE), std::move(trace_polys)};
 }
 
+// build_constraint_commitment (prover/src/lib.rs:680-715) that leaves the commitment on the device: ConstraintCommitment::query
+// (constraints/commitment.rs:54-69) is TraceCommitment::query on one matrix, so the same resident class serves it
+template <class E>
+inline std::unique_ptr<TraceCommitment<E>> build_resident_constraint_commitment(const Prover &prover,
+                                                                                const CompositionPoly<E> &composition_poly,
+                                                                                const StarkDomain &domain) {
+    const size_t cols = composition_poly.num_columns();
+    wf_params p;
+    std::memset(&p, 0, sizeof(p));
+    p.field = E::FIELD;
+    p.ext_degree = E::EXTENSION_DEGREE;
+    p.log2_trace_len = ilog2_exact(composition_poly.column_len(), "composition column length");
+    p.log2_blowup = ilog2_exact(domain.trace_to_lde_blowup(), "blowup factor");
+    p.n_cols = (uint32_t)cols;
+    p.n_traces = 1;
+    p.digest_bytes = 32;
+    unsigned __int128 off = domain.offset();
+    std::memcpy(p.domain_offset, &off, 16);
+    std::vector<const void *> in;
+    for (size_t c = 0; c < cols; c++) in.push_back(composition_poly.data().get_column(c).data());
+    wf_commitment *h = nullptr;
+    wf_check(wf_constraint_commit_resident(prover.context(), &p, in.data(), &h));
+    return std::make_unique<TraceCommitment<E>>(h, 1, cols * E::EXTENSION_DEGREE);
+}
+
 // ------------------------------------------------------------------------------------------------- FRI prover
 struct FriOptions {  // fri/src/options.rs:16-93
     size_t blowup_factor, folding_factor, remainder_max_degree;
@@ -439,6 +466,7 @@ class FriProver {
 
     size_t num_layers() const { return wf_fri_prover_num_layers(h_); }
     const std::vector<E> &remainder() const { return remainder_; }
+    wf_fri_prover *handle() { return h_; }
     void reset() {  // prover/mod.rs:150-154
         wf_check(wf_fri_prover_reset(h_));
         remainder_.clear();
@@ -456,6 +484,12 @@ class FriProver {
     void build_layers_from_poly(Channel &channel, const std::vector<E> &coefficients, size_t lde_blowup) {
         wf_check(wf_fri_prover_begin_poly(h_, coefficients.data(), coefficients.size(), lde_blowup));
         run_layers(channel, coefficients.size() * lde_blowup);
+    }
+
+    // the same with the polynomial already handed over in HBM (DeepCompositionPoly::compose_into below)
+    template <class Channel>
+    void build_layers_resident(Channel &channel, size_t n_evaluations) {
+        run_layers(channel, n_evaluations);
     }
 
   private:
@@ -529,6 +563,59 @@ class FriProver {
     wf_fri_prover *h_ = nullptr;
     size_t domain_size_ = 0;
     std::vector<E> remainder_;
+};
+
+// ------------------------------------------------------------------------------------------------- DEEP composition
+// DeepCompositionCoefficients (air/src/air/coefficients.rs): one element of E per trace column (flattened: commitment by
+// commitment, trace by trace, column by column) and per constraint composition column.
+template <class E>
+struct DeepCompositionCoefficients {
+    std::vector<E> traces;
+    std::vector<E> constraints;
+};
+
+// DeepCompositionPoly (prover/src/composer/mod.rs:16-205) over the polynomials that resident commitments hold in HBM.
+// The reference's add_trace_polys / add_composition_poly take the out-of-domain values as well; they only ever touch the
+// remainder that syn_div_in_place drops (see wf_deep_compose in wf_lde.h), so this mirror does not ask for them.
+template <class E>
+class DeepCompositionPoly {
+  public:
+    DeepCompositionPoly(wf_ctx *ctx, E z, DeepCompositionCoefficients<E> cc) : ctx_(ctx), z_(z), cc_(std::move(cc)) {}
+
+    // add_trace_polys (:62-152) and add_composition_poly (:168-193) in one step; trace_length = TracePolyTable::poly_size
+    void add_polys(const std::vector<const wf_commitment *> &trace_commitments, const wf_commitment *constraint_commitment,
+                   size_t trace_length) {
+        coefficients_.resize(trace_length);
+        wf_check(wf_deep_compose(ctx_, trace_commitments.data(), trace_commitments.size(), constraint_commitment, &z_,
+                                 E::EXTENSION_DEGREE, cc_.traces.data(), constraint_commitment ? cc_.constraints.data() : nullptr,
+                                 coefficients_.data(), nullptr, 0));
+    }
+    // the same followed by evaluate (:198-205) and FriProver::build_layers: the polynomial and its evaluations stay in HBM
+    template <class Channel>
+    void add_polys_and_build_fri_layers(const std::vector<const wf_commitment *> &trace_commitments,
+                                        const wf_commitment *constraint_commitment, size_t trace_length, size_t lde_blowup,
+                                        FriProver<E> &fri, Channel &channel, bool keep_coefficients = false) {
+        if (keep_coefficients) coefficients_.resize(trace_length);
+        wf_check(wf_deep_compose(ctx_, trace_commitments.data(), trace_commitments.size(), constraint_commitment, &z_,
+                                 E::EXTENSION_DEGREE, cc_.traces.data(), constraint_commitment ? cc_.constraints.data() : nullptr,
+                                 keep_coefficients ? coefficients_.data() : nullptr, fri.handle(), lde_blowup));
+        fri.build_layers_resident(channel, trace_length * lde_blowup);
+    }
+
+    size_t poly_size() const { return coefficients_.size(); }  // :40-43
+    size_t degree() const {                                    // polynom::degree_of (:45-48)
+        static const E zero{};
+        for (size_t i = coefficients_.size(); i-- > 0;)
+            if (!(coefficients_[i] == zero)) return i;
+        return 0;
+    }
+    const std::vector<E> &coefficients() const { return coefficients_; }
+
+  private:
+    wf_ctx *ctx_;
+    E z_;
+    DeepCompositionCoefficients<E> cc_;
+    std::vector<E> coefficients_;
 };
 
 }  // namespace winterfell

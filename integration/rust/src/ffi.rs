@@ -77,6 +77,11 @@ extern "C" {
     pub fn wf_commitment_read_lde(
         c: *const WfCommitment, trace: u32, row_begin: u64, n_rows: u64, rows_out: *mut c_void, row_width_out: *mut u64,
     ) -> c_int;
+    pub fn wf_deep_compose(
+        ctx: *mut WfCtx, trace_commitments: *const *const WfCommitment, n_trace_commitments: usize,
+        constraint_commitment: *const WfCommitment, z: *const c_void, ext_degree: u32, trace_coeffs: *const c_void,
+        constraint_coeffs: *const c_void, poly_out: *mut c_void, fri: *mut WfFriProver, lde_blowup: usize,
+    ) -> c_int;
     pub fn wf_commitment_evaluate_polys_at(
         c: *const WfCommitment, z: *const c_void, z_ext_degree: u32, out: *mut c_void,
     ) -> c_int;

@@ -348,4 +348,20 @@ void orc_eval_column_at(int field, const void *poly, size_t n, size_t ext_c, con
         orc_f128_eval_column_at((const f128e *)poly, n, ext_c, (const f128e *)z, ext_z, (f128e *)out);
 }
 
+void orc_deep_compose(int field, size_t ext, size_t n, size_t n_tables, const size_t *cols_per_table, const void *const *cols,
+                      const size_t *col_ext, const void *ood_z, const void *ood_zg, const void *cc_traces,
+                      size_t n_constraint_cols, const void *const *constraint_cols, const void *ood_constraints,
+                      const void *cc_constraints, const void *z, void *out) {
+    if (field == ORC_FIELD_F64)
+        orc_f64_deep_compose(ext, n, n_tables, cols_per_table, (const uint64_t *const *)cols, col_ext, (const uint64_t *)ood_z,
+                             (const uint64_t *)ood_zg, (const uint64_t *)cc_traces, n_constraint_cols,
+                             (const uint64_t *const *)constraint_cols, (const uint64_t *)ood_constraints,
+                             (const uint64_t *)cc_constraints, (const uint64_t *)z, (uint64_t *)out);
+    else
+        orc_f128_deep_compose(ext, n, n_tables, cols_per_table, (const f128e *const *)cols, col_ext, (const f128e *)ood_z,
+                              (const f128e *)ood_zg, (const f128e *)cc_traces, n_constraint_cols,
+                              (const f128e *const *)constraint_cols, (const f128e *)ood_constraints,
+                              (const f128e *)cc_constraints, (const f128e *)z, (f128e *)out);
+}
+
 int orc_max_threads(void) { return omp_get_max_threads(); }

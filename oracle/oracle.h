@@ -102,6 +102,21 @@ void orc_f64_eval_column_at(const uint64_t *poly, size_t n, size_t ext_c, const 
 void orc_f128_eval_column_at(const unsigned __int128 *poly, size_t n, size_t ext_c, const unsigned __int128 *z,
                              size_t ext_z, unsigned __int128 *out);
 
+/* --- DEEP composition polynomial (prover/src/composer/mod.rs:62-193) */
+void orc_deep_compose(int field, size_t ext, size_t n, size_t n_tables, const size_t *cols_per_table, const void *const *cols,
+                      const size_t *col_ext, const void *ood_z, const void *ood_zg, const void *cc_traces,
+                      size_t n_constraint_cols, const void *const *constraint_cols, const void *ood_constraints,
+                      const void *cc_constraints, const void *z, void *out);
+void orc_f64_deep_compose(size_t ext, size_t n, size_t n_tables, const size_t *cols_per_table, const uint64_t *const *cols,
+                          const size_t *col_ext, const uint64_t *ood_z, const uint64_t *ood_zg, const uint64_t *cc_traces,
+                          size_t n_constraint_cols, const uint64_t *const *constraint_cols, const uint64_t *ood_constraints,
+                          const uint64_t *cc_constraints, const uint64_t *z, uint64_t *out);
+void orc_f128_deep_compose(size_t ext, size_t n, size_t n_tables, const size_t *cols_per_table,
+                           const unsigned __int128 *const *cols, const size_t *col_ext, const unsigned __int128 *ood_z,
+                           const unsigned __int128 *ood_zg, const unsigned __int128 *cc_traces, size_t n_constraint_cols,
+                           const unsigned __int128 *const *constraint_cols, const unsigned __int128 *ood_constraints,
+                           const unsigned __int128 *cc_constraints, const unsigned __int128 *z, unsigned __int128 *out);
+
 int orc_max_threads(void);
 
 #ifdef __cplusplus

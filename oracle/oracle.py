@@ -76,6 +76,7 @@ def lib():
         L.orc_blake3_hash.argtypes = [vp, sz, vp]
         L.orc_eval_column_at.argtypes = [i32, vp, sz, sz, vp, sz, vp]
         L.orc_ext_mul.argtypes = [i32, sz, vp, vp, vp]
+        L.orc_deep_compose.argtypes = [i32, sz, sz, sz, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]
         L.orc_transpose_slice.argtypes = [i32, vp, sz, sz, sz, vp]
         L.orc_apply_drp.argtypes = [i32, vp, sz, sz, sz, vp, vp, vp, i32]
         _lib = L
@@ -437,4 +438,49 @@ def eval_column_at(field: int, poly: np.ndarray, ext_c: int, z: np.ndarray, ext_
     n = poly.size // (w * ext_c)
     out = np.empty((ext_z, w) if w > 1 else (ext_z,), dtype=np.uint64)
     lib().orc_eval_column_at(field, _p(poly), n, ext_c, _p(z), ext_z, _p(out))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- DEEP composition
+
+def deep_compose(field: int, ext: int, n: int, tables, constraint_cols, z: np.ndarray, cc_traces, cc_constraints):
+    """DeepCompositionPoly::add_trace_polys + add_composition_poly (prover/src/composer/mod.rs:62-193).
+
+    tables: one list per TracePolyTable of (column, ext_c) pairs, main columns (ext_c = 1) first, then auxiliary ones
+    (ext_c = ext); constraint_cols: columns of `ext` coordinates; cc_traces: one element of E per trace column in table
+    order; cc_constraints: one per constraint column.  The out-of-domain values the reference is handed
+    (T_i(z), T_i(z g), H_i(z)) are computed here with eval_column_at, as the prover does before composing
+    (prover/src/lib.rs: get_ood_frame / evaluate_at).  Returns n elements of E.
+    """
+    w = ELEM_WORDS[field]
+    z = np.ascontiguousarray(z, dtype=np.uint64)
+    logn = n.bit_length() - 1
+    if field == F64:
+        g = np.zeros(ext, dtype=np.uint64)
+        g[0] = lib().orc_f64_get_root_of_unity(logn)
+    else:
+        g = np.zeros((ext, w), dtype=np.uint64)
+        g[0] = f128_from_ints([f128_root_of_unity(logn)])[0]
+    zg = ext_mul(field, ext, z, g)
+    cols, col_ext, ood_z, ood_zg = [], [], [], []
+    for table in tables:
+        for col, ext_c in table:
+            col = np.ascontiguousarray(col, dtype=np.uint64)
+            cols.append(col)
+            col_ext.append(ext_c)
+            ood_z.append(eval_column_at(field, col, ext_c, z, ext))
+            ood_zg.append(eval_column_at(field, col, ext_c, zg, ext))
+    ccols = [np.ascontiguousarray(c, dtype=np.uint64) for c in constraint_cols]
+    ood_c = [eval_column_at(field, c, ext, z, ext) for c in ccols]
+    per_table = np.array([len(t) for t in tables], dtype=np.uint64)
+    col_ext_a = np.array(col_ext, dtype=np.uint64)
+    cat = lambda xs: np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.uint64).reshape(-1) for x in xs])) \
+        if len(xs) else np.zeros(1, dtype=np.uint64)
+    ood_z_a, ood_zg_a, ood_c_a = cat(ood_z), cat(ood_zg), cat(ood_c)
+    cct = cat(list(cc_traces))
+    ccc = cat(list(cc_constraints))
+    out = np.empty((n * ext, w) if w > 1 else (n * ext,), dtype=np.uint64)
+    lib().orc_deep_compose(field, ext, n, len(tables), _p(per_table), _ptr_array(cols), _p(col_ext_a), _p(ood_z_a),
+                           _p(ood_zg_a), _p(cct), len(ccols), _ptr_array(ccols) if ccols else None, _p(ood_c_a), _p(ccc),
+                           _p(z), _p(out))
     return out

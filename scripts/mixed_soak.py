@@ -28,7 +28,7 @@ def shape():
 
 
 for it in range(n):
-    kind = ["host", "resident", "constraint", "fri", "ood", "fft", "drop"][int(rng.integers(0, 7))]
+    kind = ["host", "resident", "constraint", "fri", "ood", "fft", "deep", "drop"][int(rng.integers(0, 8))]
     counts[kind] = counts.get(kind, 0) + 1
     field, ext, logR, logB, n_cols, n_traces, offset = shape()
     R, N = 1 << logR, 1 << (logR + logB)
@@ -86,6 +86,45 @@ for it in range(n):
         want = orc.evaluate_poly_with_offset(field, p, R, ext, orc.get_twiddles(field, R),
                                              L.orc_f64_new(offset) if field == F64 else offset, 1 << logB)
         assert np.array_equal(ctx.fft_evaluate_poly_with_offset(field, ext, p, offset, 1 << logB), want)
+    elif kind == "deep":
+        # DEEP composition over a fresh main segment (+ auxiliary segment) and constraint columns, then into a FRI prover
+        if ext == 1:
+            n_aux = 0
+        else:
+            n_aux = int(rng.integers(0, 3))
+        n_cons = int(rng.integers(0, 4))
+        main = [rand_cols(rng, field, n_cols, R) for _ in range(n_traces)]
+        mp = orc.build_trace_commitment(field, main, 1, logR, logB, offset)["polys"]
+        cm, _ = ctx.trace_commit_resident(capi.make_params(field, 1, logR, logB, n_cols, n_traces), [c for t in main for c in t])
+        handles, tables = [cm], [[(mp[t][c], 1) for c in range(n_cols)] for t in range(n_traces)]
+        if n_aux:
+            aux = [rand_cols(rng, field, n_aux, R * ext) for _ in range(n_traces)]
+            ap = orc.build_trace_commitment(field, aux, ext, logR, logB, offset)["polys"]
+            ca, _ = ctx.trace_commit_resident(capi.make_params(field, ext, logR, logB, n_aux, n_traces), [c for t in aux for c in t])
+            handles.append(ca)
+            for t in range(n_traces):
+                tables[t] += [(ap[t][c], ext) for c in range(n_aux)]
+        cons = rand_cols(rng, field, n_cons, R * ext) if n_cons else []
+        cc = ctx.constraint_commit_resident(capi.make_params(field, ext, logR, logB, n_cons, 1), cons) if n_cons else None
+        re = lambda k=1: rand_f64(rng, ext * k) if field == F64 else rand_f128(rng, ext * k)
+        z = re()
+        cct = [[re() for _ in tab] for tab in tables]
+        abi = [cct[t][c] for t in range(n_traces) for c in range(n_cols)] + [cct[t][n_cols + c] for t in range(n_traces) for c in range(n_aux)]
+        ccc = [re() for _ in range(n_cons)]
+        w = 1 if field == F64 else 2
+        flat = lambda xs: np.concatenate([np.asarray(x).reshape(-1, w) for x in xs]).reshape((-1, w) if w > 1 else -1)
+        want = orc.deep_compose(field, ext, R, tables, cons, z, [c for tab in cct for c in tab], ccc)
+        pr = capi.FriProver(ctx, field, ext, 2, 1 << logB, 3, offset)
+        got = ctx.deep_compose(field, ext, R, handles, cc, z, flat(abi), flat(ccc) if n_cons else None, fri=pr, lde_blowup=1 << logB)
+        assert np.array_equal(got, want), "deep composition"
+        pr2 = capi.FriProver(ctx, field, ext, 2, 1 << logB, 3, offset)
+        pr2.begin_poly(want, 1 << logB)
+        assert pr.commit_layer() == pr2.commit_layer(), "deep composition into FRI"
+        pr.close(); pr2.close()
+        for h in handles:
+            h.close()
+        if cc is not None:
+            cc.close()
     # queries against a random live commitment, then maybe drop some
     if live:
         com, want = live[int(rng.integers(0, len(live)))]

@@ -22,7 +22,7 @@ SYMBOLS = [
     "wf_ctx_release_cached", "wf_plan_digits", "wf_commitment_query", "wf_ctx_profile_enable", "wf_ctx_profile_read", "wf_params_check", "wf_elem_bytes", "wf_row_width", "wf_column_bytes", "wf_lde_bytes", "wf_digests_bytes",
     "wf_trace_commit", "wf_constraint_commit", "wf_trace_commit_dev", "wf_constraint_commit_dev",
     "wf_trace_commit_shard_dev", "wf_merkle_build_dev", "wf_trace_commit_resident", "wf_constraint_commit_resident", "wf_commitment_destroy", "wf_commitment_root",
-    "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_read_lde", "wf_commitment_prove", "wf_commitment_prove_batch",
+    "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_read_lde", "wf_deep_compose", "wf_commitment_prove", "wf_commitment_prove_batch",
     "wf_evaluate_columns_at", "wf_commitment_evaluate_polys_at", "wf_fri_layer_commit", "wf_fri_apply_drp", "wf_fri_layer_commit_dev", "wf_fri_apply_drp_dev",
     "wf_fri_prover_create", "wf_fri_prover_destroy", "wf_fri_num_layers", "wf_fri_prover_begin", "wf_fri_prover_begin_dev", "wf_fri_prover_begin_poly",
     "wf_fri_prover_commit_layer", "wf_fri_prover_fold", "wf_fri_prover_set_remainder", "wf_fri_prover_num_layers",
@@ -138,6 +138,7 @@ def load():
         L.wf_commitment_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(u32)]
         L.wf_commitment_read_rows.argtypes = [vp, vp, sz, vp]
         L.wf_commitment_read_lde.argtypes = [vp, u32, C.c_uint64, C.c_uint64, vp, C.POINTER(C.c_uint64)]
+        L.wf_deep_compose.argtypes = [vp, vp, C.c_size_t, vp, vp, u32, vp, vp, vp, vp, C.c_size_t]
         L.wf_commitment_prove.argtypes = [vp, C.c_uint64, vp]
         L.wf_commitment_prove_batch.argtypes = [vp, vp, sz, vp, vp, sz, vp, C.POINTER(sz), C.POINTER(sz),
                                                 C.POINTER(u32)]
@@ -367,6 +368,22 @@ class Context:
         h = C.c_void_p()
         _check(L.wf_constraint_commit_resident(self._h, C.byref(params), _ptr_array(cols), C.byref(h)))
         return Commitment(h, params.field, keep_alive=self)
+
+    def deep_compose(self, field, ext, n, trace_commitments, constraint_commitment, z, trace_coeffs, constraint_coeffs=None,
+                     want_poly=True, fri: "FriProver" = None, lde_blowup: int = 0):
+        """DeepCompositionPoly::add_trace_polys + add_composition_poly (prover/src/composer/mod.rs:62-193) on resident
+        commitments; returns the n coefficients of E (or None), and starts `fri` from the polynomial's LDE when given."""
+        w = ELEM_WORDS[field]
+        handles = (C.c_void_p * len(trace_commitments))(*[c._h for c in trace_commitments])
+        zz = np.ascontiguousarray(z, dtype=np.uint64)
+        cct = np.ascontiguousarray(trace_coeffs, dtype=np.uint64)
+        ccc = np.ascontiguousarray(constraint_coeffs, dtype=np.uint64) if constraint_coeffs is not None else None
+        out = np.empty((n * ext, w) if w > 1 else (n * ext,), dtype=np.uint64) if want_poly else None
+        _check(load().wf_deep_compose(self._h, handles, len(trace_commitments),
+                                      constraint_commitment._h if constraint_commitment is not None else None, _p(zz), ext,
+                                      _p(cct), _p(ccc) if ccc is not None else None, _p(out) if out is not None else None,
+                                      fri._h if fri is not None else None, lde_blowup))
+        return out
 
     # -- building blocks -----------------------------------------------------------------------------------------
     def fft_evaluate_poly(self, field, ext, poly: np.ndarray) -> np.ndarray:

@@ -21,7 +21,7 @@ struct Ext {
 };
 
 template <class F, int W>
-__device__ __forceinline__ Ext<F, W> ext_mul(const Ext<F, W> &a, const Ext<F, W> &b) {
+__host__ __device__ __forceinline__ Ext<F, W> ext_mul(const Ext<F, W> &a, const Ext<F, W> &b) {
     typedef typename F::T T;
     Ext<F, W> r;
     if constexpr (W == 1) {

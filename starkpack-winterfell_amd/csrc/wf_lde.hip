@@ -2341,7 +2341,11 @@ int wf_fri_prover_begin_dev(wf_fri_prover *pr, const void *d_evals, size_t n, vo
     return fri_prover_begin(pr, d_evals, n, true, stream ? (hipStream_t)stream : (pr ? pr->ctx->stream : nullptr));
 }
 
-int wf_fri_prover_begin_poly(wf_fri_prover *pr, const void *poly, size_t n, size_t lde_blowup) {
+}  // extern "C"
+
+// `poly`: n coefficients of E in host memory, or (poly_on_device) in device memory of this context -- wf_deep_compose
+// hands over the polynomial it has just built in ctx->io[0]
+static int fri_begin_poly_impl(wf_fri_prover *pr, const void *poly, bool poly_on_device, size_t n, size_t lde_blowup) {
     if (!pr || !poly) return fail(WF_ERR_ARG, "null argument");
     if (!pr->layers.empty() || pr->pending || pr->evals)
         return fail(WF_ERR_ARG, "a prior proof generation request has not been completed yet");
@@ -2377,7 +2381,10 @@ int wf_fri_prover_begin_poly(wf_fri_prover *pr, const void *poly, size_t n, size
     }
     pr->evals_borrowed = false;
     hipStream_t st = ctx->stream;
-    rc = hipMemcpyAsync(ctx->io[0].p, poly, wf_column_bytes(&p), hipMemcpyHostToDevice, st) == hipSuccess ? 0 : fail(WF_ERR_HIP, "upload failed");
+    if (poly != ctx->io[0].p)
+        rc = hipMemcpyAsync(ctx->io[0].p, poly, wf_column_bytes(&p), poly_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st) == hipSuccess
+                 ? 0
+                 : fail(WF_ERR_HIP, "upload failed");
     if (rc == 0 && dense) {  // the evaluation writes the dense vector itself
         rc = pr->field == WF_FIELD_F64 ? constraint_commit_dev<F64>(ctx, &p, ctx->io[0].p, pr->evals, nullptr, nullptr, st, true)
                                        : constraint_commit_dev<F128>(ctx, &p, ctx->io[0].p, pr->evals, nullptr, nullptr, st, true);
@@ -2395,6 +2402,12 @@ int wf_fri_prover_begin_poly(wf_fri_prover *pr, const void *poly, size_t n, size
     }
     pr->n = rows;
     return 0;
+}
+
+extern "C" {
+
+int wf_fri_prover_begin_poly(wf_fri_prover *pr, const void *poly, size_t n, size_t lde_blowup) {
+    return fri_begin_poly_impl(pr, poly, false, n, lde_blowup);
 }
 
 int wf_fri_prover_commit_layer(wf_fri_prover *pr, uint8_t root_out[32]) {
@@ -2525,3 +2538,4 @@ int wf_fri_prover_layer(const wf_fri_prover *pr, size_t i, const wf_commitment *
 }  // extern "C"
 
 #include "comm.hpp"
+#include "deep.hpp"

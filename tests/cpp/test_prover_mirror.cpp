@@ -341,8 +341,95 @@ static void fri_prover_resident() {
     std::printf("fri_prover_resident ok\n");
 }
 
+struct QuadChannel {
+    std::vector<Digest> layer_commitments;
+    void commit_fri_layer(const Digest &d) { layer_commitments.push_back(d); }
+    QuadExtension<F64Element> draw_fri_alpha() {
+        Digest seed;
+        orc_merge_with_int(layer_commitments.back().data(), layer_commitments.size(), seed.data());
+        uint64_t v[2];
+        std::memcpy(v, seed.data(), 16);
+        return QuadExtension<F64Element>{{F64Element{orc_f64_new(v[0] >> 2)}, F64Element{orc_f64_new(v[1] >> 2)}}};
+    }
+};
+
+// DeepCompositionPoly over two packed f64 traces and a quadratic-extension constraint commitment, everything resident;
+// checked against the literal CPU restatement of composer/mod.rs (with the out-of-domain values it is handed there)
+static void deep_composition_resident() {
+    typedef QuadExtension<F64Element> E;
+    const size_t trace_length = 1 << 9, blowup = 8, n_cols = 3, n_traces = 2, n_cons = 2;
+    Prover prover(0);
+    StarkDomain domain(trace_length, blowup, 7);
+    uint64_t seed = 12345;
+    auto next = [&]() { seed = seed * 6364136223846793005ull + 1442695040888963407ull; return orc_f64_new(seed >> 3); };
+    std::vector<ColMatrix<F64Element>> traces;
+    for (size_t t = 0; t < n_traces; t++) {
+        std::vector<std::vector<F64Element>> cols(n_cols, std::vector<F64Element>(trace_length));
+        for (auto &c : cols)
+            for (auto &v : c) v.inner = next();
+        traces.emplace_back(std::move(cols));
+    }
+    auto [commitment, trace_polys] = build_resident_trace_commitment<F64Element>(prover, {&traces[0], &traces[1]}, domain);
+    // constraint composition columns over E, committed resident through the C ABI
+    std::vector<E> composition(n_cons * trace_length);
+    for (auto &v : composition) v = E{{F64Element{next()}, F64Element{next()}}};
+    CompositionPoly<E> composition_poly(composition, trace_length, n_cons);
+    auto constraint_commitment = build_resident_constraint_commitment<E>(prover, composition_poly, domain);
+    const wf_commitment *cons_commitment = constraint_commitment->handle();
+    const void *cons_ptrs[n_cons] = {composition_poly.data().get_column(0).data(), composition_poly.data().get_column(1).data()};
+
+    const E z{{F64Element{next()}, F64Element{next()}}};
+    DeepCompositionCoefficients<E> cc;
+    for (size_t i = 0; i < n_traces * n_cols; i++) cc.traces.push_back(E{{F64Element{next()}, F64Element{next()}}});
+    for (size_t i = 0; i < n_cons; i++) cc.constraints.push_back(E{{F64Element{next()}, F64Element{next()}}});
+    DeepCompositionPoly<E> deep(prover.context(), z, cc);
+    deep.add_polys({commitment->handle()}, cons_commitment, trace_length);
+    EXPECT(deep.poly_size() == trace_length && deep.degree() == trace_length - 2);  // composer/mod.rs:151
+
+    // the reference's route on the CPU: out-of-domain frame first, then the composer
+    const uint64_t g = orc_f64_get_root_of_unity(9);
+    const uint64_t zg[2] = {orc_f64_mul(z.c[0].inner, g), orc_f64_mul(z.c[1].inner, g)};
+    std::vector<const void *> cols;
+    std::vector<size_t> col_ext, per_table(n_traces, n_cols);
+    std::vector<uint64_t> ood_z, ood_zg, ood_c;
+    for (size_t t = 0; t < n_traces; t++)
+        for (size_t c = 0; c < n_cols; c++) {
+            const uint64_t *poly = reinterpret_cast<const uint64_t *>(trace_polys[t].get_column(c).data());
+            cols.push_back(poly);
+            col_ext.push_back(1);
+            uint64_t v[2];
+            orc_eval_column_at(ORC_FIELD_F64, poly, trace_length, 1, &z, 2, v);
+            ood_z.insert(ood_z.end(), v, v + 2);
+            orc_eval_column_at(ORC_FIELD_F64, poly, trace_length, 1, zg, 2, v);
+            ood_zg.insert(ood_zg.end(), v, v + 2);
+        }
+    for (size_t c = 0; c < n_cons; c++) {
+        uint64_t v[2];
+        orc_eval_column_at(ORC_FIELD_F64, cons_ptrs[c], trace_length, 2, &z, 2, v);
+        ood_c.insert(ood_c.end(), v, v + 2);
+    }
+    std::vector<uint64_t> want(trace_length * 2);
+    orc_deep_compose(ORC_FIELD_F64, 2, trace_length, n_traces, per_table.data(), cols.data(), col_ext.data(), ood_z.data(),
+                     ood_zg.data(), cc.traces.data(), n_cons, cons_ptrs, ood_c.data(), cc.constraints.data(), &z, want.data());
+    EXPECT(std::memcmp(want.data(), deep.coefficients().data(), want.size() * 8) == 0);
+
+    // straight into FRI: first layer root = the one a prover started from the host coefficients commits to
+    FriOptions options{blowup, 4, 7};
+    FriProver<E> fri_a(prover.context(), options, 7), fri_b(prover.context(), options, 7);
+    QuadChannel ch_a, ch_b;
+    DeepCompositionPoly<E> deep2(prover.context(), z, cc);
+    deep2.add_polys_and_build_fri_layers({commitment->handle()}, cons_commitment, trace_length, blowup, fri_a, ch_a);
+    fri_b.build_layers_from_poly(ch_b, deep.coefficients(), blowup);
+    EXPECT(ch_a.layer_commitments.size() == ch_b.layer_commitments.size() && ch_a.layer_commitments.size() >= 2);
+    for (size_t i = 0; i < ch_a.layer_commitments.size(); i++) EXPECT(ch_a.layer_commitments[i] == ch_b.layer_commitments[i]);
+    EXPECT(fri_a.remainder().size() == fri_b.remainder().size());
+    for (size_t i = 0; i < fri_a.remainder().size(); i++) EXPECT(fri_a.remainder()[i] == fri_b.remainder()[i]);
+    std::printf("deep_composition_resident ok\n");
+}
+
 int main() {
     fri_prover_resident();
+    deep_composition_resident();
     extend_and_commit_trace_table();
     resident_commitment_query();
     starkpack_two_traces_f64();

@@ -313,6 +313,84 @@ def test_extension_products(orc):
     assert not orc.ext_mul(F64, 2, r, mem([0, 0])).any()
 
 
+@pytest.mark.parametrize("field,ext", [(F64, 1), (F64, 2), (F64, 3), (F128, 1), (F128, 2)])
+def test_deep_composition_is_the_sum_of_the_quotients(orc, field, ext):
+    """DeepCompositionPoly (prover/src/composer/mod.rs:52-66,156-167): the composed polynomial D satisfies, at a random
+    point x of E,  D(x) (x - z)(x - z g) = sum_i cc_i [(T_i(x) - T_i(z))(x - z g) + (T_i(x) - T_i(z g))(x - z)]
+    + sum_i cc'_i (H_i(x) - H_i(z))(x - z g) -- schoolbook arithmetic on Python integers, independent of the oracle's
+    field code."""
+    import random
+    rnd = random.Random(field * 10 + ext)
+    p = P64 if field == F64 else P128
+
+    def emul(a, b):
+        c = [0] * (2 * ext - 1)
+        for i in range(ext):
+            for j in range(ext):
+                c[i + j] += a[i] * b[j]
+        if ext == 2 and field == F64:      # x^2 = x - 2
+            c = [c[0] - 2 * c[2], c[1] + c[2]]
+        elif ext == 2:                     # x^2 = x + 1
+            c = [c[0] + c[2], c[1] + c[2]]
+        elif ext == 3:                     # x^3 = x + 1, x^4 = x^2 + x
+            c = [c[0] + c[3], c[1] + c[3] + c[4], c[2] + c[4]]
+        return [v % p for v in c]
+
+    eadd = lambda a, b: [(x + y) % p for x, y in zip(a, b)]  # noqa: E731
+    esub = lambda a, b: [(x - y) % p for x, y in zip(a, b)]  # noqa: E731
+
+    def horner(coeffs, x):  # coeffs: list of E
+        acc = [0] * ext
+        for c in reversed(coeffs):
+            acc = eadd(emul(acc, x), c)
+        return acc
+
+    if field == F64:
+        to_mem = lambda vals: np.array([(v << 64) % p for v in vals], dtype=np.uint64)  # noqa: E731
+        from_mem = lambda a: [int(v) * pow(2**64, -1, p) % p for v in np.asarray(a).reshape(-1)]  # noqa: E731
+    else:
+        to_mem = orc.f128_from_ints
+        from_mem = lambda a: orc.f128_to_ints(np.asarray(a).reshape(-1, 2))  # noqa: E731
+    embed = lambda v: [v] + [0] * (ext - 1)  # noqa: E731
+    n = 32
+    rand_e = lambda: [rnd.randrange(p) for _ in range(ext)]  # noqa: E731
+    # two packed traces: main columns over the base field, auxiliary ones over E; two composition columns
+    tables_int = []
+    for _ in range(2):
+        main = [[embed(rnd.randrange(p)) for _ in range(n)] for _ in range(3)]
+        aux = [[rand_e() for _ in range(n)] for _ in range(2 if ext > 1 else 0)]
+        tables_int.append((main, aux))
+    cons_int = [[rand_e() for _ in range(n)] for _ in range(2)]
+    z = rand_e()
+    cc_t = [[rand_e() for _ in range(len(m) + len(a))] for m, a in tables_int]
+    cc_c = [rand_e() for _ in cons_int]
+    tables = [[(to_mem([c[0] for c in col]), 1) for col in m] + [(to_mem([v for c in col for v in c]), ext) for col in a]
+              for m, a in tables_int]
+    cons = [to_mem([v for c in col for v in c]) for col in cons_int]
+    d = orc.deep_compose(field, ext, n, tables, cons, to_mem(z), [to_mem(c) for tab in cc_t for c in tab], [to_mem(c) for c in cc_c])
+    d_int = from_mem(d)
+    d_e = [d_int[i * ext:(i + 1) * ext] for i in range(n)]
+    assert d_e[n - 1] == [0] * ext and d_e[n - 2] != [0] * ext      # degree n - 2 (composer/mod.rs:151)
+    if field == F64:  # the generator of the trace domain: the reference's get_root_of_unity(log2 n)
+        g = int(orc.lib().orc_f64_get_root_of_unity(5)) * pow(2**64, -1, p) % p
+    else:
+        g = orc.f128_root_of_unity(5)
+    assert pow(g, n, p) == 1 and pow(g, n // 2, p) == p - 1
+    zg = emul(z, embed(g))
+    for _ in range(3):
+        x = rand_e()
+        lhs = emul(horner(d_e, x), emul(esub(x, z), esub(x, zg)))
+        rhs = [0] * ext
+        for (m, a), cc in zip(tables_int, cc_t):
+            for col, k in zip(m + a, cc):
+                tx, tz, tzg = horner(col, x), horner(col, z), horner(col, zg)
+                term = eadd(emul(esub(tx, tz), esub(x, zg)), emul(esub(tx, tzg), esub(x, z)))
+                rhs = eadd(rhs, emul(k, term))
+        for col, k in zip(cons_int, cc_c):
+            rhs = eadd(rhs, emul(k, emul(esub(horner(col, x), horner(col, z)), esub(x, zg))))
+        assert lhs == rhs
+
+
 # ------------------------------------------------------------------------------------ golden: the reference's own inputs
 def test_reference_literal_inputs_golden(orc):
     """LEAVES4 / LEAVES8 of crypto/src/merkle/tests.rs:13-65 and the polynomial of fri/src/prover/tests.rs:58-69 as
