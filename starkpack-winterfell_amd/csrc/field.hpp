@@ -93,16 +93,31 @@ struct F64 {
         return a < b ? r - 0xFFFFFFFFull : r;
 #endif
     }
-    // x * 2^K and x * 2^-K for 0 < K <= 32 without a general product (2 is a 192nd root of unity: 2^64 = 2^32 - 1,
+    // x * 2^K (0 < K < 64) and x * 2^-K (0 < K <= 32) without a general product (2 is a 192nd root of unity: 2^64 = 2^32 - 1,
     // 2^96 = -1).  x * 2^K = lo + hi * 2^64 = lo + hi * (2^32 - 1); x * 2^-K = (x >> K) - (x mod 2^K) * 2^(96 - K)
     // = q - m * (2^32 - 1) with m = (x mod 2^K) << (32 - K).  9 VALU each against 17 for mul; Montgomery form is
     // preserved because the factor is a plain integer.
+    // 32 < K < 64 (K = 32 + M): x 2^M = y2:y1:y0 in 32-bit words (y2 < 2^M), and with 2^64 = 2^32 - 1, 2^96 = -1
+    //     x 2^K = y0 2^32 + y1 2^64 + y2 2^96 = (y0 + y1) 2^32 - (y1 + y2).
+    // y0 + y1 = ah + k 2^32: k 2^64 = k (2^32 - 1) makes the minuend A = ah:(k ? ffffffff : 0); k = 1 needs
+    // ah = y0 + y1 - 2^32 <= (2^32 - 2^M) + (2^32 - 1) - 2^32 < ffffffff, and k = 0 gives ah:0 <= ffffffff00000000, so A < p
+    // either way; the subtrahend y1 + y2 < 2^33 < p: one canonical subtraction finishes.  12 VALU, 7 of them single-word.
     template <int K>
     static WF_HD T mul_pow2(T x) {
-        static_assert(K > 0 && K <= 32, "shift out of range");
-        const uint64_t lo = x << K;
-        const uint64_t hi = x >> (64 - K);
-        return add(lo, (hi << 32) - hi);  // add() reduces any 64-bit lo correctly here: see the bound in DESIGN.md §4
+        static_assert(K > 0 && K < 64, "shift out of range");
+        if constexpr (K <= 32) {
+            const uint64_t lo = x << K;
+            const uint64_t hi = x >> (64 - K);
+            return add(lo, (hi << 32) - hi);  // add() reduces any 64-bit lo correctly here: see the bound in DESIGN.md §4
+        } else {
+            constexpr int M = K - 32;
+            const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32);
+            const uint32_t y0 = x0 << M, y1 = (x1 << M) | (x0 >> (32 - M)), y2 = x1 >> (32 - M);
+            uint32_t ah, bl;
+            const uint32_t k = __builtin_add_overflow(y0, y1, &ah);
+            const uint32_t kb = __builtin_add_overflow(y1, y2, &bl);
+            return sub(((uint64_t)ah << 32) | (0u - k), ((uint64_t)kb << 32) | bl);
+        }
     }
     template <int K>
     static WF_HD T div_pow2(T x) {

@@ -190,20 +190,27 @@ __host__ __device__ constexpr uint32_t bitrev4(uint32_t v) {
 // DIR = +1 / -1: the transform is known to be the forward / inverse one over Goldilocks, where w_16 = 2^12
 // (f64/mod.rs:248-264: w_64 = 8), so w_16^j for j = 1, 2 is a left shift, for j = 6, 7 a negated right shift
 // (2^72 = -2^-24, 2^84 = -2^-12), and the inverse constants are w_16^-j = -2^(96 - 12 j); the negation is folded into the
-// preceding subtraction.  j = 3, 4, 5 (2^36, 2^48, 2^60) cost as much shifted as multiplied and use the table.
+// preceding subtraction.  j = 3, 4, 5 (2^36, 2^48, 2^60) are word-aligned shifts (F64::mul_pow2, K > 32): 12 VALU against
+// 17 for the table product, so a transform of known direction needs no radix-16 constants at all.
 // DIR = 0: generic (constants from the table only).
 template <class F, int DIR, int J>
 __device__ __forceinline__ typename F::T radix16_twiddle(typename F::T u, typename F::T t, const typename F::T (&w)[8]) {
-    if constexpr (DIR == 0 || F::FIELD_ID != 1 || (J >= 3 && J <= 5)) {
+    if constexpr (DIR == 0 || F::FIELD_ID != 1) {
         return F::mul(F::sub(u, t), w[J]);
     } else if constexpr (DIR > 0) {
         if constexpr (J == 1) return F::template mul_pow2<12>(F::sub(u, t));
         if constexpr (J == 2) return F::template mul_pow2<24>(F::sub(u, t));
+        if constexpr (J == 3) return F::template mul_pow2<36>(F::sub(u, t));
+        if constexpr (J == 4) return F::template mul_pow2<48>(F::sub(u, t));
+        if constexpr (J == 5) return F::template mul_pow2<60>(F::sub(u, t));
         if constexpr (J == 6) return F::template div_pow2<24>(F::sub(t, u));
         if constexpr (J == 7) return F::template div_pow2<12>(F::sub(t, u));
-    } else {
+    } else {  // w_16^-J = -2^(96 - 12 J)
         if constexpr (J == 1) return F::template div_pow2<12>(F::sub(u, t));
         if constexpr (J == 2) return F::template div_pow2<24>(F::sub(u, t));
+        if constexpr (J == 3) return F::template mul_pow2<60>(F::sub(t, u));
+        if constexpr (J == 4) return F::template mul_pow2<48>(F::sub(t, u));
+        if constexpr (J == 5) return F::template mul_pow2<36>(F::sub(t, u));
         if constexpr (J == 6) return F::template mul_pow2<24>(F::sub(t, u));
         if constexpr (J == 7) return F::template mul_pow2<12>(F::sub(t, u));
     }
@@ -301,8 +308,19 @@ __device__ __forceinline__ void seg_round16(typename F::T *x, const typename F::
     }
 }
 
+// (u - t) * w_4 of a transform of known direction over Goldilocks: w_4 = 2^48 forward, -2^48 inverse (2^96 = -1)
+template <class F, int DIR>
+__device__ __forceinline__ typename F::T mul_w4(typename F::T u, typename F::T t, typename F::T w4) {
+    if constexpr (DIR == 0 || F::FIELD_ID != 1)
+        return F::mul(F::sub(u, t), w4);
+    else if constexpr (DIR > 0)
+        return F::template mul_pow2<48>(F::sub(u, t));
+    else
+        return F::template mul_pow2<48>(F::sub(t, u));
+}
+
 // One radix-4 round (two lanes per work item, 16-byte LDS accesses for f64); w4 = w_4.
-template <class F>
+template <class F, int DIR = 0>
 __device__ __forceinline__ void seg_round4(typename F::T *x, const typename F::T *twd, typename F::T w4, uint32_t logD,
                                            uint32_t cur, uint32_t nthr, uint32_t tid) {
     typedef typename F::T T;
@@ -325,7 +343,7 @@ __device__ __forceinline__ void seg_round4(typename F::T *x, const typename F::T
         P2 y0, y1, y2, y3;
         {
             T a = F::add(x0.a, x2.a), b = F::sub(x0.a, x2.a), c = F::add(x1.a, x3.a);
-            T d = F::mul(F::sub(x1.a, x3.a), w4);
+            T d = mul_w4<F, DIR>(x1.a, x3.a, w4);
             y0.a = F::add(a, c);
             y2.a = F::sub(a, c);
             y1.a = F::add(b, d);
@@ -333,7 +351,7 @@ __device__ __forceinline__ void seg_round4(typename F::T *x, const typename F::T
         }
         {
             T a = F::add(x0.b, x2.b), b = F::sub(x0.b, x2.b), c = F::add(x1.b, x3.b);
-            T d = F::mul(F::sub(x1.b, x3.b), w4);
+            T d = mul_w4<F, DIR>(x1.b, x3.b, w4);
             y0.b = F::add(a, c);
             y2.b = F::sub(a, c);
             y1.b = F::add(b, d);
@@ -398,7 +416,7 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
     if (logD >= 2) w4 = twd[D >> 2];
     while (cur > 0) {
         if (cur >= 2) {
-            seg_round4<F>(x, twd, w4, logD, cur, nthr, threadIdx.x);
+            seg_round4<F, DIR>(x, twd, w4, logD, cur, nthr, threadIdx.x);
             cur -= 2;
         } else {
             seg_round2<F>(x, logD, nthr, threadIdx.x);

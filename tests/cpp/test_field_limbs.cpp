@@ -67,6 +67,11 @@ int main(int argc, char **argv) {
             const uint64_t e12 = (uint64_t)(((u128)x << 12) % P64), e24 = (uint64_t)(((u128)x << 24) % P64);
             const uint64_t e32 = (uint64_t)(((u128)x << 32) % P64);
             if (F64::mul_pow2<12>(x) != e12 || F64::mul_pow2<24>(x) != e24 || F64::mul_pow2<32>(x) != e32) bad++;
+            // the word-aligned middle range (K > 32: 2^36, 2^48 = w_4, 2^60 of the radix-16 block, and the range's ends)
+            if (F64::mul_pow2<33>(x) != (uint64_t)((((u128)x << 33) % P64)) || F64::mul_pow2<36>(x) != (uint64_t)(((u128)x << 36) % P64) ||
+                F64::mul_pow2<48>(x) != (uint64_t)(((u128)x << 48) % P64) || F64::mul_pow2<60>(x) != (uint64_t)(((u128)x << 60) % P64) ||
+                F64::mul_pow2<63>(x) != (uint64_t)(((u128)x << 63) % P64))
+                bad++;
             const uint64_t d12 = F64::div_pow2<12>(x), d24 = F64::div_pow2<24>(x), d32 = F64::div_pow2<32>(x);
             if ((uint64_t)(((u128)d12 << 12) % P64) != x || d12 >= F64::P) bad++;
             if ((uint64_t)(((u128)d24 << 24) % P64) != x || d24 >= F64::P) bad++;
@@ -75,7 +80,9 @@ int main(int argc, char **argv) {
         const uint64_t edge[] = {0, 1, 2, 0xFFF, 0x1000, 0xFFFFFF, 0x1000000, 0xFFFFFFFFull, 0x100000000ull,
                                  0xFFFFFFFF00000000ull, 0xFFFFFFFEFFFFFFFFull, 0xFFFFFFFF00000000ull - 1, F64::P - 1,
                                  F64::P - 2, F64::P - 0x1000, 0xFFFFF00000000000ull, 0x000FFFFFFFFFFFFFull,
-                                 0xFFF0000000000001ull % F64::P, 0x8000000000000000ull, 0x7FFFFFFFFFFFFFFFull};
+                                 0xFFF0000000000001ull % F64::P, 0x8000000000000000ull, 0x7FFFFFFFFFFFFFFFull,
+                                 0x0000FFFFFFFFFFFFull, 0x0000FFFF0000FFFFull, 0xFFFF0000FFFFFFFFull % F64::P, 0x00000000FFFF0000ull,
+                                 0x0FFFFFFFFFFFFFFFull, 0xFFFFFFFFull << 4, 0xFFFFFFFFull << 16, 0xFFFFFFFFull << 28};
         for (uint64_t e : edge) chk(e % F64::P);
         for (long it = 0; it < iters; it++) chk(rnd() % F64::P);
     }

@@ -250,6 +250,7 @@ def test_sharded_resident_commitment_and_collective_queries(orc, capi, field, lo
     positions = np.union1d(rng.integers(0, N, size=24), [0, N - 1]).astype(np.uint64)   # distinct, both ends included
     rng.shuffle(positions)
     z = rand_cols(rng, field, 1, 1)[0]
+    cc = rand_cols(rng, field, 1, n_cols * n_traces)[0]
     lb = Loopback(world)
 
     def rank_fn(r):
@@ -267,17 +268,23 @@ def test_sharded_resident_commitment_and_collective_queries(orc, capi, field, lo
             except capi.WfError as e:
                 codes.append(e.code)
         ood = com.polys().evaluate_polys_at(z, 1, n_cols * n_traces)
+        # the DEEP composition needs no exchange either: every rank holds the complete polynomials
+        deep = ctx.deep_compose(field, 1, R, [com.polys()], None, z, cc)
         com.close()
         comm.close()
         ctx.close()
-        return root, rows, proof, rows1, proof1, codes, ood
+        return root, rows, proof, rows1, proof1, codes, ood, deep
 
     pos = positions.astype(np.int64)
     want_rows = np.concatenate([want["lde"][t][pos][:, :n_cols] for t in range(n_traces)], axis=1)
     want_proof = orc.merkle_prove_batch(want["nodes"], want["leaves"], [int(p) for p in positions])
     want_proof1 = orc.merkle_prove_batch(want["nodes"], want["leaves"], [int(positions[0])])
     want_ood = np.stack([orc.eval_column_at(field, c, 1, z, 1) for t in want["polys"] for c in t])
-    for root, rows, proof, rows1, proof1, codes, ood in run_ranks(world, rank_fn):
+    w = 1 if field == F64 else 2
+    want_deep = orc.deep_compose(field, 1, R, [[(c, 1) for c in t] for t in want["polys"]], [], z,
+                                 list(cc.reshape(n_cols * n_traces, -1) if w > 1 else cc.reshape(-1, 1)), [])
+    for root, rows, proof, rows1, proof1, codes, ood, deep in run_ranks(world, rank_fn):
+        assert np.array_equal(deep, want_deep)
         assert root == want["root"]
         assert np.array_equal(rows.reshape(want_rows.shape), want_rows)
         assert proof == want_proof
