@@ -162,6 +162,9 @@ struct SegArgs {
     uint32_t *chunk_cvs;       // k_seg_last_hash<.., CHUNKED>: [LDE row][n_chunks][8] chunk chaining values (rows > 1024 bytes)
     uint32_t n_chunks;         //   ceil(n_seg / 16): a BLAKE3 chunk is 16 blocks = 16 segments of a row
     uint32_t *tile_counters;   // k_seg_last_hash: 8 ticket + 8 exit counters, one per XCD, zero between launches (self-resetting)
+#ifdef WF_EXP_STAMPS
+    unsigned long long *stamps;  // diagnostic build only: per work-group phase cycle sums of k_seg_last_hash (8 words each)
+#endif
 };
 
 // LDS position -> output index of seg_lds_ntt: radix-16 digits while >= 4 bits remain, then radix-4, then radix-2
@@ -1195,6 +1198,18 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512))
         q7 = s_[7 * step];                                          \
     } while (0)
     WF_TILE_LOAD(src, threadIdx.x);
+#ifdef WF_EXP_STAMPS
+    unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0}, st_t0, st_t1;
+#define WF_STAMP(i)                                   \
+    do {                                              \
+        st_t1 = __builtin_amdgcn_s_memtime();         \
+        st_acc[i] += st_t1 - st_t0;                   \
+        st_t0 = st_t1;                                \
+    } while (0)
+    st_t0 = __builtin_amdgcn_s_memtime();
+#else
+#define WF_STAMP(i)
+#endif
 
     while (true) {
         {
@@ -1209,7 +1224,9 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512))
             d_[7 * step] = q7;
         }
         __syncthreads();
+        WF_STAMP(0);  // tile in LDS (waits for the prefetched rows)
         seg_lds_ntt<F, 1>(x, twd, a.logD, NT);
+        WF_STAMP(1);  // transform
 
         // row stores: lane pair (2l, 2l+1) of row position pos -> its place in LDE row k * rows_per_k + c of its trace
         {
@@ -1243,9 +1260,19 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512))
                 const uint32_t k0 = seg_digit_reverse<F>(pos0, a.logD);
                 const bool tail = F::BYTES == 16 && a.tail_pad && g + 1 == a.n_seg;  // (single trace: every lane has its pa)
                 for (uint32_t pj = 0; pj < D; pj += pstride) {
+#if defined(WF_EXP_LOCAL_STORE) && WF_EXP_LOCAL_STORE == 1  // diagnostic (wrong output): rows of a tile next to each other, cosets interleaved
+                    const uint64_t k = (o << a.logD) + pos0 + pj;
+#elif defined(WF_EXP_LOCAL_STORE)  // diagnostic (wrong output): the tile written as one contiguous 64 KiB run
+                    const uint64_t k = 0;
+#else
                     const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, a.logD)) << out_shift);
+#endif
                     const P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
+#if defined(WF_EXP_LOCAL_STORE) && WF_EXP_LOCAL_STORE == 2
+                    const uint64_t off = (((uint64_t)c * a.O + o) << a.logD) * S + (uint64_t)(pos0 + pj) * S - (uint64_t)c * a.row_width;
+#else
                     const uint64_t off = (uint64_t)(uint32_t)k * k_stride;
+#endif
                     if (pair) {
                         store_pair(pa + off, v);
                     } else {
@@ -1259,6 +1286,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512))
             }
         }
 
+        WF_STAMP(2);  // row stores issued
         // the next tile -- the next segment of this row block, or the first one of a new ticket -- starts its way into
         // registers; it lands while the leaves are hashed
         bool more = true;
@@ -1276,6 +1304,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512))
             WF_TILE_LOAD(src, opaque_tid());
         }
 
+        WF_STAMP(3);  // ticket + next tile requested
         // block g of the rows' messages: one lane per row position, two rows per lane (tid and tid + D/2); the S lanes
         // of a tile row are its 64 message bytes (lanes past the last column are zero), canonical as in hash_elements
         {
@@ -1305,8 +1334,15 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512))
                 b3::compress(cv, m, ch, 0, blen, flags);  // counter = chunk index
                 const uint4 lo = make_uint4(cv[0], cv[1], cv[2], cv[3]), hi = make_uint4(cv[4], cv[5], cv[6], cv[7]);
                 if (last) {
+#if defined(WF_EXP_LOCAL_STORE) && WF_EXP_LOCAL_STORE == 1
+                    const uint64_t k = (o << a.logD) + pos;
+                    const uint64_t row = (uint64_t)(uint32_t)k * a.rows_per_k + c;
+#elif defined(WF_EXP_LOCAL_STORE)
+                    const uint64_t row = (((uint64_t)c * a.O + o) << a.logD) + pos;
+#else
                     const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << out_shift);
                     const uint64_t row = (uint64_t)(uint32_t)k * a.rows_per_k + c;
+#endif
                     uint4 *dl = reinterpret_cast<uint4 *>(CHUNKED ? a.chunk_cvs + (row * n_chunks + ch) * 8 : a.leaves + row * 8);
                     dl[0] = lo;
                     dl[1] = hi;
@@ -1319,20 +1355,30 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512))
                 }
             }
         }
+        WF_STAMP(4);  // hashing
+#ifdef WF_EXP_STAMPS
+        st_acc[6]++;
+#endif
         if (!more) {
             sign_off();
             break;
         }
         __syncthreads();  // x is rewritten by the next tile
+        WF_STAMP(5);  // end-of-tile barrier
         c = cn;
         g = MULTI ? gn : 0;
         ch = chn;
         o = on;
         rev_o = rev_on;
     }
+#ifdef WF_EXP_STAMPS
+    if (threadIdx.x == 0 && a.stamps)
+        for (int i = 0; i < 7; i++) atomicAdd(a.stamps + (size_t)blockIdx.x * 8 + i, st_acc[i]);
+#endif
 }
 
 #undef WF_TILE_LOAD
+#undef WF_STAMP
 
 // ---------------------------------------------------------------------------------------------------------------
 // Layout changes between the caller's columns ([col][row][ext coordinate]) and segments.

@@ -438,6 +438,21 @@ static int series_tables(wf_ctx *ctx, uint32_t logN, typename F::T offset, uint6
     return 0;
 }
 
+#ifdef WF_EXP_STAMPS
+// diagnostic build (scripts/last_pass_phases.py): cycle sums per work-group and phase of the persistent last pass
+static unsigned long long *g_exp_stamps = nullptr;
+static unsigned long long *exp_stamps_buffer() {
+    if (!g_exp_stamps && hipMalloc(&g_exp_stamps, 4096 * 8 * 8) == hipSuccess) (void)hipMemset(g_exp_stamps, 0, 4096 * 8 * 8);
+    return g_exp_stamps;
+}
+extern "C" int wf_exp_stamps_read(unsigned long long *out, int clear) {
+    if (!g_exp_stamps) return -1;
+    if (hipMemcpy(out, g_exp_stamps, 4096 * 8 * 8, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    if (clear) (void)hipMemset(g_exp_stamps, 0, 4096 * 8 * 8);
+    return 0;
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------- planner
 struct Plan {
     int n_pass;
@@ -846,6 +861,9 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
                 HIP_TRY(hipMemsetAsync(ctx->tickets.p, 0, 64, st));  // ordered on the launch stream (first use only)
             }
             a.tile_counters = (uint32_t *)ctx->tickets.p;
+#ifdef WF_EXP_STAMPS
+            a.stamps = exp_stamps_buffer();
+#endif
             void *kargs[] = {&a};
             HIP_TRY(hipLaunchKernel(kern, dim3((uint32_t)std::min<uint64_t>(tickets, resident)), dim3(threads), kargs, lds_p, st));
             if (chunked) {
