@@ -312,6 +312,23 @@ int wf_commitment_prove_batch(const wf_commitment *c, const uint64_t *positions,
 int wf_commitment_query(const wf_commitment *c, const uint64_t *positions, size_t n, void *rows_out, uint8_t *leaves_out,
                         uint8_t *nodes_out, size_t nodes_capacity, uint32_t *node_counts, size_t *n_vectors, size_t *n_nodes,
                         uint32_t *depth_out);
+/* The same for several commitments of ONE context in one host round trip (a proof queries the trace tree, the constraint tree
+ * and every FRI layer -- prover/src/lib.rs:593-602, fri/src/prover/mod.rs:244-282 -- ten calls otherwise, ~0.15 ms each):
+ * one upload of every position list, the gathers of all commitments, one download, one synchronisation.  Per query the
+ * arguments of wf_commitment_query (rows_out may be NULL: proof only); n_vectors, n_nodes and depth are outputs.  The first
+ * failing query fails the call with its status and nothing is written. */
+typedef struct wf_query {
+    const wf_commitment *commitment;
+    const uint64_t *positions;
+    size_t n;
+    void *rows_out;
+    uint8_t *leaves_out, *nodes_out;
+    size_t nodes_capacity;
+    uint32_t *node_counts;
+    size_t n_vectors, n_nodes;
+    uint32_t depth;
+} wf_query;
+int wf_commitment_query_many(wf_query *queries, size_t n_queries);
 
 /* ---- FRI layer commitments ---------------------------------------------------------------------- */
 

@@ -518,10 +518,17 @@ class FriProver {
     // build_proof (prover/mod.rs:244-282): every layer queried at the folded positions; resets the prover like the reference
     std::pair<std::vector<FriProofLayer>, std::vector<E>> build_proof(const std::vector<size_t> &positions) {
         if (remainder_.empty()) throw std::logic_error("FRI layers have not been built yet");
-        std::vector<FriProofLayer> layers;
+        // positions of every layer first (host arithmetic), then ONE round trip to the device for all layers
+        const size_t n_layers = num_layers();
+        std::vector<FriProofLayer> layers(n_layers);
+        std::vector<std::vector<uint64_t>> flat(n_layers);
+        std::vector<std::vector<Digest>> nodes(n_layers);
+        std::vector<std::vector<uint32_t>> counts(n_layers);
+        std::vector<size_t> words(n_layers);
+        std::vector<wf_query> queries(n_layers);
         std::vector<uint64_t> pos(positions.begin(), positions.end());
         size_t domain = domain_size_;
-        for (size_t i = 0; i < num_layers(); i++) {
+        for (size_t i = 0; i < n_layers; i++) {
             std::vector<uint64_t> folded(pos.size());
             size_t m = 0;
             wf_check(wf_fri_fold_positions(pos.data(), pos.size(), domain, (uint32_t)options_.folding_factor, folded.data(), &m));
@@ -531,27 +538,36 @@ class FriProver {
             uint64_t n_rows = 0, row_elems = 0;
             uint32_t depth = 0;
             wf_check(wf_commitment_info(layer, &n_rows, &row_elems, &depth));
-            const size_t words = row_elems * (sizeof(typename E::BaseField) / 8);
-            std::vector<uint64_t> flat(m * words);
-            FriProofLayer pl;
-            pl.positions = folded;
-            pl.proof.leaves.resize(m);
-            std::vector<Digest> nodes(m * (depth + 1));
-            std::vector<uint32_t> counts(m);
-            size_t n_vec = 0, n_nodes = 0;
-            uint32_t d = 0;
-            wf_check(wf_commitment_query(layer, folded.data(), m, flat.data(), m ? pl.proof.leaves[0].data() : nullptr, m ? nodes[0].data() : nullptr,
-                                         nodes.size(), counts.data(), &n_vec, &n_nodes, &d));
-            for (size_t j = 0; j < m; j++) pl.values.emplace_back(flat.begin() + j * words, flat.begin() + (j + 1) * words);
-            size_t k = 0;
-            for (size_t v = 0; v < n_vec; v++) {
-                pl.proof.nodes.emplace_back(nodes.begin() + k, nodes.begin() + k + counts[v]);
-                k += counts[v];
-            }
-            pl.proof.depth = (uint8_t)d;
-            layers.push_back(std::move(pl));
+            words[i] = row_elems * (sizeof(typename E::BaseField) / 8);
+            flat[i].resize(m * words[i]);
+            layers[i].positions = folded;
+            layers[i].proof.leaves.resize(m);
+            nodes[i].resize(m * (depth + 1));
+            counts[i].resize(m);
+            wf_query &q = queries[i];
+            std::memset(&q, 0, sizeof(q));
+            q.commitment = layer;
+            q.positions = layers[i].positions.data();
+            q.n = m;
+            q.rows_out = flat[i].data();
+            q.leaves_out = m ? layers[i].proof.leaves[0].data() : nullptr;
+            q.nodes_out = m ? nodes[i][0].data() : nullptr;
+            q.nodes_capacity = nodes[i].size();
+            q.node_counts = counts[i].data();
             pos = folded;
             domain /= options_.folding_factor;
+        }
+        if (n_layers) wf_check(wf_commitment_query_many(queries.data(), n_layers));
+        for (size_t i = 0; i < n_layers; i++) {
+            FriProofLayer &pl = layers[i];
+            const size_t m = pl.positions.size();
+            for (size_t j = 0; j < m; j++) pl.values.emplace_back(flat[i].begin() + j * words[i], flat[i].begin() + (j + 1) * words[i]);
+            size_t k = 0;
+            for (size_t v = 0; v < queries[i].n_vectors; v++) {
+                pl.proof.nodes.emplace_back(nodes[i].begin() + k, nodes[i].begin() + k + counts[i][v]);
+                k += counts[i][v];
+            }
+            pl.proof.depth = (uint8_t)queries[i].depth;
         }
         std::vector<E> remainder = remainder_;
         reset();

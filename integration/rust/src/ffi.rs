@@ -31,6 +31,22 @@ pub struct WfCtx {
 pub struct WfCommitment {
     _private: [u8; 0],
 }
+/// `wf_query` of `wf_lde.h`: one commitment's share of a batched query.
+#[repr(C)]
+pub struct WfQuery {
+    pub commitment: *const WfCommitment,
+    pub positions: *const u64,
+    pub n: usize,
+    pub rows_out: *mut c_void,
+    pub leaves_out: *mut u8,
+    pub nodes_out: *mut u8,
+    pub nodes_capacity: usize,
+    pub node_counts: *mut u32,
+    pub n_vectors: usize,
+    pub n_nodes: usize,
+    pub depth: u32,
+}
+
 #[repr(C)]
 pub struct WfFriProver {
     _private: [u8; 0],
@@ -77,6 +93,7 @@ extern "C" {
     pub fn wf_commitment_read_lde(
         c: *const WfCommitment, trace: u32, row_begin: u64, n_rows: u64, rows_out: *mut c_void, row_width_out: *mut u64,
     ) -> c_int;
+    pub fn wf_commitment_query_many(queries: *mut WfQuery, n_queries: usize) -> c_int;
     pub fn wf_deep_compose(
         ctx: *mut WfCtx, trace_commitments: *const *const WfCommitment, n_trace_commitments: usize,
         constraint_commitment: *const WfCommitment, z: *const c_void, ext_degree: u32, trace_coeffs: *const c_void,

@@ -42,14 +42,13 @@ for rep in range(4):
         fri.fold(alphas[i])
     fri.set_remainder(1 << 12)
     t.append(time.perf_counter())
-    tcom.query(pos)
-    ccom.query(pos)
+    requests = [(tcom, pos, True), (ccom, pos, True)]
     p, size = pos, N
     for i in range(n_layers):
         p = capi.fri_fold_positions(p, size, folding)
-        lay = fri.layer(i)
-        lay.query(p)
+        requests.append((fri.layer(i), p, True))
         size //= folding
+    capi.query_many(requests, parse=False)               # every tree in one round trip (C call only)
     t.append(time.perf_counter())
     fri.reset(); tcom.close(); ccom.close()
     t.append(time.perf_counter())

@@ -22,7 +22,7 @@ SYMBOLS = [
     "wf_ctx_release_cached", "wf_plan_digits", "wf_commitment_query", "wf_ctx_profile_enable", "wf_ctx_profile_read", "wf_params_check", "wf_elem_bytes", "wf_row_width", "wf_column_bytes", "wf_lde_bytes", "wf_digests_bytes",
     "wf_trace_commit", "wf_constraint_commit", "wf_trace_commit_dev", "wf_constraint_commit_dev",
     "wf_trace_commit_shard_dev", "wf_merkle_build_dev", "wf_trace_commit_resident", "wf_constraint_commit_resident", "wf_commitment_destroy", "wf_commitment_root",
-    "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_read_lde", "wf_deep_compose", "wf_commitment_prove", "wf_commitment_prove_batch",
+    "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_read_lde", "wf_deep_compose", "wf_commitment_query_many", "wf_commitment_prove", "wf_commitment_prove_batch",
     "wf_evaluate_columns_at", "wf_commitment_evaluate_polys_at", "wf_fri_layer_commit", "wf_fri_apply_drp", "wf_fri_layer_commit_dev", "wf_fri_apply_drp_dev",
     "wf_fri_prover_create", "wf_fri_prover_destroy", "wf_fri_num_layers", "wf_fri_prover_begin", "wf_fri_prover_begin_dev", "wf_fri_prover_begin_poly",
     "wf_fri_prover_commit_layer", "wf_fri_prover_fold", "wf_fri_prover_set_remainder", "wf_fri_prover_num_layers",
@@ -57,6 +57,13 @@ TRANSPORT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size
 class Transport(C.Structure):
     """wf_transport: caller-supplied collectives (device pointers)."""
     _fields_ = [("user", C.c_void_p), ("all_gather", TRANSPORT_FN), ("all_to_all", TRANSPORT_FN)]
+
+
+class Query(C.Structure):
+    """wf_query (include/wf_lde.h): one commitment's share of wf_commitment_query_many."""
+    _fields_ = [("commitment", C.c_void_p), ("positions", C.c_void_p), ("n", C.c_size_t), ("rows_out", C.c_void_p),
+                ("leaves_out", C.c_void_p), ("nodes_out", C.c_void_p), ("nodes_capacity", C.c_size_t),
+                ("node_counts", C.c_void_p), ("n_vectors", C.c_size_t), ("n_nodes", C.c_size_t), ("depth", C.c_uint32)]
 
 
 def make_params(field, ext_degree, log2_trace_len, log2_blowup, n_cols, n_traces=1, offset=None) -> Params:
@@ -139,6 +146,7 @@ def load():
         L.wf_commitment_read_rows.argtypes = [vp, vp, sz, vp]
         L.wf_commitment_read_lde.argtypes = [vp, u32, C.c_uint64, C.c_uint64, vp, C.POINTER(C.c_uint64)]
         L.wf_deep_compose.argtypes = [vp, vp, C.c_size_t, vp, vp, u32, vp, vp, vp, vp, C.c_size_t]
+        L.wf_commitment_query_many.argtypes = [C.POINTER(Query), C.c_size_t]
         L.wf_commitment_prove.argtypes = [vp, C.c_uint64, vp]
         L.wf_commitment_prove_batch.argtypes = [vp, vp, sz, vp, vp, sz, vp, C.POINTER(sz), C.POINTER(sz),
                                                 C.POINTER(u32)]
@@ -562,6 +570,38 @@ class Commitment:
             out.append([bytes(nodes[k + j]) for j in range(int(counts[i]))])
             k += int(counts[i])
         return rows, ([bytes(x) for x in leaves[:n]], out, depth.value)
+
+
+def query_many(requests, parse=True):
+    """wf_commitment_query_many: [(commitment, positions, want_rows)] of one context answered in one host round trip;
+    returns [(rows or None, (leaves, nodes, depth))] like Commitment.query / prove_batch (parse=False: the raw output
+    arrays, for timing the call without the Python-side unpacking)."""
+    qs = (Query * len(requests))()
+    keep = []
+    for q, (com, positions, want_rows) in zip(qs, requests):
+        pos = np.ascontiguousarray(positions, dtype=np.uint64)
+        n = len(pos)
+        w = ELEM_WORDS[com.field]
+        rows = np.empty((n, com.row_elems, w) if w > 1 else (n, com.row_elems), dtype=np.uint64) if want_rows else None
+        cap = max(1, n) * (com.depth + 1)
+        leaves = np.empty((max(1, n), 32), dtype=np.uint8)
+        nodes = np.empty((cap, 32), dtype=np.uint8)
+        counts = np.zeros(max(1, n), dtype=np.uint32)
+        q.commitment, q.positions, q.n = com._h, _p(pos), n
+        q.rows_out = _p(rows) if rows is not None else None
+        q.leaves_out, q.nodes_out, q.nodes_capacity, q.node_counts = _p(leaves), _p(nodes), cap, _p(counts)
+        keep.append((pos, rows, leaves, nodes, counts))
+    _check(load().wf_commitment_query_many(qs, len(requests)))
+    if not parse:
+        return keep
+    out = []
+    for q, (pos, rows, leaves, nodes, counts) in zip(qs, keep):
+        vecs, k = [], 0
+        for i in range(q.n_vectors):
+            vecs.append([bytes(nodes[k + j]) for j in range(int(counts[i]))])
+            k += int(counts[i])
+        out.append((rows, ([bytes(x) for x in leaves[:len(pos)]], vecs, int(q.depth))))
+    return out
 
 
 def plan_digits(field: int, log2_n: int, n_segments: int = 1):

@@ -78,6 +78,8 @@ struct wf_ctx {
     size_t pool_bytes = 0, pool_cap = (size_t)64 << 30;
     void *pin = nullptr;  // pinned host staging for uploads of many small columns (upload_columns)
     size_t pin_cap = 0;
+    void *qpin = nullptr;  // pinned staging of the query service (ids up, rows and digests back)
+    size_t qpin_cap = 0;
     // One call at a time: the thread inside an entry point (0 = none) and its nesting depth.  A second thread entering
     // while a call is in progress gets WF_ERR_BUSY instead of corrupting scratch and ticket counters.
     std::atomic<uintptr_t> owner{0};
@@ -1240,6 +1242,7 @@ void wf_ctx_destroy(wf_ctx *ctx) {
     if (ctx->tickets.p) (void)hipFree(ctx->tickets.p);
     for (auto &b : ctx->pool) (void)hipFree(b.first);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
+    if (ctx->qpin) (void)hipHostFree(ctx->qpin);
     for (auto e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
     (void)hipStreamDestroy(ctx->stream);
@@ -1693,60 +1696,128 @@ static int batch_proof_ids(const wf_commitment *c, const uint64_t *positions, si
     return 0;
 }
 
+// Several commitments of one context queried in one host round trip: every id list goes up in one copy from pinned
+// memory, the gathers of all commitments are queued, one copy brings rows and digests back, one synchronisation.
+// (A proof queries the trace tree, the constraint tree and every FRI layer: ten calls of ~0.15 ms each otherwise.)
+static int query_many_impl(wf_query *q, size_t nq) {
+    if (!q || nq == 0) return fail(WF_ERR_ARG, "no queries");
+    wf_ctx *ctx = nullptr;
+    for (size_t i = 0; i < nq; i++) {
+        int rc = check_positions(q[i].commitment, q[i].positions, q[i].n);
+        if (rc) return rc;
+        if (!q[i].leaves_out || !q[i].nodes_out || !q[i].node_counts) return fail(WF_ERR_ARG, "query %zu: null output", i);
+        if (!ctx) ctx = q[i].commitment->ctx;
+        if (q[i].commitment->ctx != ctx) return fail(WF_ERR_ARG, "query %zu: the commitments belong to different contexts", i);
+        if (q[i].rows_out && !q[i].commitment->lde) return fail(WF_ERR_LEAVES, "query %zu: this commitment holds no rows", i);
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
+    struct Part {
+        std::vector<std::vector<uint64_t>> vec_ids;
+        size_t total = 0, n_ids = 0, ids_off = 0, rows_off = 0, rows_bytes = 0, dig_off = 0;
+    };
+    std::vector<Part> parts(nq);
+    size_t ids_total = 0, out_total = 0;
+    for (size_t i = 0; i < nq; i++) {
+        const wf_commitment *c = q[i].commitment;
+        Part &pt = parts[i];
+        int rc = batch_proof_ids(c, q[i].positions, q[i].n, pt.vec_ids, pt.total);
+        if (rc) return rc;
+        if (pt.total > q[i].nodes_capacity) return fail(WF_ERR_ARG, "query %zu: nodes_out too small: %zu digests needed", i, pt.total);
+        pt.n_ids = q[i].n + pt.total;  // the queried leaves first: also the positions of the row gather
+        pt.ids_off = ids_total;
+        ids_total += pt.n_ids;
+        pt.rows_bytes = q[i].rows_out ? q[i].n * c->row_elems * wf_elem_bytes(c->p.field) : 0;
+        pt.rows_off = out_total;
+        out_total += (pt.rows_bytes + 255) & ~(size_t)255;
+        pt.dig_off = out_total;
+        out_total += (pt.n_ids * 32 + 255) & ~(size_t)255;
+    }
+    const size_t ids_bytes = (ids_total * 8 + 255) & ~(size_t)255;
+    int rc;
+    if ((rc = ensure(ctx, ctx->io[3], ids_bytes))) return rc;
+    if ((rc = ensure(ctx, ctx->io[4], out_total))) return rc;
+    if (ctx->qpin_cap < ids_bytes + out_total) {
+        if (ctx->qpin) (void)hipHostFree(ctx->qpin);
+        ctx->qpin = nullptr;
+        ctx->qpin_cap = 0;
+        const size_t want = std::max<size_t>(2 * (ids_bytes + out_total), (size_t)1 << 20);
+        if (hipHostMalloc(&ctx->qpin, want, hipHostMallocDefault) != hipSuccess)
+            return fail(WF_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(hipGetLastError()));
+        ctx->qpin_cap = want;
+    }
+    uint64_t *h_ids = (uint64_t *)ctx->qpin;
+    char *h_out = (char *)ctx->qpin + ids_bytes;
+    for (size_t i = 0; i < nq; i++) {
+        uint64_t *d = h_ids + parts[i].ids_off;
+        memcpy(d, q[i].positions, q[i].n * 8);
+        d += q[i].n;
+        for (auto &v : parts[i].vec_ids) {
+            memcpy(d, v.data(), v.size() * 8);
+            d += v.size();
+        }
+    }
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->io[3].p, h_ids, ids_total * 8, hipMemcpyHostToDevice, st));
+    for (size_t i = 0; i < nq; i++) {
+        const wf_commitment *c = q[i].commitment;
+        const Part &pt = parts[i];
+        const uint64_t *d_ids = (const uint64_t *)ctx->io[3].p + pt.ids_off;
+        const uint32_t n = (uint32_t)q[i].n;
+        if (q[i].rows_out) {
+            const uint64_t trace_elems = c->n_rows * c->row_width;
+            if (c->p.field == WF_FIELD_F64)
+                hipLaunchKernelGGL(k_gather_rows<F64>, dim3(n, c->p.n_traces), dim3(64), 0, st, (const uint64_t *)c->lde, trace_elems,
+                                   (uint32_t)c->row_width, (uint32_t)c->epr, d_ids, (uint64_t *)((char *)ctx->io[4].p + pt.rows_off));
+            else
+                hipLaunchKernelGGL(k_gather_rows<F128>, dim3(n, c->p.n_traces), dim3(64), 0, st, (const U128 *)c->lde, trace_elems,
+                                   (uint32_t)c->row_width, (uint32_t)c->epr, d_ids, (U128 *)((char *)ctx->io[4].p + pt.rows_off));
+            HIP_TRY(hipGetLastError());
+        }
+        const uint32_t nid = (uint32_t)pt.n_ids;
+        hipLaunchKernelGGL(k_gather_digests, dim3((2 * nid + 255) / 256), dim3(256), 0, st, (const uint4 *)c->leaves,
+                           (const uint4 *)c->nodes, c->n_rows, d_ids, nid, (uint4 *)((char *)ctx->io[4].p + pt.dig_off));
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(h_out, ctx->io[4].p, out_total, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t i = 0; i < nq; i++) {
+        const Part &pt = parts[i];
+        if (q[i].rows_out) memcpy(q[i].rows_out, h_out + pt.rows_off, pt.rows_bytes);
+        memcpy(q[i].leaves_out, h_out + pt.dig_off, q[i].n * 32);
+        memcpy(q[i].nodes_out, h_out + pt.dig_off + q[i].n * 32, pt.total * 32);
+        for (size_t v = 0; v < pt.vec_ids.size(); v++) q[i].node_counts[v] = (uint32_t)pt.vec_ids[v].size();
+        q[i].n_vectors = pt.vec_ids.size();
+        q[i].n_nodes = pt.total;
+        q[i].depth = q[i].commitment->depth;
+    }
+    return 0;
+}
+
 // rows_out == nullptr: the proof only
 static int query_impl(const wf_commitment *c, const uint64_t *positions, size_t n, void *rows_out, uint8_t *leaves_out,
                       uint8_t *nodes_out, size_t nodes_capacity, uint32_t *node_counts, size_t *n_vectors, size_t *n_nodes,
                       uint32_t *depth_out) {
-    int rc = check_positions(c, positions, n);
+    if (!n_vectors || !n_nodes) return fail(WF_ERR_ARG, "null argument");
+    wf_query q;
+    memset(&q, 0, sizeof(q));
+    q.commitment = c;
+    q.positions = positions;
+    q.n = n;
+    q.rows_out = rows_out;
+    q.leaves_out = leaves_out;
+    q.nodes_out = nodes_out;
+    q.nodes_capacity = nodes_capacity;
+    q.node_counts = node_counts;
+    int rc = query_many_impl(&q, 1);
     if (rc) return rc;
-    if (!leaves_out || !nodes_out || !node_counts || !n_vectors || !n_nodes) return fail(WF_ERR_ARG, "null argument");
-    wf_ctx *ctx = c->ctx;
-    HIP_TRY(hipSetDevice(ctx->device));
-    WF_ENTER(ctx, ctx->stream);
-    std::vector<std::vector<uint64_t>> vec_ids;
-    size_t total = 0;
-    if ((rc = batch_proof_ids(c, positions, n, vec_ids, total))) return rc;
-    if (total > nodes_capacity) return fail(WF_ERR_ARG, "nodes_out too small: %zu digests needed", total);
-    std::vector<uint64_t> ids(positions, positions + n);  // the queried leaves first: also the positions of the row gather
-    for (auto &v : vec_ids) ids.insert(ids.end(), v.begin(), v.end());
-    // one upload, the gathers, one download, one synchronisation
-    const size_t eb = wf_elem_bytes(c->p.field);
-    const size_t rows_bytes = rows_out ? ((n * c->row_elems * eb + 255) & ~(size_t)255) : 0, dig_bytes = ids.size() * 32;
-    if ((rc = ensure(ctx, ctx->io[3], ids.size() * 8))) return rc;
-    if ((rc = ensure(ctx, ctx->io[4], rows_bytes + dig_bytes))) return rc;
-    hipStream_t st = ctx->stream;
-    HIP_TRY(hipMemcpyAsync(ctx->io[3].p, ids.data(), ids.size() * 8, hipMemcpyHostToDevice, st));
-    if (rows_out && n) {
-        const uint64_t trace_elems = c->n_rows * c->row_width;
-        if (c->p.field == WF_FIELD_F64)
-            hipLaunchKernelGGL(k_gather_rows<F64>, dim3((uint32_t)n, c->p.n_traces), dim3(64), 0, st, (const uint64_t *)c->lde,
-                               trace_elems, (uint32_t)c->row_width, (uint32_t)c->epr, (const uint64_t *)ctx->io[3].p,
-                               (uint64_t *)ctx->io[4].p);
-        else
-            hipLaunchKernelGGL(k_gather_rows<F128>, dim3((uint32_t)n, c->p.n_traces), dim3(64), 0, st, (const U128 *)c->lde,
-                               trace_elems, (uint32_t)c->row_width, (uint32_t)c->epr, (const uint64_t *)ctx->io[3].p,
-                               (U128 *)ctx->io[4].p);
-        HIP_TRY(hipGetLastError());
-    }
-    std::vector<uint8_t> buf(dig_bytes);
-    if (!ids.empty()) {
-        const uint32_t nid = (uint32_t)ids.size();
-        hipLaunchKernelGGL(k_gather_digests, dim3((2 * nid + 255) / 256), dim3(256), 0, st, (const uint4 *)c->leaves,
-                           (const uint4 *)c->nodes, c->n_rows, (const uint64_t *)ctx->io[3].p, nid,
-                           (uint4 *)((char *)ctx->io[4].p + rows_bytes));
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(buf.data(), (char *)ctx->io[4].p + rows_bytes, dig_bytes, hipMemcpyDeviceToHost, st));
-    }
-    if (rows_out && n) HIP_TRY(hipMemcpyAsync(rows_out, ctx->io[4].p, n * c->row_elems * eb, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    memcpy(leaves_out, buf.data(), n * 32);
-    memcpy(nodes_out, buf.data() + n * 32, total * 32);
-    for (size_t i = 0; i < vec_ids.size(); i++) node_counts[i] = (uint32_t)vec_ids[i].size();
-    *n_vectors = vec_ids.size();
-    *n_nodes = total;
-    if (depth_out) *depth_out = c->depth;
+    *n_vectors = q.n_vectors;
+    *n_nodes = q.n_nodes;
+    if (depth_out) *depth_out = q.depth;
     return 0;
 }
+
+int wf_commitment_query_many(wf_query *queries, size_t n_queries) { return query_many_impl(queries, n_queries); }
 
 int wf_commitment_prove_batch(const wf_commitment *c, const uint64_t *positions, size_t n, uint8_t *leaves_out,
                               uint8_t *nodes_out, size_t nodes_capacity, uint32_t *node_counts, size_t *n_vectors,

@@ -106,6 +106,23 @@ int main(void) {
     CHECK(memcmp(path, leaves + pos[0] * 32, 32) == 0 && memcmp(path + 32, leaves + (pos[0] ^ 1) * 32, 32) == 0);
     pos[0] = N;
     CHECK(wf_commitment_read_rows(com, pos, 1, row) == WF_ERR_LEAVES);
+    { /* a range of the resident matrix as RowMatrix::data holds it, and the DEEP composition of its polynomials */
+        uint64_t width = 0, z = 12345, cc[COLS] = {3, 5, 7}, zero_z = 0;
+        uint64_t *piece = (uint64_t *)malloc((size_t)64 * 8 * 8), *deep = (uint64_t *)malloc((size_t)R * 8),
+                 *deep2 = (uint64_t *)malloc((size_t)R * 8);
+        const wf_commitment *handles[1];
+        CHECK(wf_commitment_read_lde(com, 0, 100, 64, piece, &width) == WF_OK && width == rw);
+        CHECK(memcmp(piece, lde + 100 * rw, (size_t)64 * rw * 8) == 0);
+        CHECK(wf_commitment_read_lde(com, 1, 0, 1, piece, NULL) == WF_ERR_TRACES);
+        handles[0] = com;
+        CHECK(wf_deep_compose(ctx, handles, 1, NULL, &z, 1, cc, NULL, deep, NULL, 0) == WF_OK);
+        CHECK(deep[R - 1] == 0 && deep[R - 2] != 0); /* degree R - 2 (composer/mod.rs:151) */
+        CHECK(wf_deep_compose(ctx, handles, 1, NULL, &z, 1, cc, NULL, deep2, NULL, 0) == WF_OK);
+        CHECK(memcmp(deep, deep2, (size_t)R * 8) == 0);
+        CHECK(wf_deep_compose(ctx, handles, 1, NULL, &zero_z, 1, cc, NULL, deep, NULL, 0) == WF_ERR_ARG);
+        CHECK(wf_deep_compose(ctx, handles, 1, NULL, &z, 1, cc, NULL, NULL, NULL, 0) == WF_ERR_ARG);
+        free(piece); free(deep); free(deep2);
+    }
     wf_commitment_destroy(com);
 
     p.n_cols = 0;

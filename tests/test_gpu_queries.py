@@ -6,7 +6,7 @@ ConstraintCommitment::query (prover/src/constraints/commitment.rs:54-69), Merkle
 import numpy as np
 import pytest
 
-from conftest import rand_cols
+from conftest import rand_cols, rand_f64
 
 pytestmark = pytest.mark.gpu
 F64, F128 = 1, 2
@@ -155,3 +155,52 @@ def test_read_lde_ranges(ctx, orc, capi):
     got = comc.read_lde(0, 40, 64)
     assert np.array_equal(got[:, :2], wantc["lde"][40:104, :2]) and got.shape[1] in (2, 8)
     comc.close()
+
+
+def test_query_many_equals_single_queries(ctx, orc, capi):
+    """wf_commitment_query_many: the trace tree, the constraint tree and FRI layers of different shapes answered in one round
+    trip -- the same rows and BatchMerkleProofs as one wf_commitment_query each; a bad list fails the whole call."""
+    rng = np.random.default_rng(77)
+    logR, logB = 10, 3
+    N = 1 << (logR + logB)
+    traces = [rand_cols(rng, F64, 5, 1 << logR) for _ in range(2)]
+    tcom, _ = ctx.trace_commit_resident(capi.make_params(F64, 1, logR, logB, 5, 2), [c for t in traces for c in t])
+    ccom = ctx.constraint_commit_resident(capi.make_params(F64, 2, logR, logB, 3, 1), rand_cols(rng, F64, 3, 2 << logR))
+    fri = capi.FriProver(ctx, F64, 2, 4, 1 << logB, 7, 7)
+    fri.begin(rand_cols(rng, F64, 1, 2 * N)[0])
+    n_layers = capi.fri_num_layers(4, 1 << logB, 7, N)
+    for _ in range(n_layers):
+        fri.commit_layer()
+        fri.fold(rand_f64(rng, 2))
+    pos = np.unique(rng.integers(0, N, size=40)).astype(np.uint64)
+    requests = [(tcom, pos, True), (ccom, pos, True)]
+    p, size = pos, N
+    for i in range(n_layers):
+        p = capi.fri_fold_positions(p, size, 4)
+        requests.append((fri.layer(i), p, True))
+        size //= 4
+    requests.append((tcom, pos[:3], False))  # proof only
+    got = capi.query_many(requests)
+    assert len(got) == len(requests)
+    for (com, positions, want_rows), (rows, proof) in zip(requests, got):
+        if want_rows:
+            want_r, want_p = com.query(positions)
+            assert np.array_equal(rows, want_r)
+        else:
+            assert rows is None
+            want_p = com.prove_batch(positions)
+        assert proof == want_p
+    with pytest.raises(capi.WfError) as e:  # duplicate positions in the third list: DuplicateLeafIndex for the whole call
+        capi.query_many(requests[:2] + [(requests[2][0], np.array([1, 1], dtype=np.uint64), True)])
+    assert e.value.code == -18
+    with pytest.raises(capi.WfError):
+        capi.query_many([])
+    other = capi.Context(0)
+    ocom, _ = other.trace_commit_resident(capi.make_params(F64, 1, 5, 1, 2, 1), rand_cols(rng, F64, 2, 32))
+    with pytest.raises(capi.WfError):  # two contexts in one call
+        capi.query_many([(tcom, pos[:2], True), (ocom, np.array([1], dtype=np.uint64), True)])
+    ocom.close()
+    other.close()
+    fri.close()
+    tcom.close()
+    ccom.close()
