@@ -279,6 +279,20 @@ int wf_trace_commit_resident(wf_ctx *ctx, const wf_params *p, const void *const 
                              wf_commitment **out);
 /* build_constraint_commitment with host inputs. */
 int wf_constraint_commit_resident(wf_ctx *ctx, const wf_params *p, const void *const *poly_cols, wf_commitment **out);
+/* The constraint side from the combined constraint EVALUATIONS on, without the composition polynomial visiting the host:
+ *   - the tail of ConstraintEvaluationTable::into_comb_poly (prover/src/constraints/evaluation_table.rs:166-186):
+ *     fft::interpolate_poly_with_offset of every table's combined column over the constraint evaluation domain of
+ *     ce_domain_size points with p->domain_offset (the division by the divisors in front of it is AIR-specific: the caller's);
+ *   - STARKPack's combination over the n_tables packed traces (prover/src/lib.rs:442-453):
+ *     final = comb_0 + sum_{i >= 1} comb_i * final_coeff^i   (final_coeff: one element of E; NULL for one table);
+ *   - CompositionPoly::new / segment (constraints/composition_poly.rs:21-41, 86-98): p->n_cols columns of 2^log2_trace_len
+ *     coefficients = the first n_cols chunks of the polynomial (ce_domain_size a power of two > trace length);
+ *   - build_constraint_commitment (lib.rs:680-715) into a resident handle.
+ * combined_evaluations: [n_tables] host arrays of ce_domain_size elements of E (p->ext_degree coordinates); polys_out: NULL or
+ * [n_cols] host columns for the composition polynomial's columns.  The handle serves CompositionPoly::evaluate_at
+ * (wf_commitment_evaluate_polys_at), the DEEP composition (wf_deep_compose) and ConstraintCommitment::query. */
+int wf_constraint_commit_from_evaluations(wf_ctx *ctx, const wf_params *p, const void *const *combined_evaluations, size_t n_tables,
+                                          size_t ce_domain_size, const void *final_coeff, void *const *polys_out, wf_commitment **out);
 void wf_commitment_destroy(wf_commitment *c);
 /* MerkleTree::root (merkle/mod.rs:167) */
 int wf_commitment_root(const wf_commitment *c, uint8_t root_out[32]);

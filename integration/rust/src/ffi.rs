@@ -94,6 +94,10 @@ extern "C" {
         c: *const WfCommitment, trace: u32, row_begin: u64, n_rows: u64, rows_out: *mut c_void, row_width_out: *mut u64,
     ) -> c_int;
     pub fn wf_commitment_query_many(queries: *mut WfQuery, n_queries: usize) -> c_int;
+    pub fn wf_constraint_commit_from_evaluations(
+        ctx: *mut WfCtx, p: *const WfParams, combined_evaluations: *const *const c_void, n_tables: usize, ce_domain_size: usize,
+        final_coeff: *const c_void, polys_out: *const *mut c_void, out: *mut *mut WfCommitment,
+    ) -> c_int;
     pub fn wf_deep_compose(
         ctx: *mut WfCtx, trace_commitments: *const *const WfCommitment, n_trace_commitments: usize,
         constraint_commitment: *const WfCommitment, z: *const c_void, ext_degree: u32, trace_coeffs: *const c_void,

@@ -364,4 +364,11 @@ void orc_deep_compose(int field, size_t ext, size_t n, size_t n_tables, const si
                               (const f128e *)cc_constraints, (const f128e *)z, (f128e *)out);
 }
 
+void orc_scale_acc(int field, void *acc, const void *src, size_t ext, size_t n, const void *final_coeff, size_t power) {
+    if (field == ORC_FIELD_F64)
+        orc_f64_scale_acc((uint64_t *)acc, (const uint64_t *)src, ext, n, (const uint64_t *)final_coeff, power);
+    else
+        orc_f128_scale_acc((f128e *)acc, (const f128e *)src, ext, n, (const f128e *)final_coeff, power);
+}
+
 int orc_max_threads(void) { return omp_get_max_threads(); }

@@ -117,6 +117,12 @@ void orc_f128_deep_compose(size_t ext, size_t n, size_t n_tables, const size_t *
                            const unsigned __int128 *const *constraint_cols, const unsigned __int128 *ood_constraints,
                            const unsigned __int128 *cc_constraints, const unsigned __int128 *z, unsigned __int128 *out);
 
+/* --- STARKPack combination of composition polynomials (prover/src/lib.rs:442-453) */
+void orc_scale_acc(int field, void *acc, const void *src, size_t ext, size_t n, const void *final_coeff, size_t power);
+void orc_f64_scale_acc(uint64_t *acc, const uint64_t *src, size_t ext, size_t n, const uint64_t *final_coeff, size_t power);
+void orc_f128_scale_acc(unsigned __int128 *acc, const unsigned __int128 *src, size_t ext, size_t n,
+                        const unsigned __int128 *final_coeff, size_t power);
+
 int orc_max_threads(void);
 
 #ifdef __cplusplus

@@ -76,6 +76,7 @@ def lib():
         L.orc_blake3_hash.argtypes = [vp, sz, vp]
         L.orc_eval_column_at.argtypes = [i32, vp, sz, sz, vp, sz, vp]
         L.orc_ext_mul.argtypes = [i32, sz, vp, vp, vp]
+        L.orc_scale_acc.argtypes = [i32, vp, vp, sz, sz, vp, sz]
         L.orc_deep_compose.argtypes = [i32, sz, sz, sz, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]
         L.orc_transpose_slice.argtypes = [i32, vp, sz, sz, sz, vp]
         L.orc_apply_drp.argtypes = [i32, vp, sz, sz, sz, vp, vp, vp, i32]
@@ -484,3 +485,28 @@ def deep_compose(field: int, ext: int, n: int, tables, constraint_cols, z: np.nd
                            _p(ood_zg_a), _p(cct), len(ccols), _ptr_array(ccols) if ccols else None, _p(ood_c_a), _p(ccc),
                            _p(z), _p(out))
     return out
+
+
+# ----------------------------------------------------------------------------------------------- constraint side from evaluations
+
+def composition_poly_from_evaluations(field: int, ext: int, tables, log2_R: int, n_cols: int, offset: int, final_coeff=None):
+    """The tail of ConstraintEvaluationTable::into_comb_poly for every packed trace (constraints/evaluation_table.rs:178-185:
+    interpolate_poly_with_offset over the constraint evaluation domain), STARKPack's combination
+    final = comb_0 + sum comb_i * final_coeff^i (prover/src/lib.rs:442-453) and CompositionPoly::new / segment
+    (constraints/composition_poly.rs:21-41, 86-98).  tables: combined constraint evaluations, one array of ce elements of E per
+    packed trace.  Returns the n_cols column polynomials (R elements of E each)."""
+    w = ELEM_WORDS[field]
+    R = 1 << log2_R
+    final = None
+    for i, t in enumerate(tables):
+        v = np.ascontiguousarray(t, dtype=np.uint64).copy()
+        ce = v.size // (w * ext)
+        interpolate_poly_with_offset(field, v, ce, ext, get_twiddles(field, ce, inverse=True),
+                                     lib().orc_f64_new(offset) if field == F64 else offset)
+        if i == 0:
+            final = v
+        else:
+            fc = np.ascontiguousarray(final_coeff, dtype=np.uint64)
+            lib().orc_scale_acc(field, _p(final), _p(v), ext, ce, _p(fc), i)
+    flat = final.reshape(-1, ext * w)
+    return [np.ascontiguousarray(flat[c * R:(c + 1) * R]).reshape((R * ext, w) if w > 1 else (R * ext,)) for c in range(n_cols)]

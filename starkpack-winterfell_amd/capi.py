@@ -22,7 +22,7 @@ SYMBOLS = [
     "wf_ctx_release_cached", "wf_plan_digits", "wf_commitment_query", "wf_ctx_profile_enable", "wf_ctx_profile_read", "wf_params_check", "wf_elem_bytes", "wf_row_width", "wf_column_bytes", "wf_lde_bytes", "wf_digests_bytes",
     "wf_trace_commit", "wf_constraint_commit", "wf_trace_commit_dev", "wf_constraint_commit_dev",
     "wf_trace_commit_shard_dev", "wf_merkle_build_dev", "wf_trace_commit_resident", "wf_constraint_commit_resident", "wf_commitment_destroy", "wf_commitment_root",
-    "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_read_lde", "wf_deep_compose", "wf_commitment_query_many", "wf_commitment_prove", "wf_commitment_prove_batch",
+    "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_read_lde", "wf_deep_compose", "wf_constraint_commit_from_evaluations", "wf_commitment_query_many", "wf_commitment_prove", "wf_commitment_prove_batch",
     "wf_evaluate_columns_at", "wf_commitment_evaluate_polys_at", "wf_fri_layer_commit", "wf_fri_apply_drp", "wf_fri_layer_commit_dev", "wf_fri_apply_drp_dev",
     "wf_fri_prover_create", "wf_fri_prover_destroy", "wf_fri_num_layers", "wf_fri_prover_begin", "wf_fri_prover_begin_dev", "wf_fri_prover_begin_poly",
     "wf_fri_prover_commit_layer", "wf_fri_prover_fold", "wf_fri_prover_set_remainder", "wf_fri_prover_num_layers",
@@ -147,6 +147,7 @@ def load():
         L.wf_commitment_read_lde.argtypes = [vp, u32, C.c_uint64, C.c_uint64, vp, C.POINTER(C.c_uint64)]
         L.wf_deep_compose.argtypes = [vp, vp, C.c_size_t, vp, vp, u32, vp, vp, vp, vp, C.c_size_t]
         L.wf_commitment_query_many.argtypes = [C.POINTER(Query), C.c_size_t]
+        L.wf_constraint_commit_from_evaluations.argtypes = [vp, C.POINTER(Params), vp, C.c_size_t, C.c_size_t, vp, vp, vp]
         L.wf_commitment_prove.argtypes = [vp, C.c_uint64, vp]
         L.wf_commitment_prove_batch.argtypes = [vp, vp, sz, vp, vp, sz, vp, C.POINTER(sz), C.POINTER(sz),
                                                 C.POINTER(u32)]
@@ -376,6 +377,26 @@ class Context:
         h = C.c_void_p()
         _check(L.wf_constraint_commit_resident(self._h, C.byref(params), _ptr_array(cols), C.byref(h)))
         return Commitment(h, params.field, keep_alive=self)
+
+    def constraint_commit_from_evaluations(self, params: Params, combined_evaluations, final_coeff=None, want_polys=False):
+        """wf_constraint_commit_from_evaluations: [n_tables] combined constraint evaluations over the constraint evaluation
+        domain -> resident constraint commitment (and, on request, the composition polynomial's columns)."""
+        L = load()
+        _check(L.wf_params_check(C.byref(params), 1))
+        tabs = [np.ascontiguousarray(t, dtype=np.uint64) for t in combined_evaluations]
+        w = ELEM_WORDS[params.field]
+        ce = tabs[0].size // (w * params.ext_degree)
+        fc = np.ascontiguousarray(final_coeff, dtype=np.uint64) if final_coeff is not None else None
+        R = 1 << params.log2_trace_len
+        polys = None
+        if want_polys:
+            shape = (R * params.ext_degree, w) if w > 1 else (R * params.ext_degree,)
+            polys = [np.empty(shape, dtype=np.uint64) for _ in range(params.n_cols)]
+        h = C.c_void_p()
+        _check(L.wf_constraint_commit_from_evaluations(self._h, C.byref(params), _ptr_array(tabs), len(tabs), ce,
+                                                       _p(fc) if fc is not None else None,
+                                                       _ptr_array(polys) if polys else None, C.byref(h)))
+        return Commitment(h, params.field, keep_alive=self), polys
 
     def deep_compose(self, field, ext, n, trace_commitments, constraint_commitment, z, trace_coeffs, constraint_coeffs=None,
                      want_poly=True, fri: "FriProver" = None, lde_blowup: int = 0):

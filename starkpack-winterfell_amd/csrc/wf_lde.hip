@@ -1473,19 +1473,10 @@ static void free_commitment(wf_commitment *c) {
     delete c;
 }
 
-static int commit_resident(wf_ctx *ctx, const wf_params *p, bool constraint, const void *const *cols_in,
-                           void *const *polys_out, wf_commitment **out) {
-    if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
-    if (!out) return fail(WF_ERR_ARG, "out is null");
-    int rc = check_params(p, constraint);
-    if (rc) return rc;
-    if (!cols_in) return fail(WF_ERR_ARG, "column pointer array is null");
-    HIP_TRY(hipSetDevice(ctx->device));
-    WF_ENTER(ctx, ctx->stream);
+// A resident commitment's handle with its buffers (LDE, leaves, nodes, polynomials) taken from the context's pool
+static int commitment_alloc(wf_ctx *ctx, const wf_params *p, bool constraint, wf_commitment **out, bool *dense_out) {
     const size_t colb = wf_column_bytes(p), ldeb = wf_lde_bytes(p), digb = wf_digests_bytes(p);
     const size_t TC = (size_t)p->n_cols * p->n_traces;
-    for (size_t i = 0; i < TC; i++)
-        if (!cols_in[i]) return fail(WF_ERR_ARG, "column %zu is null", i);
     wf_commitment *c = new wf_commitment();
     memset(c, 0, sizeof(*c));
     c->ctx = ctx;
@@ -1507,6 +1498,27 @@ static int commit_resident(wf_ctx *ctx, const wf_params *p, bool constraint, con
         free_commitment(c);
         return fail(WF_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
     }
+    *out = c;
+    *dense_out = dense;
+    return 0;
+}
+
+static int commit_resident(wf_ctx *ctx, const wf_params *p, bool constraint, const void *const *cols_in,
+                           void *const *polys_out, wf_commitment **out) {
+    if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
+    if (!out) return fail(WF_ERR_ARG, "out is null");
+    int rc = check_params(p, constraint);
+    if (rc) return rc;
+    if (!cols_in) return fail(WF_ERR_ARG, "column pointer array is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
+    const size_t colb = wf_column_bytes(p);
+    const size_t TC = (size_t)p->n_cols * p->n_traces;
+    for (size_t i = 0; i < TC; i++)
+        if (!cols_in[i]) return fail(WF_ERR_ARG, "column %zu is null", i);
+    wf_commitment *c = nullptr;
+    bool dense = false;
+    if ((rc = commitment_alloc(ctx, p, constraint, &c, &dense))) return rc;
     rc = ensure(ctx, ctx->io[0], TC * colb);
     if (rc) {
         free_commitment(c);
@@ -1531,7 +1543,7 @@ static int commit_resident(wf_ctx *ctx, const wf_params *p, bool constraint, con
         free_commitment(c);
         return rc;
     }
-    e = hipMemcpyAsync(c->root, (char *)c->nodes + 32, 32, hipMemcpyDeviceToHost, st);
+    hipError_t e = hipMemcpyAsync(c->root, (char *)c->nodes + 32, 32, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
         free_commitment(c);
@@ -2628,3 +2640,4 @@ int wf_fri_prover_layer(const wf_fri_prover *pr, size_t i, const wf_commitment *
 
 #include "comm.hpp"
 #include "deep.hpp"
+#include "constraint_poly.hpp"
