@@ -435,6 +435,35 @@ inline std::unique_ptr<TraceCommitment<E>> build_resident_constraint_commitment(
     return std::make_unique<TraceCommitment<E>>(h, 1, cols * E::EXTENSION_DEGREE);
 }
 
+// The constraint side from the combined constraint evaluations on (ConstraintEvaluationTable::into_comb_poly's
+// interpolation, evaluation_table.rs:178-185; STARKPack's final_coeff combination, lib.rs:442-453; into_poly +
+// build_constraint_commitment) in one device-resident step.  combined[i]: the combined column of packed trace i over the
+// constraint evaluation domain.
+template <class E>
+inline std::unique_ptr<TraceCommitment<E>> build_resident_constraint_commitment_from_evaluations(
+    const Prover &prover, const std::vector<std::vector<E>> &combined, const E &final_coeff, size_t num_cols, const StarkDomain &domain) {
+    if (combined.empty()) throw std::invalid_argument("at least one evaluation table is required");
+    wf_params p;
+    std::memset(&p, 0, sizeof(p));
+    p.field = E::FIELD;
+    p.ext_degree = E::EXTENSION_DEGREE;
+    p.log2_trace_len = ilog2_exact(domain.trace_length(), "trace length");
+    p.log2_blowup = ilog2_exact(domain.trace_to_lde_blowup(), "blowup factor");
+    p.n_cols = (uint32_t)num_cols;
+    p.n_traces = 1;
+    p.digest_bytes = 32;
+    unsigned __int128 off = domain.offset();
+    std::memcpy(p.domain_offset, &off, 16);
+    std::vector<const void *> in;
+    for (auto &t : combined) {
+        if (t.size() != combined[0].size()) throw std::invalid_argument("evaluation tables of different sizes");
+        in.push_back(t.data());
+    }
+    wf_commitment *h = nullptr;
+    wf_check(wf_constraint_commit_from_evaluations(prover.context(), &p, in.data(), in.size(), combined[0].size(), &final_coeff, nullptr, &h));
+    return std::make_unique<TraceCommitment<E>>(h, 1, num_cols * E::EXTENSION_DEGREE);
+}
+
 // ------------------------------------------------------------------------------------------------- FRI prover
 struct FriOptions {  // fri/src/options.rs:16-93
     size_t blowup_factor, folding_factor, remainder_max_degree;

@@ -28,7 +28,7 @@ def shape():
 
 
 for it in range(n):
-    kind = ["host", "resident", "constraint", "fri", "ood", "fft", "deep", "drop"][int(rng.integers(0, 8))]
+    kind = ["host", "resident", "constraint", "fri", "ood", "fft", "deep", "cevals", "drop"][int(rng.integers(0, 9))]
     counts[kind] = counts.get(kind, 0) + 1
     field, ext, logR, logB, n_cols, n_traces, offset = shape()
     R, N = 1 << logR, 1 << (logR + logB)
@@ -86,6 +86,17 @@ for it in range(n):
         want = orc.evaluate_poly_with_offset(field, p, R, ext, orc.get_twiddles(field, R),
                                              L.orc_f64_new(offset) if field == F64 else offset, 1 << logB)
         assert np.array_equal(ctx.fft_evaluate_poly_with_offset(field, ext, p, offset, 1 << logB), want)
+    elif kind == "cevals":
+        # constraint side from combined evaluations: interpolation over the ce domain, final_coeff combination, commitment
+        ce_log = logR + int(rng.integers(1, 4))
+        n_cols = min(n_cols, 1 << (ce_log - logR))
+        tabs = [rand_cols(rng, field, 1, (1 << ce_log) * ext)[0] for _ in range(n_traces)]
+        fc = rand_f64(rng, ext) if field == F64 else rand_f128(rng, ext)
+        cols = orc.composition_poly_from_evaluations(field, ext, tabs, logR, n_cols, offset, fc)
+        want = orc.build_constraint_commitment(field, cols, ext, logR, logB, offset)
+        com, _ = ctx.constraint_commit_from_evaluations(capi.make_params(field, ext, logR, logB, n_cols, 1), tabs, fc if n_traces > 1 else None)
+        assert com.root() == want["root"], "constraint commitment from evaluations"
+        live.append((com, want))
     elif kind == "deep":
         # DEEP composition over a fresh main segment (+ auxiliary segment) and constraint columns, then into a FRI prover
         if ext == 1:

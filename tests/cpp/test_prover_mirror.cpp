@@ -424,6 +424,19 @@ static void deep_composition_resident() {
     for (size_t i = 0; i < ch_a.layer_commitments.size(); i++) EXPECT(ch_a.layer_commitments[i] == ch_b.layer_commitments[i]);
     EXPECT(fri_a.remainder().size() == fri_b.remainder().size());
     for (size_t i = 0; i < fri_a.remainder().size(); i++) EXPECT(fri_a.remainder()[i] == fri_b.remainder()[i]);
+    // the same constraint commitment reached from combined EVALUATIONS over a constraint evaluation domain of 4 R points:
+    // evaluate the composition polynomial there on the CPU, hand the evaluations over, compare the roots
+    {
+        const size_t ce = 4 * trace_length;
+        std::vector<uint64_t> tw(ce / 2), coeffs(ce * 2, 0), evals(ce * 2);
+        EXPECT(orc_f64_get_twiddles(tw.data(), ce, 0) == 0);
+        std::memcpy(coeffs.data(), composition.data(), n_cons * trace_length * 16);  // the columns are the polynomial's chunks
+        orc_f64_evaluate_poly_with_offset(coeffs.data(), ce, 2, tw.data(), orc_f64_new(7), 1, evals.data());
+        std::vector<std::vector<E>> combined(1, std::vector<E>(ce));
+        std::memcpy(combined[0].data(), evals.data(), ce * 16);
+        auto from_evals = build_resident_constraint_commitment_from_evaluations<E>(prover, combined, z, n_cons, domain);
+        EXPECT(from_evals->main_trace_root() == constraint_commitment->main_trace_root());
+    }
     std::printf("deep_composition_resident ok\n");
 }
 
