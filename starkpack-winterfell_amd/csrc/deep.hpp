@@ -20,7 +20,10 @@
 
 namespace wf {
 
-constexpr uint32_t DEEP_RUN = 4, DEEP_BLOCK = 256 * DEEP_RUN;
+#ifndef WF_DEEP_RUN_LOG
+#define WF_DEEP_RUN_LOG 2
+#endif
+constexpr uint32_t DEEP_RUN_LOG = WF_DEEP_RUN_LOG, DEEP_RUN = 1u << DEEP_RUN_LOG, DEEP_BLOCK = 256 * DEEP_RUN;
 
 template <class F, int WE>
 __device__ __forceinline__ Ext<F, WE> ext_zero() {
@@ -319,12 +322,11 @@ static int deep_launch(wf_ctx *ctx, hipStream_t st, const DeepTable &tab, const 
     uint32_t logn = 0;
     while (((uint64_t)1 << logn) < n) logn++;
     const T g = f_root_of_unity<F>(logn);
-    static_assert(DEEP_RUN == 4 && DEEP_BLOCK == 1024, "exponents below");
     for (int s = 0; s < 2; s++) {
         E y;
         for (int w = 0; w < WE; w++) y.c[w] = s == 0 ? z[w] : F::mul(z[w], g);
-        E rp = ext_pow2k<F, WE>(y, 2);            // y^DEEP_RUN
-        const E Y = ext_pow2k<F, WE>(y, 10);      // y^DEEP_BLOCK
+        E rp = ext_pow2k<F, WE>(y, DEEP_RUN_LOG);          // y^DEEP_RUN
+        const E Y = ext_pow2k<F, WE>(y, 8 + DEEP_RUN_LOG);  // y^DEEP_BLOCK
         E cp;                                      // Y^L by square and multiply
         for (int w = 0; w < WE; w++) cp.c[w] = w == 0 ? F::one() : F::zero();
         E base = Y;
