@@ -141,3 +141,32 @@ def test_fri_commit_phase_from_deep_poly_2_20(ctx, orc, capi):
     assert np.array_equal(rem.reshape(-1), want_rem[:keep]) and not want_rem[keep:].any()
     assert digest == orc.hash_elements(F64, want_rem[:keep])
     pr.close()
+
+
+def test_proof_chain_cfg2_constraint_side_and_deep_composition(ctx, orc, capi):
+    """cfg 2's proof shape, the resident chain that follows the trace commitment: the constraint side from combined evaluations
+    over a constraint evaluation domain of 2^21 points (interpolation with offset, STARKPack combination of two packed
+    traces, two columns of the quadratic extension, commitment: prover/src/lib.rs:435-472) and the DEEP composition over the
+    2^20 x 8 main trace and those columns (composer/mod.rs:62-193), both in full against the oracle."""
+    logR, logB, ext, n_cols = 20, 3, 2, 8
+    R = 1 << logR
+    rng = np.random.default_rng(77)
+    trace = [rand_f64(rng, R) for _ in range(n_cols)]
+    want_t = orc.build_trace_commitment(F64, [trace], 1, logR, logB, 7, threads=THREADS)
+    tcom, _ = ctx.trace_commit_resident(capi.make_params(F64, 1, logR, logB, n_cols, 1), trace)
+    assert tcom.root() == want_t["root"]
+    tables = [rand_f64(rng, 2 * R * ext) for _ in range(2)]
+    fc = rand_f64(rng, ext)
+    want_cols = orc.composition_poly_from_evaluations(F64, ext, tables, logR, 2, 7, fc)
+    want_c = orc.build_constraint_commitment(F64, want_cols, ext, logR, logB, 7, threads=THREADS)
+    ccom, polys = ctx.constraint_commit_from_evaluations(capi.make_params(F64, ext, logR, logB, 2, 1), tables, fc, want_polys=True)
+    assert ccom.root() == want_c["root"]
+    assert all(np.array_equal(a, b) for a, b in zip(polys, want_cols))
+    z = rand_f64(rng, ext)
+    cc_t = [rand_f64(rng, ext) for _ in range(n_cols)]
+    cc_c = [rand_f64(rng, ext) for _ in range(2)]
+    want_d = orc.deep_compose(F64, ext, R, [[(p, 1) for p in want_t["polys"][0]]], want_cols, z, cc_t, cc_c)
+    got_d = ctx.deep_compose(F64, ext, R, [tcom], ccom, z, np.concatenate(cc_t), np.concatenate(cc_c))
+    assert np.array_equal(got_d, want_d)
+    tcom.close()
+    ccom.close()
