@@ -293,6 +293,30 @@ int wf_constraint_commit_resident(wf_ctx *ctx, const wf_params *p, const void *c
  * (wf_commitment_evaluate_polys_at), the DEEP composition (wf_deep_compose) and ConstraintCommitment::query. */
 int wf_constraint_commit_from_evaluations(wf_ctx *ctx, const wf_params *p, const void *const *combined_evaluations, size_t n_tables,
                                           size_t ce_domain_size, const void *final_coeff, void *const *polys_out, wf_commitment **out);
+/* The same starting one step earlier, from the constraint evaluation TABLE: all of ConstraintEvaluationTable::into_comb_poly
+ * (evaluation_table.rs:166-186) -- acc_column (:335-391) divides every column by its divisor over the constraint evaluation
+ * domain x_i = offset * g^i and sums them, get_inv_evaluation (:393-426) supplies 1 / (x^a - b), then the interpolation and the
+ * steps above.  A divisor (ConstraintDivisor, air/src/air/divisor.rs:26-29) is (x^a - b) / prod_k (x - e_k) with ONE numerator
+ * term (evaluation_table.rs:343 asserts it): a = numerator_degree (a power of two: the trace length for the transition
+ * divisor, trace length / stride for assertions), b and the e_k base-field elements in memory representation (exemptions
+ * empty for boundary-constraint columns, the last `num_transition_exemptions` trace-domain points for the transition column;
+ * at most 8).  columns: [n_columns] host arrays of ce_domain_size elements of E, column j goes with divisors[j].
+ * (acc_column indexes the inverses with the position inside its thread's batch; that equals the position in the column
+ * whenever the number of distinct inverses divides the batch size -- both are powers of two and batches hold >= 128 rows,
+ * so always for the ce_domain_size / trace_length values of a transition divisor.) */
+typedef struct wf_divisor {
+    uint64_t numerator_degree;
+    uint8_t numerator_constant[16];
+    const void *exemptions;
+    uint32_t n_exemptions;
+} wf_divisor;
+typedef struct wf_evaluation_table {
+    const void *const *columns;
+    const wf_divisor *divisors;
+    uint32_t n_columns;
+} wf_evaluation_table;
+int wf_constraint_commit_from_tables(wf_ctx *ctx, const wf_params *p, const wf_evaluation_table *tables, size_t n_tables,
+                                     size_t ce_domain_size, const void *final_coeff, void *const *polys_out, wf_commitment **out);
 void wf_commitment_destroy(wf_commitment *c);
 /* MerkleTree::root (merkle/mod.rs:167) */
 int wf_commitment_root(const wf_commitment *c, uint8_t root_out[32]);

@@ -31,6 +31,21 @@ pub struct WfCtx {
 pub struct WfCommitment {
     _private: [u8; 0],
 }
+/// `wf_divisor`: (x^a - b) / prod_k (x - e_k) -- `ConstraintDivisor` with its single numerator term.
+#[repr(C)]
+pub struct WfDivisor {
+    pub numerator_degree: u64,
+    pub numerator_constant: [u8; 16],
+    pub exemptions: *const c_void,
+    pub n_exemptions: u32,
+}
+/// `wf_evaluation_table`: the columns of one `ConstraintEvaluationTable` with their divisors.
+#[repr(C)]
+pub struct WfEvaluationTable {
+    pub columns: *const *const c_void,
+    pub divisors: *const WfDivisor,
+    pub n_columns: u32,
+}
 /// `wf_query` of `wf_lde.h`: one commitment's share of a batched query.
 #[repr(C)]
 pub struct WfQuery {
@@ -96,6 +111,10 @@ extern "C" {
     pub fn wf_commitment_query_many(queries: *mut WfQuery, n_queries: usize) -> c_int;
     pub fn wf_constraint_commit_from_evaluations(
         ctx: *mut WfCtx, p: *const WfParams, combined_evaluations: *const *const c_void, n_tables: usize, ce_domain_size: usize,
+        final_coeff: *const c_void, polys_out: *const *mut c_void, out: *mut *mut WfCommitment,
+    ) -> c_int;
+    pub fn wf_constraint_commit_from_tables(
+        ctx: *mut WfCtx, p: *const WfParams, tables: *const WfEvaluationTable, n_tables: usize, ce_domain_size: usize,
         final_coeff: *const c_void, polys_out: *const *mut c_void, out: *mut *mut WfCommitment,
     ) -> c_int;
     pub fn wf_deep_compose(

@@ -371,4 +371,18 @@ void orc_scale_acc(int field, void *acc, const void *src, size_t ext, size_t n, 
         orc_f128_scale_acc((f128e *)acc, (const f128e *)src, ext, n, (const f128e *)final_coeff, power);
 }
 
+void orc_acc_column(int field, const void *column, size_t ext, size_t ce, size_t a, const void *b, const void *exemptions, size_t n_ex,
+                    const uint8_t offset_le[16], void *result) {
+    f128e off;
+    memcpy(&off, offset_le, 16);
+    if (field == ORC_FIELD_F64) {
+        orc_f64_acc_column((const uint64_t *)column, ext, ce, a, *(const uint64_t *)b, (const uint64_t *)exemptions, n_ex,
+                           f64_new((uint64_t)off), (uint64_t *)result);
+    } else {
+        f128e bb;
+        memcpy(&bb, b, 16);
+        orc_f128_acc_column((const f128e *)column, ext, ce, a, bb, (const f128e *)exemptions, n_ex, off, (f128e *)result);
+    }
+}
+
 int orc_max_threads(void) { return omp_get_max_threads(); }

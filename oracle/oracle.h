@@ -123,6 +123,15 @@ void orc_f64_scale_acc(uint64_t *acc, const uint64_t *src, size_t ext, size_t n,
 void orc_f128_scale_acc(unsigned __int128 *acc, const unsigned __int128 *src, size_t ext, size_t n,
                         const unsigned __int128 *final_coeff, size_t power);
 
+/* --- into_comb_poly's division by the divisors (prover/src/constraints/evaluation_table.rs:335-426); b and the exemptions are
+ * base-field elements in memory representation */
+void orc_acc_column(int field, const void *column, size_t ext, size_t ce, size_t a, const void *b, const void *exemptions, size_t n_ex,
+                    const uint8_t offset_le[16], void *result);
+void orc_f64_acc_column(const uint64_t *column, size_t ext, size_t ce, size_t a, uint64_t b, const uint64_t *exemptions, size_t n_ex,
+                        uint64_t offset, uint64_t *result);
+void orc_f128_acc_column(const unsigned __int128 *column, size_t ext, size_t ce, size_t a, unsigned __int128 b,
+                         const unsigned __int128 *exemptions, size_t n_ex, unsigned __int128 offset, unsigned __int128 *result);
+
 int orc_max_threads(void);
 
 #ifdef __cplusplus

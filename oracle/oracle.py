@@ -76,6 +76,7 @@ def lib():
         L.orc_blake3_hash.argtypes = [vp, sz, vp]
         L.orc_eval_column_at.argtypes = [i32, vp, sz, sz, vp, sz, vp]
         L.orc_ext_mul.argtypes = [i32, sz, vp, vp, vp]
+        L.orc_acc_column.argtypes = [i32, vp, sz, sz, sz, vp, vp, sz, vp, vp]
         L.orc_scale_acc.argtypes = [i32, vp, vp, sz, sz, vp, sz]
         L.orc_deep_compose.argtypes = [i32, sz, sz, sz, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]
         L.orc_transpose_slice.argtypes = [i32, vp, sz, sz, sz, vp]
@@ -510,3 +511,20 @@ def composition_poly_from_evaluations(field: int, ext: int, tables, log2_R: int,
             lib().orc_scale_acc(field, _p(final), _p(v), ext, ce, _p(fc), i)
     flat = final.reshape(-1, ext * w)
     return [np.ascontiguousarray(flat[c * R:(c + 1) * R]).reshape((R * ext, w) if w > 1 else (R * ext,)) for c in range(n_cols)]
+
+
+def combine_evaluation_table(field: int, ext: int, columns, divisors, offset: int) -> np.ndarray:
+    """ConstraintEvaluationTable::into_comb_poly up to the interpolation (evaluation_table.rs:166-176): every column divided by
+    its divisor and summed.  divisors: one (a, b, exemptions) per column -- numerator x^a - b with b a base-field element in
+    memory representation, exemptions a (possibly empty) array of base-field elements (air/src/air/divisor.rs:26-29)."""
+    w = ELEM_WORDS[field]
+    cols = [np.ascontiguousarray(c, dtype=np.uint64) for c in columns]
+    ce = cols[0].size // (w * ext)
+    result = np.zeros_like(cols[0])  # E::zeroed_vector(self.num_rows())
+    for col, (a, b, ex) in zip(cols, divisors):
+        bb = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1)
+        exs = np.ascontiguousarray(ex, dtype=np.uint64) if ex is not None and len(ex) else None
+        n_ex = 0 if exs is None else exs.size // w
+        lib().orc_acc_column(field, _p(col), ext, ce, a, _p(bb), _p(exs) if exs is not None else None, n_ex,
+                             _p(_off_bytes(offset)), _p(result))
+    return result

@@ -22,7 +22,7 @@ SYMBOLS = [
     "wf_ctx_release_cached", "wf_plan_digits", "wf_commitment_query", "wf_ctx_profile_enable", "wf_ctx_profile_read", "wf_params_check", "wf_elem_bytes", "wf_row_width", "wf_column_bytes", "wf_lde_bytes", "wf_digests_bytes",
     "wf_trace_commit", "wf_constraint_commit", "wf_trace_commit_dev", "wf_constraint_commit_dev",
     "wf_trace_commit_shard_dev", "wf_merkle_build_dev", "wf_trace_commit_resident", "wf_constraint_commit_resident", "wf_commitment_destroy", "wf_commitment_root",
-    "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_read_lde", "wf_deep_compose", "wf_constraint_commit_from_evaluations", "wf_commitment_query_many", "wf_commitment_prove", "wf_commitment_prove_batch",
+    "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_read_lde", "wf_deep_compose", "wf_constraint_commit_from_evaluations", "wf_constraint_commit_from_tables", "wf_commitment_query_many", "wf_commitment_prove", "wf_commitment_prove_batch",
     "wf_evaluate_columns_at", "wf_commitment_evaluate_polys_at", "wf_fri_layer_commit", "wf_fri_apply_drp", "wf_fri_layer_commit_dev", "wf_fri_apply_drp_dev",
     "wf_fri_prover_create", "wf_fri_prover_destroy", "wf_fri_num_layers", "wf_fri_prover_begin", "wf_fri_prover_begin_dev", "wf_fri_prover_begin_poly",
     "wf_fri_prover_commit_layer", "wf_fri_prover_fold", "wf_fri_prover_set_remainder", "wf_fri_prover_num_layers",
@@ -57,6 +57,17 @@ TRANSPORT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size
 class Transport(C.Structure):
     """wf_transport: caller-supplied collectives (device pointers)."""
     _fields_ = [("user", C.c_void_p), ("all_gather", TRANSPORT_FN), ("all_to_all", TRANSPORT_FN)]
+
+
+class Divisor(C.Structure):
+    """wf_divisor: (x^a - b) / prod_k (x - e_k), one numerator term (ConstraintDivisor, air/src/air/divisor.rs:26-29)."""
+    _fields_ = [("numerator_degree", C.c_uint64), ("numerator_constant", C.c_uint8 * 16), ("exemptions", C.c_void_p),
+                ("n_exemptions", C.c_uint32)]
+
+
+class EvaluationTable(C.Structure):
+    """wf_evaluation_table: the columns of one ConstraintEvaluationTable with their divisors."""
+    _fields_ = [("columns", C.c_void_p), ("divisors", C.POINTER(Divisor)), ("n_columns", C.c_uint32)]
 
 
 class Query(C.Structure):
@@ -148,6 +159,7 @@ def load():
         L.wf_deep_compose.argtypes = [vp, vp, C.c_size_t, vp, vp, u32, vp, vp, vp, vp, C.c_size_t]
         L.wf_commitment_query_many.argtypes = [C.POINTER(Query), C.c_size_t]
         L.wf_constraint_commit_from_evaluations.argtypes = [vp, C.POINTER(Params), vp, C.c_size_t, C.c_size_t, vp, vp, vp]
+        L.wf_constraint_commit_from_tables.argtypes = [vp, C.POINTER(Params), C.POINTER(EvaluationTable), C.c_size_t, C.c_size_t, vp, vp, vp]
         L.wf_commitment_prove.argtypes = [vp, C.c_uint64, vp]
         L.wf_commitment_prove_batch.argtypes = [vp, vp, sz, vp, vp, sz, vp, C.POINTER(sz), C.POINTER(sz),
                                                 C.POINTER(u32)]
@@ -396,6 +408,45 @@ class Context:
         _check(L.wf_constraint_commit_from_evaluations(self._h, C.byref(params), _ptr_array(tabs), len(tabs), ce,
                                                        _p(fc) if fc is not None else None,
                                                        _ptr_array(polys) if polys else None, C.byref(h)))
+        return Commitment(h, params.field, keep_alive=self), polys
+
+    def constraint_commit_from_tables(self, params: Params, tables, final_coeff=None, want_polys=False):
+        """wf_constraint_commit_from_tables: tables = [[(column, (a, b, exemptions)), ..] per packed trace] -- the whole of
+        ConstraintEvaluationTable::into_comb_poly, the final_coeff combination and the commitment, resident."""
+        L = load()
+        _check(L.wf_params_check(C.byref(params), 1))
+        w = ELEM_WORDS[params.field]
+        keep, c_tables = [], (EvaluationTable * len(tables))()
+        ce = None
+        for t, table in zip(c_tables, tables):
+            cols = [np.ascontiguousarray(c, dtype=np.uint64) for c, _ in table]
+            ce = cols[0].size // (w * params.ext_degree)
+            divs = (Divisor * len(table))()
+            for d, (_, (a, b, ex)) in zip(divs, table):
+                d.numerator_degree = a
+                bb = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1)
+                raw = bb.tobytes().ljust(16, b"\0")
+                d.numerator_constant[:] = list(raw[:16])
+                if ex is not None and len(ex):
+                    e = np.ascontiguousarray(ex, dtype=np.uint64)
+                    keep.append(e)
+                    d.exemptions = e.ctypes.data
+                    d.n_exemptions = e.size // w
+            ptrs = _ptr_array(cols)
+            keep += [cols, divs, ptrs]
+            t.columns = C.cast(ptrs, C.c_void_p)
+            t.divisors = divs
+            t.n_columns = len(table)
+        fc = np.ascontiguousarray(final_coeff, dtype=np.uint64) if final_coeff is not None else None
+        R = 1 << params.log2_trace_len
+        polys = None
+        if want_polys:
+            shape = (R * params.ext_degree, w) if w > 1 else (R * params.ext_degree,)
+            polys = [np.empty(shape, dtype=np.uint64) for _ in range(params.n_cols)]
+        h = C.c_void_p()
+        _check(L.wf_constraint_commit_from_tables(self._h, C.byref(params), c_tables, len(tables), ce,
+                                                  _p(fc) if fc is not None else None, _ptr_array(polys) if polys else None,
+                                                  C.byref(h)))
         return Commitment(h, params.field, keep_alive=self), polys
 
     def deep_compose(self, field, ext, n, trace_commitments, constraint_commitment, z, trace_coeffs, constraint_coeffs=None,

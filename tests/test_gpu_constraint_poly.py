@@ -60,3 +60,64 @@ def test_constraint_commit_from_evaluations_errors(ctx, capi):
         ctx.constraint_commit_from_evaluations(p, tabs, np.array([2**64 - 1, 0], dtype=np.uint64))
     com, _ = ctx.constraint_commit_from_evaluations(p, tabs, rand_f64(rng, 2))   # the context is fine afterwards
     com.close()
+
+
+def _divisors(orc, field, logR, n_ex, rng):
+    """A transition divisor (x^n - 1) / prod (x - g^(n-i)) (ConstraintDivisor::from_transition, air/src/air/divisor.rs:52-66),
+    an assertion at one step (x - g^step) (from_assertion :68-96, a = 1: as many inverses as the domain has points) and a
+    periodic assertion (x^(n/stride) - g^(offset n / stride))."""
+    n = 1 << logR
+    L = orc.lib()
+    if field == F64:
+        g = L.orc_f64_get_root_of_unity(logR)
+        mem = lambda v: np.array([v], dtype=np.uint64)                 # noqa: E731
+        gpow = lambda e: mem(L.orc_f64_exp(g, e))                      # noqa: E731
+        one = mem(L.orc_f64_new(1))
+    else:
+        gi = orc.f128_root_of_unity(logR)
+        P = 2**128 - 45 * 2**40 + 1
+        gpow = lambda e: orc.f128_from_ints([pow(gi, e, P)])           # noqa: E731
+        one = orc.f128_from_ints([1])
+    exemptions = np.concatenate([gpow(n - 1 - i) for i in range(n_ex)]) if n_ex else None
+    return [(n, one, exemptions), (1, gpow(int(rng.integers(0, n))), None), (n // 4, gpow((3 * n) // 4 % n), None)]
+
+
+@pytest.mark.parametrize("field,ext", [(F64, 1), (F64, 2), (F64, 3), (F128, 1), (F128, 2)])
+@pytest.mark.parametrize("logR,log_ce_blowup,n_cols,n_tables,n_ex", [(4, 1, 2, 1, 1), (7, 2, 3, 2, 2), (11, 3, 4, 3, 1), (12, 1, 2, 1, 3)])
+def test_constraint_commit_from_tables(ctx, orc, capi, field, ext, logR, log_ce_blowup, n_cols, n_tables, n_ex):
+    """All of ConstraintEvaluationTable::into_comb_poly on the device: acc_column + get_inv_evaluation
+    (constraints/evaluation_table.rs:335-426) per column, then the chain above."""
+    rng = np.random.default_rng(logR * 11 + ext + field * 50)
+    off = 7 if field == F64 else 3
+    ce = 1 << (logR + log_ce_blowup)
+    tables, combined = [], []
+    for _ in range(n_tables):
+        divs = _divisors(orc, field, logR, n_ex, rng)
+        cols = rand_cols(rng, field, len(divs), ce * ext)
+        tables.append(list(zip(cols, divs)))
+        combined.append(orc.combine_evaluation_table(field, ext, cols, divs, off))
+    fc = rand_f64(rng, ext) if field == F64 else rand_f128(rng, ext)
+    want_cols = orc.composition_poly_from_evaluations(field, ext, combined, logR, n_cols, off, fc)
+    want = orc.build_constraint_commitment(field, want_cols, ext, logR, 3, off)
+    com, polys = ctx.constraint_commit_from_tables(capi.make_params(field, ext, logR, 3, n_cols, 1), tables,
+                                                   fc if n_tables > 1 else None, want_polys=True)
+    for c in range(n_cols):
+        assert np.array_equal(polys[c], want_cols[c]), f"column {c}"
+    assert com.root() == want["root"]
+    com.close()
+
+
+def test_constraint_commit_from_tables_errors(ctx, orc, capi):
+    rng = np.random.default_rng(9)
+    p = capi.make_params(F64, 2, 6, 2, 2, 1)
+    col = rand_cols(rng, F64, 1, 256 * 2)[0]
+    one = np.array([orc.lib().orc_f64_new(1)], dtype=np.uint64)
+    for bad in [(3, one, None),                                            # numerator degree not a power of two
+                (512, one, None),                                          # larger than the domain
+                (64, np.array([2**64 - 1], dtype=np.uint64), None),        # not a field element
+                (64, one, np.full(9, 5, dtype=np.uint64)),                 # more exemption points than supported
+                (64, one, np.array([2**64 - 2], dtype=np.uint64))]:        # invalid exemption point
+        with pytest.raises(capi.WfError):
+            ctx.constraint_commit_from_tables(p, [[(col, bad)]])
+    com, _ = ctx.constraint_commit_from_tables(p, [[(col, (64, one, None))]])
+    com.close()

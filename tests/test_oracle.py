@@ -391,6 +391,42 @@ def test_deep_composition_is_the_sum_of_the_quotients(orc, field, ext):
         assert lhs == rhs
 
 
+@pytest.mark.parametrize("field", [F64, F128])
+def test_acc_column_divides_by_the_divisor(orc, field):
+    """acc_column + get_inv_evaluation (prover/src/constraints/evaluation_table.rs:335-426): for every point x_i = offset g^i
+    of the constraint evaluation domain, result[i] (x_i^a - b) = column[i] prod_k (x_i - e_k) -- on Python integers; and the
+    zero of a divisor's numerator inside the domain leaves a zero (math::batch_inversion ignores zeros)."""
+    import random
+    rnd = random.Random(field)
+    p = P64 if field == F64 else P128
+    ce, ext, off = 64, 2, (7 if field == F64 else 3)
+    if field == F64:
+        to_mem = lambda vals: np.array([(v << 64) % p for v in vals], dtype=np.uint64)  # noqa: E731
+        from_mem = lambda a: [int(v) * pow(2**64, -1, p) % p for v in np.asarray(a).reshape(-1)]  # noqa: E731
+        g = int(orc.lib().orc_f64_get_root_of_unity(6)) * pow(2**64, -1, p) % p
+    else:
+        to_mem = orc.f128_from_ints
+        from_mem = lambda a: orc.f128_to_ints(np.asarray(a).reshape(-1, 2))  # noqa: E731
+        g = orc.f128_root_of_unity(6)
+    for a, n_ex in [(16, 2), (1, 0), (4, 0), (64, 1)]:
+        b = rnd.randrange(1, p)
+        ex = [rnd.randrange(p) for _ in range(n_ex)]
+        col = [rnd.randrange(p) for _ in range(ce * ext)]
+        got = from_mem(orc.combine_evaluation_table(field, ext, [to_mem(col)], [(a, to_mem([b]), to_mem(ex) if ex else None)], off))
+        for i in range(ce):
+            x = off * pow(g, i, p) % p
+            e = 1
+            for v in ex:
+                e = e * (x - v) % p
+            for w in range(ext):
+                assert got[i * ext + w] * (pow(x, a, p) - b) % p == col[i * ext + w] * e % p
+    # b = (offset g^5)^1: the numerator vanishes at i = 5 -> the inverse there is taken as zero
+    b = off * pow(g, 5, p) % p
+    col = [rnd.randrange(1, p) for _ in range(ce)]
+    got = from_mem(orc.combine_evaluation_table(field, 1, [to_mem(col)], [(1, to_mem([b]), None)], off))
+    assert got[5] == 0 and all(v != 0 for i, v in enumerate(got) if i != 5)
+
+
 # ------------------------------------------------------------------------------------ golden: the reference's own inputs
 def test_reference_literal_inputs_golden(orc):
     """LEAVES4 / LEAVES8 of crypto/src/merkle/tests.rs:13-65 and the polynomial of fri/src/prover/tests.rs:58-69 as
