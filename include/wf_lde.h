@@ -332,6 +332,12 @@ int wf_commitment_read_rows(const wf_commitment *c, const uint64_t *positions, s
  * prover/src/trace/trace_lde.rs:78-98, reads rows i and i + blowup of the same data).  n_rows == 0: only the width. */
 int wf_commitment_read_lde(const wf_commitment *c, uint32_t trace, uint64_t row_begin, uint64_t n_rows, void *rows_out,
                            uint64_t *row_width_out);
+/* Every row_stride-th row from row_begin on (rows row_begin + k * row_stride, k < n_rows), packed next to each other: the
+ * constraint evaluation domain is the LDE domain thinned by lde_blowup / ce_blowup, and the evaluator reads rows
+ * step * ce_to_lde_blowup and their successors one trace step later, which are again multiples of that stride
+ * (prover/src/trace/trace_lde.rs:78-98) -- a quarter of the matrix for a ce blowup of 2 under an LDE blowup of 8. */
+int wf_commitment_read_lde_strided(const wf_commitment *c, uint32_t trace, uint64_t row_begin, uint64_t n_rows, uint64_t row_stride,
+                                   void *rows_out, uint64_t *row_width_out);
 /* MerkleTree::prove (merkle/mod.rs:192-212): path_out receives (depth + 1) digests: leaf, sibling leaf, siblings
  * bottom-up. */
 int wf_commitment_prove(const wf_commitment *c, uint64_t index, uint8_t *path_out);

@@ -122,6 +122,10 @@ extern "C" {
         constraint_commitment: *const WfCommitment, z: *const c_void, ext_degree: u32, trace_coeffs: *const c_void,
         constraint_coeffs: *const c_void, poly_out: *mut c_void, fri: *mut WfFriProver, lde_blowup: usize,
     ) -> c_int;
+    pub fn wf_commitment_read_lde_strided(
+        c: *const WfCommitment, trace: u32, row_begin: u64, n_rows: u64, row_stride: u64, rows_out: *mut c_void,
+        row_width_out: *mut u64,
+    ) -> c_int;
     pub fn wf_commitment_evaluate_polys_at(
         c: *const WfCommitment, z: *const c_void, z_ext_degree: u32, out: *mut c_void,
     ) -> c_int;

@@ -22,7 +22,7 @@ SYMBOLS = [
     "wf_ctx_release_cached", "wf_plan_digits", "wf_commitment_query", "wf_ctx_profile_enable", "wf_ctx_profile_read", "wf_params_check", "wf_elem_bytes", "wf_row_width", "wf_column_bytes", "wf_lde_bytes", "wf_digests_bytes",
     "wf_trace_commit", "wf_constraint_commit", "wf_trace_commit_dev", "wf_constraint_commit_dev",
     "wf_trace_commit_shard_dev", "wf_merkle_build_dev", "wf_trace_commit_resident", "wf_constraint_commit_resident", "wf_commitment_destroy", "wf_commitment_root",
-    "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_read_lde", "wf_deep_compose", "wf_constraint_commit_from_evaluations", "wf_constraint_commit_from_tables", "wf_commitment_query_many", "wf_commitment_prove", "wf_commitment_prove_batch",
+    "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_read_lde", "wf_commitment_read_lde_strided", "wf_deep_compose", "wf_constraint_commit_from_evaluations", "wf_constraint_commit_from_tables", "wf_commitment_query_many", "wf_commitment_prove", "wf_commitment_prove_batch",
     "wf_evaluate_columns_at", "wf_commitment_evaluate_polys_at", "wf_fri_layer_commit", "wf_fri_apply_drp", "wf_fri_layer_commit_dev", "wf_fri_apply_drp_dev",
     "wf_fri_prover_create", "wf_fri_prover_destroy", "wf_fri_num_layers", "wf_fri_prover_begin", "wf_fri_prover_begin_dev", "wf_fri_prover_begin_poly",
     "wf_fri_prover_commit_layer", "wf_fri_prover_fold", "wf_fri_prover_set_remainder", "wf_fri_prover_num_layers",
@@ -156,6 +156,7 @@ def load():
         L.wf_commitment_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(u32)]
         L.wf_commitment_read_rows.argtypes = [vp, vp, sz, vp]
         L.wf_commitment_read_lde.argtypes = [vp, u32, C.c_uint64, C.c_uint64, vp, C.POINTER(C.c_uint64)]
+        L.wf_commitment_read_lde_strided.argtypes = [vp, u32, C.c_uint64, C.c_uint64, C.c_uint64, vp, C.POINTER(C.c_uint64)]
         L.wf_deep_compose.argtypes = [vp, vp, C.c_size_t, vp, vp, u32, vp, vp, vp, vp, C.c_size_t]
         L.wf_commitment_query_many.argtypes = [C.POINTER(Query), C.c_size_t]
         L.wf_constraint_commit_from_evaluations.argtypes = [vp, C.POINTER(Params), vp, C.c_size_t, C.c_size_t, vp, vp, vp]
@@ -586,13 +587,16 @@ class Commitment:
         _check(load().wf_commitment_read_rows(self._h, _p(pos), len(pos), _p(out)))
         return out
 
-    def read_lde(self, trace: int, row_begin: int, n_rows: int) -> np.ndarray:
-        """Rows [row_begin, row_begin + n_rows) of one trace's matrix as stored (padded rows)."""
+    def read_lde(self, trace: int, row_begin: int, n_rows: int, row_stride: int = 1) -> np.ndarray:
+        """Rows row_begin + k * row_stride (k < n_rows) of one trace's matrix as stored (padded rows)."""
         rw = C.c_uint64()
         _check(load().wf_commitment_read_lde(self._h, trace, 0, 0, None, C.byref(rw)))
         w = ELEM_WORDS[self.field]
         out = np.empty((n_rows, rw.value, w) if w > 1 else (n_rows, rw.value), dtype=np.uint64)
-        _check(load().wf_commitment_read_lde(self._h, trace, row_begin, n_rows, _p(out), C.byref(rw)))
+        if row_stride == 1:
+            _check(load().wf_commitment_read_lde(self._h, trace, row_begin, n_rows, _p(out), C.byref(rw)))
+        else:
+            _check(load().wf_commitment_read_lde_strided(self._h, trace, row_begin, n_rows, row_stride, _p(out), C.byref(rw)))
         return out
 
     def evaluate_polys_at(self, z: np.ndarray, z_ext: int, n_cols_total: int) -> np.ndarray:

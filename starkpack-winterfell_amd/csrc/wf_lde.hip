@@ -1638,6 +1638,48 @@ int wf_commitment_read_lde(const wf_commitment *c, uint32_t trace, uint64_t row_
     return 0;
 }
 
+}  // extern "C"
+
+// rows row_begin + k * stride (k < n_rows) of a row-major matrix packed next to each other; 16 bytes per thread
+__global__ void __launch_bounds__(256) k_gather_strided_rows(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint64_t n_rows,
+                                                             uint64_t stride_q, uint32_t row_q) {  // *_q: in 16-byte units
+    const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_rows * row_q) return;
+    const uint64_t r = idx / row_q, q = idx - r * row_q;
+    dst[idx] = src[r * stride_q + q];
+}
+
+extern "C" {
+
+int wf_commitment_read_lde_strided(const wf_commitment *c, uint32_t trace, uint64_t row_begin, uint64_t n_rows, uint64_t row_stride,
+                                   void *rows_out, uint64_t *row_width_out) {
+    if (!c) return fail(WF_ERR_ARG, "commitment is null");
+    if (row_stride <= 1) return wf_commitment_read_lde(c, trace, row_begin, n_rows, rows_out, row_width_out);
+    if (row_width_out) *row_width_out = c->row_width;
+    if (n_rows == 0) return 0;
+    if (!rows_out) return fail(WF_ERR_ARG, "rows_out is null");
+    if (!c->lde) return fail(WF_ERR_ARG, "this commitment holds no rows");
+    if (trace >= c->p.n_traces) return fail(WF_ERR_TRACES, "trace %u of %u", trace, c->p.n_traces);
+    if (row_begin >= c->n_rows || (n_rows - 1) > (c->n_rows - 1 - row_begin) / row_stride)
+        return fail(WF_ERR_LEAVES, "rows %llu + k * %llu, k < %llu, leave the %llu rows of the matrix", (unsigned long long)row_begin,
+                    (unsigned long long)row_stride, (unsigned long long)n_rows, (unsigned long long)c->n_rows);
+    wf_ctx *ctx = c->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
+    const size_t rb = c->row_width * wf_elem_bytes(c->p.field);
+    if (rb % 16) return fail(WF_ERR_ARG, "rows of %zu bytes cannot be gathered in 16-byte pieces", rb);  // (dense one-column f64 rows)
+    int rc = ensure(ctx, ctx->io[4], n_rows * rb);
+    if (rc) return rc;
+    const char *src = (const char *)c->lde + ((size_t)trace * c->n_rows + row_begin) * rb;
+    const uint64_t quads = n_rows * (rb / 16);
+    hipLaunchKernelGGL(k_gather_strided_rows, dim3((uint32_t)((quads + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4 *)src,
+                       (uint4 *)ctx->io[4].p, n_rows, row_stride * (rb / 16), (uint32_t)(rb / 16));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rows_out, ctx->io[4].p, n_rows * rb, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 // fetch digests by id (id < n_rows: leaf; else node id - n_rows) into host memory
 static int fetch_digests(const wf_commitment *c, const std::vector<uint64_t> &ids, uint8_t *out) {
     if (ids.empty()) return 0;

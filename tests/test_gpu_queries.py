@@ -204,3 +204,26 @@ def test_query_many_equals_single_queries(ctx, orc, capi):
     fri.close()
     tcom.close()
     ccom.close()
+
+
+def test_read_lde_strided(ctx, orc, capi):
+    """The constraint evaluation domain's rows of a resident trace LDE (every (lde blowup / ce blowup)-th row) in one read."""
+    rng = np.random.default_rng(5)
+    logR, logB = 9, 3
+    N = 1 << (logR + logB)
+    for field, n_cols in ((F64, 5), (F128, 3)):
+        traces = [rand_cols(rng, field, n_cols, 1 << logR) for _ in range(2)]
+        want = orc.build_trace_commitment(field, traces, 1, logR, logB, 7 if field == F64 else 3)
+        com, _ = ctx.trace_commit_resident(capi.make_params(field, 1, logR, logB, n_cols, 2), [c for t in traces for c in t])
+        for t in range(2):
+            for begin, stride in ((0, 4), (0, 2), (3, 8), (5, 1), (N - 1, 7)):
+                n = (N - 1 - begin) // stride + 1
+                got = com.read_lde(t, begin, n, stride)
+                assert np.array_equal(got, want["lde"][t][begin::stride][:n])
+            assert com.read_lde(t, 8, 3, 16).shape[0] == 3
+        with pytest.raises(capi.WfError) as e:
+            com.read_lde(0, 1, N // 4 + 1, 4)      # the last row would be N + 1
+        assert e.value.code == -18
+        with pytest.raises(capi.WfError):
+            com.read_lde(2, 0, 1, 4)
+        com.close()
