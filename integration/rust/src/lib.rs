@@ -35,6 +35,7 @@ use core::marker::PhantomData;
 use std::ffi::CStr;
 use std::os::raw::c_void;
 
+use air::DeepCompositionCoefficients;
 use crypto::{BatchMerkleProof, ElementHasher, Hasher, MerkleTree};
 use math::{fields::f128, fields::f64, FieldElement, StarkField};
 use prover::{ColMatrix, CompositionPoly, ConstraintCommitment, RowMatrix, StarkDomain};
@@ -314,6 +315,101 @@ where
         check(rc).expect("failed to evaluate polynomials");
         out
     }
+}
+
+impl<'a, B, E, H> ResidentCommitment<'a, E, H>
+where
+    B: WfField,
+    E: FieldElement<BaseField = B>,
+    H: WfHasher,
+{
+    /// All of `ConstraintEvaluationTable::into_comb_poly` for every packed trace (division by the divisors, offset
+    /// interpolation), STARKPack's `final_coeff` combination, `into_poly` and `build_constraint_commitment`
+    /// (prover/src/lib.rs:435-472) in one call, resident.  `tables[i]` = the evaluation columns of packed trace i with their
+    /// divisors ((numerator degree a, numerator constant b, exemption points): `ConstraintDivisor` has one numerator term).
+    pub fn commit_evaluation_tables(
+        ctx: &'a WfContext, tables: &[Vec<(&[E], (u64, B, Vec<B>))>], trace_length: usize, num_cols: usize, final_coeff: E,
+        domain: &StarkDomain<B>,
+    ) -> Self {
+        let ce = tables[0][0].0.len();
+        let p = params::<B, E>(trace_length, num_cols, 1, domain);
+        let mut col_ptrs: Vec<Vec<*const c_void>> = Vec::new();
+        let mut divisors: Vec<Vec<WfDivisor>> = Vec::new();
+        for t in tables {
+            col_ptrs.push(t.iter().map(|(c, _)| c.as_ptr() as *const c_void).collect());
+            divisors.push(
+                t.iter()
+                    .map(|(_, (a, b, ex))| {
+                        let mut constant = [0u8; 16];
+                        let raw = unsafe { core::slice::from_raw_parts(b as *const B as *const u8, core::mem::size_of::<B>()) };
+                        constant[..raw.len()].copy_from_slice(raw);
+                        WfDivisor {
+                            numerator_degree: *a,
+                            numerator_constant: constant,
+                            exemptions: ex.as_ptr() as *const c_void,
+                            n_exemptions: ex.len() as u32,
+                        }
+                    })
+                    .collect(),
+            );
+        }
+        let c_tables: Vec<WfEvaluationTable> = col_ptrs
+            .iter()
+            .zip(divisors.iter())
+            .map(|(c, d)| WfEvaluationTable { columns: c.as_ptr(), divisors: d.as_ptr(), n_columns: c.len() as u32 })
+            .collect();
+        let mut raw = core::ptr::null_mut();
+        let rc = unsafe {
+            wf_constraint_commit_from_tables(
+                ctx.raw, &p, c_tables.as_ptr(), c_tables.len(), ce, &final_coeff as *const E as *const c_void, core::ptr::null(),
+                &mut raw,
+            )
+        };
+        check(rc).expect("failed to build constraint commitment");
+        Self { raw, n_traces: 1, n_cols: num_cols, _ctx: PhantomData, _types: PhantomData }
+    }
+
+    /// The rows of the constraint evaluation domain (every `stride`-th LDE row, `stride` = lde blowup / ce blowup) of one
+    /// trace's extended matrix, `row_width` base elements each, for the AIR's evaluator on the host
+    /// (`TraceLde::read_main_trace_frame_into`, prover/src/trace/trace_lde.rs:78-98).
+    pub fn read_ce_rows(&self, trace: usize, stride: usize) -> (Vec<B>, usize) {
+        let (mut n_rows, mut row_elems, mut depth, mut width) = (0u64, 0u64, 0u32, 0u64);
+        check(unsafe { wf_commitment_info(self.raw, &mut n_rows, &mut row_elems, &mut depth) }).expect("info");
+        check(unsafe { wf_commitment_read_lde(self.raw, trace as u32, 0, 0, core::ptr::null_mut(), &mut width) }).expect("width");
+        let n = n_rows as usize / stride;
+        let mut rows: Vec<B> = unsafe { uninit_vector(n * width as usize) };
+        let rc = unsafe {
+            wf_commitment_read_lde_strided(
+                self.raw, trace as u32, 0, n as u64, stride as u64, rows.as_mut_ptr() as *mut c_void, &mut width,
+            )
+        };
+        check(rc).expect("failed to read the extended trace");
+        (rows, width as usize)
+    }
+}
+
+/// `DeepCompositionPoly::new(z, cc)` + `add_trace_polys` + `add_composition_poly` + `evaluate(&domain)` +
+/// `fri_prover.build_layers`'s first step (prover/src/lib.rs:508-560): the composition over the polynomials the resident
+/// commitments hold, its LDE and the FRI prover's first layer, all in HBM.  `cc.traces` flattened handle by handle, trace by
+/// trace, column by column.  The out-of-domain frames are not arguments: the composer's result does not depend on them
+/// (`wf_lde.h`, wf_deep_compose).
+pub fn deep_compose_into_fri<B, E, H>(
+    ctx: &WfContext, traces: &[&ResidentCommitment<E, H>], constraints: &ResidentCommitment<E, H>, z: E,
+    cc: &DeepCompositionCoefficients<E>, fri: *mut WfFriProver, lde_blowup: usize,
+) where
+    B: WfField,
+    E: FieldElement<BaseField = B>,
+    H: WfHasher,
+{
+    let handles: Vec<*const WfCommitment> = traces.iter().map(|t| t.raw as *const WfCommitment).collect();
+    let flat: Vec<E> = cc.traces.iter().flatten().copied().collect();
+    let rc = unsafe {
+        wf_deep_compose(
+            ctx.raw, handles.as_ptr(), handles.len(), constraints.raw, &z as *const E as *const c_void, E::EXTENSION_DEGREE as u32,
+            flat.as_ptr() as *const c_void, cc.constraints.as_ptr() as *const c_void, core::ptr::null_mut(), fri, lde_blowup,
+        )
+    };
+    check(rc).expect("failed to build the DEEP composition polynomial");
 }
 
 impl<'a, E: FieldElement, H: WfHasher> Drop for ResidentCommitment<'a, E, H> {
