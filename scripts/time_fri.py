@@ -35,3 +35,17 @@ for rep in range(4):
     fri.reset()
     print(f"rep {rep}: begin_poly (H2D {poly.nbytes >> 20} MiB + LDE) {(t1 - t0) * 1e3:.2f} ms, {n_layers} layers + remainder {(t2 - t1) * 1e3:.2f} ms",
           [round(x, 3) for x in per])
+
+# per-launch device times of one more run (events around every launch)
+ctx.profile_enable(2)
+fri.begin_poly(poly, blowup)
+for i in range(n_layers):
+    fri.commit_layer()
+    fri.fold(alphas[i])
+fri.set_remainder(1 << 12)
+marks = ctx.profile_read()
+ctx.profile_enable(0)
+acc = {}
+for k, v in marks:
+    acc.setdefault(k, []).append(round(v, 4))
+print({k: v[:3] for k, v in acc.items()})
