@@ -454,6 +454,11 @@ int wf_evaluate_columns_at(wf_ctx *ctx, uint32_t field, uint32_t ext_degree, con
                            size_t n_cols, size_t n, const void *z, uint32_t z_ext_degree, void *out);
 /* The same on the polynomials a resident commitment keeps in HBM ([n_traces][n_cols] columns). */
 int wf_commitment_evaluate_polys_at(const wf_commitment *c, const void *z, uint32_t z_ext_degree, void *out);
+/* The same at up to four points in one call and one host round trip -- TracePolyTable::get_ood_frame(z) is the two points
+ * z and z * g (prover/src/trace/poly_table.rs:60-73): points = n_points elements of z_ext_degree coordinates, out receives
+ * [n_points][n_traces * n_cols] elements. */
+int wf_commitment_evaluate_polys_at_points(const wf_commitment *c, const void *points, uint32_t n_points, uint32_t z_ext_degree,
+                                           void *out);
 
 /* ---- DEEP composition polynomial (the caller between the out-of-domain frame and the DEEP LDE + FRI) ------------------ */
 

@@ -108,6 +108,9 @@ extern "C" {
     pub fn wf_commitment_read_lde(
         c: *const WfCommitment, trace: u32, row_begin: u64, n_rows: u64, rows_out: *mut c_void, row_width_out: *mut u64,
     ) -> c_int;
+    pub fn wf_commitment_evaluate_polys_at_points(
+        c: *const WfCommitment, points: *const c_void, n_points: u32, z_ext_degree: u32, out: *mut c_void,
+    ) -> c_int;
     pub fn wf_commitment_query_many(queries: *mut WfQuery, n_queries: usize) -> c_int;
     pub fn wf_constraint_commit_from_evaluations(
         ctx: *mut WfCtx, p: *const WfParams, combined_evaluations: *const *const c_void, n_tables: usize, ce_domain_size: usize,

@@ -22,7 +22,7 @@ SYMBOLS = [
     "wf_ctx_release_cached", "wf_plan_digits", "wf_commitment_query", "wf_ctx_profile_enable", "wf_ctx_profile_read", "wf_params_check", "wf_elem_bytes", "wf_row_width", "wf_column_bytes", "wf_lde_bytes", "wf_digests_bytes",
     "wf_trace_commit", "wf_constraint_commit", "wf_trace_commit_dev", "wf_constraint_commit_dev",
     "wf_trace_commit_shard_dev", "wf_merkle_build_dev", "wf_trace_commit_resident", "wf_constraint_commit_resident", "wf_commitment_destroy", "wf_commitment_root",
-    "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_read_lde", "wf_commitment_read_lde_strided", "wf_deep_compose", "wf_constraint_commit_from_evaluations", "wf_constraint_commit_from_tables", "wf_commitment_query_many", "wf_commitment_prove", "wf_commitment_prove_batch",
+    "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_read_lde", "wf_commitment_read_lde_strided", "wf_deep_compose", "wf_commitment_evaluate_polys_at_points", "wf_constraint_commit_from_evaluations", "wf_constraint_commit_from_tables", "wf_commitment_query_many", "wf_commitment_prove", "wf_commitment_prove_batch",
     "wf_evaluate_columns_at", "wf_commitment_evaluate_polys_at", "wf_fri_layer_commit", "wf_fri_apply_drp", "wf_fri_layer_commit_dev", "wf_fri_apply_drp_dev",
     "wf_fri_prover_create", "wf_fri_prover_destroy", "wf_fri_num_layers", "wf_fri_prover_begin", "wf_fri_prover_begin_dev", "wf_fri_prover_begin_poly",
     "wf_fri_prover_commit_layer", "wf_fri_prover_fold", "wf_fri_prover_set_remainder", "wf_fri_prover_num_layers",
@@ -158,6 +158,7 @@ def load():
         L.wf_commitment_read_lde.argtypes = [vp, u32, C.c_uint64, C.c_uint64, vp, C.POINTER(C.c_uint64)]
         L.wf_commitment_read_lde_strided.argtypes = [vp, u32, C.c_uint64, C.c_uint64, C.c_uint64, vp, C.POINTER(C.c_uint64)]
         L.wf_deep_compose.argtypes = [vp, vp, C.c_size_t, vp, vp, u32, vp, vp, vp, vp, C.c_size_t]
+        L.wf_commitment_evaluate_polys_at_points.argtypes = [vp, vp, u32, u32, vp]
         L.wf_commitment_query_many.argtypes = [C.POINTER(Query), C.c_size_t]
         L.wf_constraint_commit_from_evaluations.argtypes = [vp, C.POINTER(Params), vp, C.c_size_t, C.c_size_t, vp, vp, vp]
         L.wf_constraint_commit_from_tables.argtypes = [vp, C.POINTER(Params), C.POINTER(EvaluationTable), C.c_size_t, C.c_size_t, vp, vp, vp]
@@ -604,6 +605,14 @@ class Commitment:
         w = ELEM_WORDS[self.field]
         out = np.empty((n_cols_total, z_ext, w) if w > 1 else (n_cols_total, z_ext), dtype=np.uint64)
         _check(load().wf_commitment_evaluate_polys_at(self._h, _p(zz), z_ext, _p(out)))
+        return out
+
+    def evaluate_polys_at_points(self, points: np.ndarray, n_points: int, z_ext: int, n_cols_total: int) -> np.ndarray:
+        """An out-of-domain frame (z, z g) in one round trip: [n_points][n_cols_total] elements of z's field."""
+        zz = np.ascontiguousarray(points, dtype=np.uint64)
+        w = ELEM_WORDS[self.field]
+        out = np.empty((n_points, n_cols_total, z_ext, w) if w > 1 else (n_points, n_cols_total, z_ext), dtype=np.uint64)
+        _check(load().wf_commitment_evaluate_polys_at_points(self._h, _p(zz), n_points, z_ext, _p(out)))
         return out
 
     def prove(self, index: int):

@@ -151,7 +151,8 @@ struct EvalAtArgs {
     T *out;           // [n_cols] elements of WZ coordinates
     uint64_t n;
     uint32_t n_blocks;  // ceil(n / EVAL_BLOCK)
-    T z[3];
+    uint32_t n_cols;
+    T z[4][3];          // up to four points per launch (blockIdx.z): an out-of-domain frame is z and z g
 };
 
 template <class F, int WC, int WZ>
@@ -160,12 +161,12 @@ __global__ void __launch_bounds__(256) k_eval_columns_at(EvalAtArgs<F> a) {
     typedef Ext<F, WZ> E;
     __shared__ __attribute__((aligned(16))) unsigned char sh_raw[256 * sizeof(E)];
     E *sh = reinterpret_cast<E *>(sh_raw);
-    const uint32_t blk = blockIdx.x, col = blockIdx.y, t = threadIdx.x;
+    const uint32_t blk = blockIdx.x, col = blockIdx.y, pt = blockIdx.z, t = threadIdx.x;
     const T *poly = a.polys + (uint64_t)col * a.n * WC;
     const uint64_t base = (uint64_t)blk * EVAL_BLOCK;
     E z, zp;
 #pragma unroll
-    for (int w = 0; w < WZ; w++) z.c[w] = a.z[w];
+    for (int w = 0; w < WZ; w++) z.c[w] = a.z[pt][w];
     zp = z;  // z^256
 #pragma unroll 1
     for (int q = 0; q < 8; q++) zp = ext_mul<F, WZ>(zp, zp);
@@ -213,7 +214,7 @@ __global__ void __launch_bounds__(256) k_eval_columns_at(EvalAtArgs<F> a) {
         }
         const E r = ext_mul<F, WZ>(sh[0], f);
 #pragma unroll
-        for (int w = 0; w < WZ; w++) a.partial[((uint64_t)col * a.n_blocks + blk) * WZ + w] = r.c[w];
+        for (int w = 0; w < WZ; w++) a.partial[(((uint64_t)pt * a.n_cols + col) * a.n_blocks + blk) * WZ + w] = r.c[w];
     }
 }
 
@@ -222,7 +223,7 @@ __global__ void __launch_bounds__(256) k_eval_columns_sum(EvalAtArgs<F> a) {
     typedef Ext<F, WZ> E;
     __shared__ __attribute__((aligned(16))) unsigned char sh_raw[256 * sizeof(E)];
     E *sh = reinterpret_cast<E *>(sh_raw);
-    const uint32_t col = blockIdx.x, t = threadIdx.x;
+    const uint32_t col = blockIdx.y * a.n_cols + blockIdx.x, t = threadIdx.x;  // (point, column)
     E acc;
 #pragma unroll
     for (int w = 0; w < WZ; w++) acc.c[w] = F::zero();

@@ -2051,21 +2051,24 @@ int wf_fri_apply_drp(wf_ctx *ctx, uint32_t field, uint32_t ext, const void *tran
 
 template <class F>
 static int eval_columns_at_dev(wf_ctx *ctx, hipStream_t st, const void *d_polys, size_t n_cols, size_t n, uint32_t ext_c,
-                               const void *z_host, uint32_t ext_z, void *d_out) {
+                               const void *z_host, uint32_t ext_z, void *d_out, uint32_t n_points = 1) {
     typedef typename F::T T;
     EvalAtArgs<F> a;
     memset(&a, 0, sizeof(a));
     a.polys = (const T *)d_polys;
     a.out = (T *)d_out;
     a.n = n;
-    memcpy(a.z, z_host, ext_z * sizeof(T));
-    for (uint32_t w = 0; w < ext_z; w++)
-        if (!F::is_valid(a.z[w])) return fail(WF_ERR_ARG, "z is not a valid field element");
+    a.n_cols = (uint32_t)n_cols;
+    for (uint32_t q = 0; q < n_points; q++) {
+        memcpy(a.z[q], (const T *)z_host + (size_t)q * ext_z, ext_z * sizeof(T));
+        for (uint32_t w = 0; w < ext_z; w++)
+            if (!F::is_valid(a.z[q][w])) return fail(WF_ERR_ARG, "z is not a valid field element");
+    }
     a.n_blocks = (uint32_t)((n + EVAL_BLOCK - 1) / EVAL_BLOCK);
-    int rcp = ensure(ctx, ctx->hash_tmp, n_cols * a.n_blocks * ext_z * sizeof(T));  // (block values; no hashing runs alongside)
+    int rcp = ensure(ctx, ctx->hash_tmp, (size_t)n_points * n_cols * a.n_blocks * ext_z * sizeof(T));  // (block values; no hashing runs alongside)
     if (rcp) return rcp;
     a.partial = (T *)ctx->hash_tmp.p;
-    const dim3 grid(a.n_blocks, (uint32_t)n_cols), grid2((uint32_t)n_cols), block(256);
+    const dim3 grid(a.n_blocks, (uint32_t)n_cols, n_points), grid2((uint32_t)n_cols, n_points), block(256);
     prof_mark(ctx, st, "ood.evaluate_columns_at");
     const uint32_t key = ext_c * 10 + ext_z;
     switch (key) {
@@ -2110,6 +2113,28 @@ int wf_commitment_evaluate_polys_at(const wf_commitment *c, const void *z, uint3
     rc = c->p.field == WF_FIELD_F64
              ? eval_columns_at_dev<F64>(ctx, st, c->polys, n_cols, n, c->p.ext_degree, z, z_ext_degree, ctx->io[4].p)
              : eval_columns_at_dev<F128>(ctx, st, c->polys, n_cols, n, c->p.ext_degree, z, z_ext_degree, ctx->io[4].p);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, ctx->io[4].p, out_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int wf_commitment_evaluate_polys_at_points(const wf_commitment *c, const void *points, uint32_t n_points, uint32_t z_ext_degree,
+                                           void *out) {
+    if (!c || !points || !out) return fail(WF_ERR_ARG, "null argument");
+    if (n_points < 1 || n_points > 4) return fail(WF_ERR_ARG, "1 to 4 points per call (got %u)", n_points);
+    if (!c->polys) return fail(WF_ERR_ARG, "this commitment holds no polynomials (FRI layer)");
+    wf_ctx *ctx = c->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    WF_ENTER(ctx, ctx->stream);
+    const size_t n_cols = (size_t)c->p.n_cols * c->p.n_traces, n = (size_t)1 << c->p.log2_trace_len;
+    const size_t out_bytes = (size_t)n_points * n_cols * z_ext_degree * wf_elem_bytes(c->p.field);
+    int rc = ensure(ctx, ctx->io[4], out_bytes);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    rc = c->p.field == WF_FIELD_F64
+             ? eval_columns_at_dev<F64>(ctx, st, c->polys, n_cols, n, c->p.ext_degree, points, z_ext_degree, ctx->io[4].p, n_points)
+             : eval_columns_at_dev<F128>(ctx, st, c->polys, n_cols, n, c->p.ext_degree, points, z_ext_degree, ctx->io[4].p, n_points);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, ctx->io[4].p, out_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

@@ -38,6 +38,14 @@ def test_ood_frame_of_resident_commitment(ctx, orc, capi):
         for t in range(n_traces):
             for c in range(n_cols):
                 assert np.array_equal(got[t * n_cols + c], orc.eval_column_at(F64, want["polys"][t][c], 1, point, 2))
+    # the frame in one call
+    frame = com.evaluate_polys_at_points(np.concatenate([z, zg]), 2, 2, n_cols * n_traces)
+    for q, point in enumerate((z, zg)):
+        assert np.array_equal(frame[q], com.evaluate_polys_at(point, 2, n_cols * n_traces))
+    four = com.evaluate_polys_at_points(np.concatenate([zg, z, z, zg]), 4, 2, n_cols * n_traces)
+    assert np.array_equal(four[0], frame[1]) and np.array_equal(four[1], frame[0]) and np.array_equal(four[3], frame[1])
+    with pytest.raises(capi.WfError):
+        com.evaluate_polys_at_points(np.concatenate([z] * 5), 5, 2, n_cols * n_traces)
     with pytest.raises(capi.WfError):
         com.evaluate_polys_at(np.array([2**64 - 1, 0], dtype=np.uint64), 2, n_cols * n_traces)  # invalid element
     com.close()
