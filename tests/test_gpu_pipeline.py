@@ -86,3 +86,97 @@ def test_prove_shaped_pipeline(ctx, orc, capi):
     fri.close()
     ccom.close()
     tcom.close()
+
+
+def test_prove_shaped_pipeline_resident_chain(ctx, orc, capi):
+    """The same chain with this round's entry points, nothing but the (stand-in) constraint evaluator on the host: packed
+    trace commitment -> strided read of the constraint evaluation domain's rows -> constraint commitment from the
+    evaluation TABLES of both packed traces (divisors, interpolation, final_coeff combination) -> out-of-domain frames in
+    one call each -> DEEP composition straight into the FRI prover -> commit phase -> every tree queried in one round trip."""
+    L = orc.lib()
+    rng = np.random.default_rng(20261004)
+    logR, logB, log_ce, n_cols, n_traces, ext, n_comp = 9, 3, 1, 5, 2, 2, 2
+    R, N, ce, offset = 1 << logR, 1 << (logR + logB), 1 << (logR + log_ce), 7
+    folding, max_rem = 4, 7
+    re = lambda k=1: rand_cols(rng, F64, 1, ext * k)[0]                         # noqa: E731
+
+    traces = [rand_cols(rng, F64, n_cols, R) for _ in range(n_traces)]
+    want_t = orc.build_trace_commitment(F64, traces, 1, logR, logB, offset)
+    tcom, _ = ctx.trace_commit_resident(capi.make_params(F64, 1, logR, logB, n_cols, n_traces), [c for t in traces for c in t])
+    assert tcom.root() == want_t["root"]
+
+    # the evaluator's input: rows of the constraint evaluation domain = every (lde / ce)-th row of the extended trace
+    stride = N // ce
+    for t in range(n_traces):
+        assert np.array_equal(tcom.read_lde(t, 0, ce, stride), want_t["lde"][t][::stride])
+
+    # the evaluator's output (stand-in): per packed trace a transition column and a boundary column over the ce domain
+    g_trace = L.orc_f64_get_root_of_unity(logR)
+    one = np.array([L.orc_f64_new(1)], dtype=np.uint64)
+    divisors = [(R, one, np.array([L.orc_f64_exp(g_trace, R - 1)], dtype=np.uint64)),       # (x^n - 1) / (x - g^(n-1))
+                (1, one, None)]                                                               # x - 1: an assertion at step 0
+    tables = [[(rand_cols(rng, F64, 1, ce * ext)[0], d) for d in divisors] for _ in range(n_traces)]
+    final_coeff = re()
+    combined = [orc.combine_evaluation_table(F64, ext, [c for c, _ in tab], [d for _, d in tab], offset) for tab in tables]
+    comp = orc.composition_poly_from_evaluations(F64, ext, combined, logR, n_comp, offset, final_coeff)
+    want_c = orc.build_constraint_commitment(F64, comp, ext, logR, logB, offset)
+    ccom, _ = ctx.constraint_commit_from_tables(capi.make_params(F64, ext, logR, logB, n_comp, 1), tables, final_coeff)
+    assert ccom.root() == want_c["root"]
+
+    # out-of-domain frames
+    z = re()
+    zg = orc.ext_mul(F64, ext, z, np.array([g_trace, 0], dtype=np.uint64))
+    frame = tcom.evaluate_polys_at_points(np.concatenate([z, zg]), 2, ext, n_cols * n_traces)
+    for q, point in enumerate((z, zg)):
+        for t in range(n_traces):
+            for c in range(n_cols):
+                assert np.array_equal(frame[q][t * n_cols + c], orc.eval_column_at(F64, want_t["polys"][t][c], 1, point, ext))
+    ood_c = ccom.evaluate_polys_at(z, ext, n_comp)
+    for c in range(n_comp):
+        assert np.array_equal(ood_c[c], orc.eval_column_at(F64, comp[c], ext, z, ext))
+
+    # DEEP composition into the FRI prover, commit phase
+    cc_t = [re() for _ in range(n_cols * n_traces)]
+    cc_c = [re() for _ in range(n_comp)]
+    want_deep = orc.deep_compose(F64, ext, R, [[(p, 1) for p in want_t["polys"][t]] for t in range(n_traces)], comp, z, cc_t, cc_c)
+    fri = capi.FriProver(ctx, F64, ext, folding, 1 << logB, max_rem, offset)
+    got_deep = ctx.deep_compose(F64, ext, R, [tcom], ccom, z, np.concatenate(cc_t), np.concatenate(cc_c), fri=fri, lde_blowup=1 << logB)
+    assert np.array_equal(got_deep, want_deep)
+    cur = orc.evaluate_poly_with_offset(F64, want_deep, R, ext, orc.get_twiddles(F64, R), L.orc_f64_new(offset), 1 << logB)
+    size, want_layers = N, []
+    for i in range(capi.fri_num_layers(folding, 1 << logB, max_rem, N)):
+        want = orc.fri_layer_commit(F64, cur, size, ext, folding)
+        assert fri.commit_layer() == want["root"]
+        alpha = re()
+        cur = orc.apply_drp(F64, want["transposed"], size // folding, ext, folding, offset, alpha)
+        fri.fold(alpha)
+        want_layers.append(want)
+        size //= folding
+    fri.set_remainder(size)
+
+    # query phase: one round trip
+    positions = np.sort(rng.choice(N, size=23, replace=False)).astype(np.uint64)
+    requests = [(tcom, positions, True), (ccom, positions, True)]
+    folded, domain = positions, N
+    for i in range(len(want_layers)):
+        folded = capi.fri_fold_positions(folded, domain, folding)
+        requests.append((fri.layer(i), folded, True))
+        domain //= folding
+    answers = capi.query_many(requests)
+    plist = [int(p) for p in positions]
+    rows_t, proof_t = answers[0]
+    for i, p in enumerate(plist):
+        assert np.array_equal(rows_t[i], np.concatenate([want_t["lde"][t][p, :n_cols] for t in range(n_traces)]))
+    assert proof_t == orc.merkle_prove_batch(want_t["nodes"], want_t["leaves"], plist)
+    rows_c, proof_c = answers[1]
+    assert np.array_equal(rows_c.reshape(len(plist), -1), want_c["lde"].reshape(N, -1)[positions.astype(np.int64)][:, :n_comp * ext])
+    assert proof_c == orc.merkle_prove_batch(want_c["nodes"], want_c["leaves"], plist)
+    domain = N
+    for (com, pos, _), (rows, proof), want in zip(requests[2:], answers[2:], want_layers):
+        tr = want["transposed"].reshape(domain // folding, folding * ext)
+        assert np.array_equal(rows, tr[pos.astype(np.int64)])
+        assert proof == orc.merkle_prove_batch(want["nodes"], want["leaves"], [int(p) for p in pos])
+        domain //= folding
+    fri.close()
+    ccom.close()
+    tcom.close()
