@@ -141,19 +141,54 @@ __global__ void __launch_bounds__(256) k_fri_drp(DrpArgs<F> a) {
 // EVAL_BLOCK coefficients from b * EVAL_BLOCK on -- lane t those at t, t + 256, .. (coalesced), Horner in z^256 -- folds
 // its 256 lane values sum_t z^t v_t pairwise through LDS and scales by z^(b * EVAL_BLOCK); k_eval_columns_sum adds the
 // block values of a column.  (One work-group per column with a contiguous chunk per lane: 1.35 ms for 8 columns of 2^20.)
-constexpr uint32_t EVAL_BLOCK = 4096;
+constexpr uint32_t EVAL_BLOCK = 4096, EVAL_POINTS = 2;
+
+// powers of a point prepared by the host: pw[s] = z^(2^s) for the exponents the two kernels use
+//   s = 0..7   pairwise fold of the 256 lane values of a block          (k_eval_columns_at)
+//   s = 8      Horner step of a lane: z^256
+//   s = 12..19 pairwise fold of 256 lane values over BLOCKS: Z^(2^(s-12)), Z = z^EVAL_BLOCK   (k_eval_columns_sum)
+//   s = 20     Horner step of a lane over blocks: Z^256
+constexpr int EVAL_POWERS = 21;
 
 template <class F>
 struct EvalAtArgs {
     typedef typename F::T T;
     const T *polys;   // [n_cols] columns of n elements of WC coordinates
-    T *partial;       // [n_cols][n_blocks] elements of WZ coordinates (k_eval_columns_at -> k_eval_columns_sum)
-    T *out;           // [n_cols] elements of WZ coordinates
+    T *partial;       // [points][n_cols][n_blocks] elements of WZ coordinates: sum_k c_(base + k) z^k of every block
+    T *out;           // [points][n_cols] elements of WZ coordinates
     uint64_t n;
     uint32_t n_blocks;  // ceil(n / EVAL_BLOCK)
     uint32_t n_cols;
-    T z[4][3];          // up to four points per launch (blockIdx.z): an out-of-domain frame is z and z g
+    T pw[EVAL_POINTS][EVAL_POWERS][3];  // up to two points per launch (an out-of-domain frame is z and z g)
 };
+
+template <class F, int WZ>
+__device__ __forceinline__ Ext<F, WZ> eval_power(const EvalAtArgs<F> &a, uint32_t pt, uint32_t s) {
+    Ext<F, WZ> r;
+#pragma unroll
+    for (int w = 0; w < WZ; w++) r.c[w] = a.pw[pt][s][w];
+    return r;
+}
+
+// sum_t y^t v_t over the 256 lanes: v_t <- v_2t + y^(2^q) v_2t+1, multipliers a.pw[pt][s0 + q]; result in sh[0]
+template <class F, int WZ>
+__device__ __forceinline__ void eval_fold(const EvalAtArgs<F> &a, uint32_t pt, uint32_t s0, Ext<F, WZ> *sh, uint32_t t) {
+    typedef Ext<F, WZ> E;
+    uint32_t q = 0;
+#pragma unroll 1
+    for (uint32_t width = 128; width >= 1; width >>= 1, q++) {
+        E v;
+        if (t < width) {
+            const E lo = sh[2 * t], hi = sh[2 * t + 1];
+            v = ext_mul<F, WZ>(hi, eval_power<F, WZ>(a, pt, s0 + q));
+#pragma unroll
+            for (int w = 0; w < WZ; w++) v.c[w] = F::add(v.c[w], lo.c[w]);
+        }
+        __syncthreads();
+        if (t < width) sh[t] = v;
+        __syncthreads();
+    }
+}
 
 template <class F, int WC, int WZ>
 __global__ void __launch_bounds__(256) k_eval_columns_at(EvalAtArgs<F> a) {
@@ -164,87 +199,64 @@ __global__ void __launch_bounds__(256) k_eval_columns_at(EvalAtArgs<F> a) {
     const uint32_t blk = blockIdx.x, col = blockIdx.y, pt = blockIdx.z, t = threadIdx.x;
     const T *poly = a.polys + (uint64_t)col * a.n * WC;
     const uint64_t base = (uint64_t)blk * EVAL_BLOCK;
-    E z, zp;
+    // every coefficient of this lane is requested before the first one is used (the Horner chain below is serial)
+    constexpr int STEPS = EVAL_BLOCK / 256;
+    T cf[STEPS][WC];
 #pragma unroll
-    for (int w = 0; w < WZ; w++) z.c[w] = a.z[pt][w];
-    zp = z;  // z^256
-#pragma unroll 1
-    for (int q = 0; q < 8; q++) zp = ext_mul<F, WZ>(zp, zp);
+    for (int j = 0; j < STEPS; j++) {
+        const uint64_t k = base + t + 256u * (uint32_t)j;
+#pragma unroll
+        for (int w = 0; w < WC; w++) cf[j][w] = k < a.n ? poly[k * WC + w] : F::zero();
+    }
+    const E zp = eval_power<F, WZ>(a, pt, 8);  // z^256
     E acc;
 #pragma unroll
-    for (int w = 0; w < WZ; w++) acc.c[w] = F::zero();
-#pragma unroll 1
-    for (int j = EVAL_BLOCK / 256 - 1; j >= 0; j--) {
-        const uint64_t k = base + t + 256u * (uint32_t)j;
-        acc = ext_mul<F, WZ>(acc, zp);
-        if (k < a.n) {
+    for (int w = 0; w < WZ; w++) acc.c[w] = w < WC ? cf[STEPS - 1][w < WC ? w : 0] : F::zero();
 #pragma unroll
-            for (int w = 0; w < WC; w++) acc.c[w] = F::add(acc.c[w], poly[k * WC + w]);
-        }
+    for (int j = STEPS - 2; j >= 0; j--) {
+        acc = ext_mul<F, WZ>(acc, zp);
+#pragma unroll
+        for (int w = 0; w < WC; w++) acc.c[w] = F::add(acc.c[w], cf[j][w]);
     }
-    // sum_t z^t acc_t: v_t <- v_2t + y v_2t+1 with y = z, z^2, z^4, ..
-    E y = z;
     sh[t] = acc;
     __syncthreads();
-#pragma unroll 1
-    for (uint32_t width = 128; width >= 1; width >>= 1) {
-        E v;
-        if (t < width) {
-            const E lo = sh[2 * t], hi = sh[2 * t + 1];
-            v = ext_mul<F, WZ>(hi, y);
-#pragma unroll
-            for (int w = 0; w < WZ; w++) v.c[w] = F::add(v.c[w], lo.c[w]);
-        }
-        __syncthreads();
-        if (t < width) sh[t] = v;
-        __syncthreads();
-        y = ext_mul<F, WZ>(y, y);
-    }
+    eval_fold<F, WZ>(a, pt, 0, sh, t);
     if (t == 0) {
-        // z^base, base = blk * 2^12: zb = z^4096 = y after the eight squarings above (z^256) and four more
-        E zb = y;  // y = z^256 here
-#pragma unroll 1
-        for (int q = 0; q < 4; q++) zb = ext_mul<F, WZ>(zb, zb);
-        E f;  // zb^blk by square and multiply
-#pragma unroll
-        for (int w = 0; w < WZ; w++) f.c[w] = w == 0 ? F::one() : F::zero();
-        for (uint32_t e = blk; e; e >>= 1) {
-            if (e & 1) f = ext_mul<F, WZ>(f, zb);
-            zb = ext_mul<F, WZ>(zb, zb);
-        }
-        const E r = ext_mul<F, WZ>(sh[0], f);
+        const E r = sh[0];
 #pragma unroll
         for (int w = 0; w < WZ; w++) a.partial[(((uint64_t)pt * a.n_cols + col) * a.n_blocks + blk) * WZ + w] = r.c[w];
     }
 }
 
+// P(z) = sum_b partial_b Z^b, Z = z^EVAL_BLOCK: the same two-level Horner over the blocks of one column and point
 template <class F, int WZ>
 __global__ void __launch_bounds__(256) k_eval_columns_sum(EvalAtArgs<F> a) {
     typedef Ext<F, WZ> E;
     __shared__ __attribute__((aligned(16))) unsigned char sh_raw[256 * sizeof(E)];
     E *sh = reinterpret_cast<E *>(sh_raw);
-    const uint32_t col = blockIdx.y * a.n_cols + blockIdx.x, t = threadIdx.x;  // (point, column)
+    const uint32_t pt = blockIdx.y, col = pt * a.n_cols + blockIdx.x, t = threadIdx.x;  // (point, column)
+    const E step = eval_power<F, WZ>(a, pt, 20);  // Z^256
     E acc;
 #pragma unroll
     for (int w = 0; w < WZ; w++) acc.c[w] = F::zero();
-    for (uint32_t b = t; b < a.n_blocks; b += 256)
+    const uint32_t rounds = (a.n_blocks + 255) / 256;
+#pragma unroll 1
+    for (int j = (int)rounds - 1; j >= 0; j--) {  // lane t: blocks t, t + 256, ..
+        const uint32_t blk = t + 256u * (uint32_t)j;
+        if (j != (int)rounds - 1) acc = ext_mul<F, WZ>(acc, step);
+        if (blk < a.n_blocks) {
 #pragma unroll
-        for (int w = 0; w < WZ; w++) acc.c[w] = F::add(acc.c[w], a.partial[((uint64_t)col * a.n_blocks + b) * WZ + w]);
+            for (int w = 0; w < WZ; w++) acc.c[w] = F::add(acc.c[w], a.partial[((uint64_t)col * a.n_blocks + blk) * WZ + w]);
+        }
+    }
     sh[t] = acc;
     __syncthreads();
-    for (uint32_t width = 128; width >= 1; width >>= 1) {
-        if (t < width) {
-            E lo = sh[t];
-            const E hi = sh[t + width];
+    eval_fold<F, WZ>(a, pt, 12, sh, t);
+    if (t == 0) {
+        const E r = sh[0];
 #pragma unroll
-            for (int w = 0; w < WZ; w++) lo.c[w] = F::add(lo.c[w], hi.c[w]);
-            sh[t] = lo;
-        }
-        __syncthreads();
+        for (int w = 0; w < WZ; w++) a.out[(uint64_t)col * WZ + w] = r.c[w];
     }
-    if (t == 0)
-#pragma unroll
-        for (int w = 0; w < WZ; w++) a.out[(uint64_t)col * WZ + w] = sh[0].c[w];
 }
 
 }  // namespace wf

@@ -2049,51 +2049,74 @@ int wf_fri_apply_drp(wf_ctx *ctx, uint32_t field, uint32_t ext, const void *tran
 // out-of-domain evaluation -------------------------------------------------------------------------
 }  // extern "C"
 
+template <class F, int WZ>
+static void eval_fill_powers(EvalAtArgs<F> &a, uint32_t q, const typename F::T *z) {
+    Ext<F, WZ> y;
+    for (int w = 0; w < WZ; w++) y.c[w] = z[w];
+    for (int s = 0; s < EVAL_POWERS; s++) {  // y = z^(2^s)
+        for (int w = 0; w < WZ; w++) a.pw[q][s][w] = y.c[w];
+        y = ext_mul<F, WZ>(y, y);
+    }
+}
+
 template <class F>
 static int eval_columns_at_dev(wf_ctx *ctx, hipStream_t st, const void *d_polys, size_t n_cols, size_t n, uint32_t ext_c,
                                const void *z_host, uint32_t ext_z, void *d_out, uint32_t n_points = 1) {
     typedef typename F::T T;
-    EvalAtArgs<F> a;
-    memset(&a, 0, sizeof(a));
-    a.polys = (const T *)d_polys;
-    a.out = (T *)d_out;
-    a.n = n;
-    a.n_cols = (uint32_t)n_cols;
-    for (uint32_t q = 0; q < n_points; q++) {
-        memcpy(a.z[q], (const T *)z_host + (size_t)q * ext_z, ext_z * sizeof(T));
-        for (uint32_t w = 0; w < ext_z; w++)
-            if (!F::is_valid(a.z[q][w])) return fail(WF_ERR_ARG, "z is not a valid field element");
-    }
-    a.n_blocks = (uint32_t)((n + EVAL_BLOCK - 1) / EVAL_BLOCK);
-    int rcp = ensure(ctx, ctx->hash_tmp, (size_t)n_points * n_cols * a.n_blocks * ext_z * sizeof(T));  // (block values; no hashing runs alongside)
-    if (rcp) return rcp;
-    a.partial = (T *)ctx->hash_tmp.p;
-    const dim3 grid(a.n_blocks, (uint32_t)n_cols, n_points), grid2((uint32_t)n_cols, n_points), block(256);
-    prof_mark(ctx, st, "ood.evaluate_columns_at");
     const uint32_t key = ext_c * 10 + ext_z;
-    switch (key) {
-        case 11: hipLaunchKernelGGL((k_eval_columns_at<F, 1, 1>), grid, block, 0, st, a); break;
-        case 12: hipLaunchKernelGGL((k_eval_columns_at<F, 1, 2>), grid, block, 0, st, a); break;
-        case 22: hipLaunchKernelGGL((k_eval_columns_at<F, 2, 2>), grid, block, 0, st, a); break;
-        case 13:
-            if constexpr (F::FIELD_ID == 1) { hipLaunchKernelGGL((k_eval_columns_at<F, 1, 3>), grid, block, 0, st, a); break; }
-            return fail(WF_ERR_EXTENSION, "f128 has no cubic extension");
-        case 33:
-            if constexpr (F::FIELD_ID == 1) { hipLaunchKernelGGL((k_eval_columns_at<F, 3, 3>), grid, block, 0, st, a); break; }
-            return fail(WF_ERR_EXTENSION, "f128 has no cubic extension");
-        default:
-            return fail(WF_ERR_EXTENSION, "cannot evaluate degree-%u extension coefficients at a degree-%u extension point", ext_c, ext_z);
+    if (key != 11 && key != 12 && key != 22 && !(F::FIELD_ID == 1 && (key == 13 || key == 33))) {
+        if (F::FIELD_ID != 1 && (key == 13 || key == 33)) return fail(WF_ERR_EXTENSION, "f128 has no cubic extension");
+        return fail(WF_ERR_EXTENSION, "cannot evaluate degree-%u extension coefficients at a degree-%u extension point", ext_c, ext_z);
     }
-    HIP_TRY(hipGetLastError());
-    switch (ext_z) {
-        case 1: hipLaunchKernelGGL((k_eval_columns_sum<F, 1>), grid2, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((k_eval_columns_sum<F, 2>), grid2, block, 0, st, a); break;
-        default:
-            if constexpr (F::FIELD_ID == 1) hipLaunchKernelGGL((k_eval_columns_sum<F, 3>), grid2, block, 0, st, a);
-            break;
+    const uint32_t n_blocks = (uint32_t)((n + EVAL_BLOCK - 1) / EVAL_BLOCK);
+    int rcp = ensure(ctx, ctx->hash_tmp, (size_t)n_points * n_cols * n_blocks * ext_z * sizeof(T));  // (block values; no hashing runs alongside)
+    if (rcp) return rcp;
+    for (uint32_t q0 = 0; q0 < n_points; q0 += EVAL_POINTS) {  // two points per launch
+        const uint32_t np = std::min<uint32_t>(EVAL_POINTS, n_points - q0);
+        EvalAtArgs<F> a;
+        memset(&a, 0, sizeof(a));
+        a.polys = (const T *)d_polys;
+        a.n = n;
+        a.n_cols = (uint32_t)n_cols;
+        a.n_blocks = n_blocks;
+        a.partial = (T *)ctx->hash_tmp.p + (size_t)q0 * n_cols * n_blocks * ext_z;
+        a.out = (T *)d_out + (size_t)q0 * n_cols * ext_z;
+        for (uint32_t q = 0; q < np; q++) {
+            const T *z = (const T *)z_host + (size_t)(q0 + q) * ext_z;
+            for (uint32_t w = 0; w < ext_z; w++)
+                if (!F::is_valid(z[w])) return fail(WF_ERR_ARG, "z is not a valid field element");
+            switch (ext_z) {
+                case 1: eval_fill_powers<F, 1>(a, q, z); break;
+                case 2: eval_fill_powers<F, 2>(a, q, z); break;
+                default:
+                    if constexpr (F::FIELD_ID == 1) eval_fill_powers<F, 3>(a, q, z);
+                    break;
+            }
+        }
+        const dim3 grid(a.n_blocks, (uint32_t)n_cols, np), grid2((uint32_t)n_cols, np), block(256);
+        prof_mark(ctx, st, "ood.evaluate_columns_at");
+        switch (key) {
+            case 11: hipLaunchKernelGGL((k_eval_columns_at<F, 1, 1>), grid, block, 0, st, a); break;
+            case 12: hipLaunchKernelGGL((k_eval_columns_at<F, 1, 2>), grid, block, 0, st, a); break;
+            case 22: hipLaunchKernelGGL((k_eval_columns_at<F, 2, 2>), grid, block, 0, st, a); break;
+            case 13:
+                if constexpr (F::FIELD_ID == 1) hipLaunchKernelGGL((k_eval_columns_at<F, 1, 3>), grid, block, 0, st, a);
+                break;
+            default:
+                if constexpr (F::FIELD_ID == 1) hipLaunchKernelGGL((k_eval_columns_at<F, 3, 3>), grid, block, 0, st, a);
+                break;
+        }
+        HIP_TRY(hipGetLastError());
+        switch (ext_z) {
+            case 1: hipLaunchKernelGGL((k_eval_columns_sum<F, 1>), grid2, block, 0, st, a); break;
+            case 2: hipLaunchKernelGGL((k_eval_columns_sum<F, 2>), grid2, block, 0, st, a); break;
+            default:
+                if constexpr (F::FIELD_ID == 1) hipLaunchKernelGGL((k_eval_columns_sum<F, 3>), grid2, block, 0, st, a);
+                break;
+        }
+        HIP_TRY(hipGetLastError());
+        prof_mark(ctx, st, "between_calls");
     }
-    HIP_TRY(hipGetLastError());
-    prof_mark(ctx, st, "between_calls");
     return 0;
 }
 
