@@ -86,6 +86,58 @@ __device__ __forceinline__ void merge(const uint32_t (&m)[16], uint32_t (&out)[8
     compress(out, m, 0, 0, 64, CHUNK_START | CHUNK_END | ROOT);
 }
 
+// ---- the same merge by FOUR lanes (a quad): lane q holds column q of the 4 x 4 state (a = v[q], b = v[4+q], c = v[8+q],
+// d = v[12+q]); the column step is lane-local, the diagonal step reaches the neighbours' b, c, d through DPP quad permutes.
+// A third of the instructions per lane (about 230 against 678): for the narrow top levels of a Merkle tree, where one
+// compression per level is pure latency.  msg: the 16 message words (two child digests) in LDS; lane q returns the two
+// words cv[q] and cv[4 + q] of the parent.
+__host__ __device__ constexpr uint32_t quad_index_word(int q, int word) {  // 4-bit message indices, eight per word
+    uint32_t w = 0;
+    for (int n = 0; n < 8; n++) {
+        const int j = word * 8 + n;  // j = 4 r + t: t = 0, 1 column step (mx, my); t = 2, 3 diagonal step
+        if (j >= 28) break;
+        const int r = j / 4, t = j % 4;
+        const int pos = (t < 2 ? 0 : 8) + 2 * q + (t & 1);
+        w |= (uint32_t)sched(r, pos) << (4 * n);
+    }
+    return w;
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_perm(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, false);
+}
+
+__device__ __forceinline__ void merge_quad(const uint32_t *msg, uint32_t q, uint32_t &out_lo, uint32_t &out_hi) {
+    // this lane's 28 message indices: one of four compile-time tables, selected by q
+    uint32_t iw[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint32_t w0 = quad_index_word(0, w), w1 = quad_index_word(1, w), w2 = quad_index_word(2, w), w3 = quad_index_word(3, w);
+        iw[w] = q == 0 ? w0 : q == 1 ? w1 : q == 2 ? w2 : w3;
+    }
+    uint32_t mw[28];
+#pragma unroll
+    for (int j = 0; j < 28; j++) mw[j] = msg[(iw[j / 8] >> (4 * (j % 8))) & 15u];
+    const uint32_t iv_lo = q == 0 ? 0x6A09E667u : q == 1 ? 0xBB67AE85u : q == 2 ? 0x3C6EF372u : 0xA54FF53Au;
+    const uint32_t iv_hi = q == 0 ? 0x510E527Fu : q == 1 ? 0x9B05688Cu : q == 2 ? 0x1F83D9ABu : 0x5BE0CD19u;
+    uint32_t a = iv_lo, b = iv_hi, c = iv_lo;
+    uint32_t d = q == 2 ? 64u : q == 3 ? (uint32_t)(CHUNK_START | CHUNK_END | ROOT) : 0u;  // counter = 0, block_len = 64, flags
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+        WF_B3_G(a, b, c, d, mw[4 * r], mw[4 * r + 1])
+        b = quad_perm<0x39>(b);  // lane q takes lane q + 1
+        c = quad_perm<0x4E>(c);  //              q + 2
+        d = quad_perm<0x93>(d);  //              q + 3
+        WF_B3_G(a, b, c, d, mw[4 * r + 2], mw[4 * r + 3])
+        b = quad_perm<0x93>(b);
+        c = quad_perm<0x4E>(c);
+        d = quad_perm<0x39>(d);
+    }
+    out_lo = a ^ c;
+    out_hi = b ^ d;
+}
+
 // Hash of a message of `len` <= 1024 bytes (one chunk; len a multiple of 4) delivered block by block:
 // load(block_index, m) must fill the 16 words of 64-byte block `block_index`, zero-padded past `len`.
 // Longer messages go through chunk_cv + merge_chunk_cvs below (one lane per chunk).
