@@ -147,6 +147,7 @@ struct SegArgs {
     uint32_t store_cols, total_store_cols;
     uint32_t pad_traces;  // the lane that stores a trace's last column also zeroes the rest of that (padded) row
     uint32_t tail_pad;  // zero elements the last segment writes after its own S lanes (0 or S: f128 rows of 8 elements)
+    uint32_t seg_stride;       // strided pass: segments between consecutive cosets of src / dst (= n_seg unless a segment range runs)
     uint32_t coset0;           // first coset computed by this call (coset sharding across GPUs); 0 otherwise
     uint32_t rows_per_k;       // cosets held by the output matrix: row = k * rows_per_k + local coset (= blowup unless sharded)
     // coset-packed lanes (narrow matrices: total_base_cols <= S/2): a row holds 2^cpr_log cosets x 2^lg_log lanes;
@@ -462,8 +463,9 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_strided(SegArgs<F> a) {
     const uint32_t rest = (uint32_t)(bid >> (logI + logO));
     const uint32_t c = rest / a.n_seg, g = rest - c * a.n_seg;
     const uint64_t seg_elems = ((uint64_t)1 << a.logN) * S;
-    const T *src = a.src + (a.src_shared ? (uint64_t)g : (uint64_t)c * a.n_seg + g) * seg_elems;
-    T *dst = a.dst + ((uint64_t)c * a.n_seg + g) * seg_elems;
+    // (seg_stride = segments of the whole matrix; n_seg < seg_stride when the launch covers a range of them)
+    const T *src = a.src + (a.src_shared ? (uint64_t)g : (uint64_t)c * a.seg_stride + g) * seg_elems;
+    T *dst = a.dst + ((uint64_t)c * a.seg_stride + g) * seg_elems;
 
     Pow2L<F> pre = a.pre;
     // PACKED: the two lanes of this thread may belong to different cosets; their tables and h_c^i factors

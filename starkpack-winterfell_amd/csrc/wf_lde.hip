@@ -76,6 +76,8 @@ struct wf_ctx {
     // hipMalloc of 64..512 MiB cost about as much as the commitment itself); released by wf_ctx_release_cached / destroy.
     std::vector<std::pair<void *, size_t>> pool;
     size_t pool_bytes = 0, pool_cap = (size_t)64 << 30;
+    hipStream_t copy_stream = nullptr;  // uploads that run under kernels (trace_commit_pipelined)
+    std::vector<hipEvent_t> seg_events;
     void *pin = nullptr;  // pinned host staging for uploads of many small columns (upload_columns)
     size_t pin_cap = 0;
     void *qpin = nullptr;  // pinned staging of the query service (ids up, rows and digests back)
@@ -686,6 +688,10 @@ struct SegDesc {
     bool pad_in_kernel = false;  // rows_out: the last pass also writes the zero padding lanes of the rows
     uint32_t base_cols, total_base_cols, coset0;
     uint64_t row_width, trace_lde_elems;
+    // a multi-pass transform in two calls (uploads of later segments run under the strided passes of earlier ones):
+    // phase 1 = the strided passes of segments [seg0, seg0 + seg_cnt) only, phase 2 = the last pass (all segments) only
+    uint32_t seg0 = 0, seg_cnt = 0;
+    int phase = 0;
 };
 
 template <class F>
@@ -732,8 +738,15 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
     const char *tag_s = d.rows_out ? "evaluate.strided_pass" : "interpolate.strided_pass";
     const char *tag_l = d.rows_out ? "evaluate.last_pass" : "interpolate.last_pass";
 
+    const uint32_t run_cnt = d.seg_cnt ? d.seg_cnt : d.n_seg;
+    const size_t run_off = (size_t)d.seg0 * (N * SegCfg<F>::S);  // elements in front of segment seg0 within one coset
+    a.seg_stride = d.n_seg;
     uint32_t done_bits = 0;
     for (int pi = 0; pi + 1 < plan.n_pass; pi++) {
+        if (d.phase == 2) {  // strided passes already run
+            done_bits += plan.dig[pi];
+            continue;
+        }
         const bool first = pi == 0;
         a.logD = plan.dig[pi];
         a.O = (uint64_t)1 << done_bits;
@@ -754,11 +767,14 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             a.scale_on = first ? 1 : 0;     // 1/n rides on the first inter-pass twiddle table
             a.scale = inv_n;
         }
+        a.src += run_off;
+        a.dst += run_off;
+        a.n_seg = run_cnt;
         uint32_t threads;
         size_t lds;
         rc = seg_launch_dims<F>(a.logD, threads, lds, false);
         if (rc) return rc;
-        const uint64_t grid = (uint64_t)n_groups * d.n_seg * a.O * a.I;
+        const uint64_t grid = (uint64_t)n_groups * run_cnt * a.O * a.I;
         if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
         prof_mark(ctx, st, tag_s);
         // f64 tiles of 2^10 rows (the digits of the 2^19 .. 2^21 plans) run the tile-size-specialised instantiation
@@ -786,6 +802,8 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         HIP_TRY(hipGetLastError());
         done_bits += a.logD;
     }
+    a.n_seg = d.n_seg;
+    if (d.phase == 1) return 0;
     {
         const int pi = plan.n_pass - 1;
         const bool single = plan.n_pass == 1;
@@ -1056,7 +1074,8 @@ static int path_buffers(wf_ctx *ctx, const wf_params *p, PathBufs<F> &b, uint32_
 template <class F>
 static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, const PathBufs<F> &b, void *d_lde,
                                void *d_leaves, void *d_nodes, uint32_t coset0 = 0, uint32_t n_cosets = 0,
-                               bool dense_rows = false) {
+                               bool dense_rows = false, int phase = 0, uint32_t seg0 = 0, uint32_t seg_cnt = 0) {
+    // phase 1: the strided evaluation passes of segments [seg0, seg0 + seg_cnt) only; phase 2: everything after them
     typedef typename F::T T;
     const uint32_t W = p->ext_degree, logR = p->log2_trace_len, logB = p->log2_blowup;
     if (n_cosets == 0) n_cosets = 1u << logB;  // all of them; otherwise a shard [coset0, coset0 + n_cosets)
@@ -1083,7 +1102,7 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
     // trace's last column writes that row's zeros.  Only coset-packed multi-trace / f128 matrices are cleared up front.
     const bool pad_traces = row_width != base_cols && !pad_in_kernel &&
                             !packed_shape<F>(b.n_seg, b.total_base_cols, base_cols, n_cosets, &cpr_unused, &lg_unused);
-    if (row_width != base_cols && !pad_in_kernel && !pad_traces) {
+    if (phase != 1 && row_width != base_cols && !pad_in_kernel && !pad_traces) {
         const uint64_t n16 = (uint64_t)p->n_traces * Nrows * row_width * sizeof(T) / 16;  // rows are multiples of 64 bytes
         hipLaunchKernelGGL(k_zero16, dim3((uint32_t)std::min<uint64_t>((n16 + 255) / 256, 256 * 32)), dim3(256), 0, st, (uint4 *)d_lde, n16);
         HIP_TRY(hipGetLastError());
@@ -1110,8 +1129,12 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
     d.leaves = d_leaves;
     d.hash_epr = b.total_base_cols;  // the combined row of all traces (= base_cols for one trace)
     d.fused = &hashed;
+    d.phase = phase;
+    d.seg0 = seg0;
+    d.seg_cnt = seg_cnt;
     rc = run_seg_transform<F>(ctx, st, d);
     if (rc) return rc;
+    if (phase == 1) return 0;
 
     if (d_leaves) {
         if (!hashed) {
@@ -1156,6 +1179,68 @@ static int trace_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_trace
     rc = run_xpose<F>(ctx, st, false, b.segB, d_polys, R, p->ext_degree, b.total_base_cols, b.n_seg);
     if (rc) return rc;
     return evaluate_and_commit<F>(ctx, st, p, b, d_lde, d_leaves, d_nodes);
+}
+
+// build_trace_commitment from HOST columns of a matrix of several segments, the upload running under the kernels: segment g's
+// eight columns go up on a copy stream while segment g - 1 is laid out, interpolated and taken through the strided
+// evaluation passes of all cosets on the compute stream (those passes work on one segment at a time); only the last
+// evaluation pass, which hashes whole rows, and the tree wait for the last segment.  Base-field matrices (a column is a
+// base column); the results are the same launches' results in another order.
+template <class F>
+static int trace_commit_pipelined(wf_ctx *ctx, const wf_params *p, const void *const *cols_in, void *d_stage, void *d_polys,
+                                  void *d_lde, void *d_leaves, void *d_nodes, hipStream_t st) {
+    typedef typename F::T T;
+    constexpr uint32_t S = SegCfg<F>::S;
+    PathBufs<F> b;
+    int rc = path_buffers<F>(ctx, p, b);
+    if (rc) return rc;
+    const uint64_t R = (uint64_t)1 << p->log2_trace_len;
+    const size_t colb = R * sizeof(T), TC = b.total_base_cols;
+    if (!ctx->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    while (ctx->seg_events.size() < (size_t)b.n_seg + 1) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->seg_events.push_back(e);
+    }
+    // the staging buffer may still be read by what this context queued before
+    HIP_TRY(hipEventRecord(ctx->seg_events[b.n_seg], st));
+    HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->seg_events[b.n_seg], 0));
+    for (uint32_t g = 0; g < b.n_seg; g++) {
+        for (size_t i = (size_t)g * S; i < std::min<size_t>(TC, (size_t)(g + 1) * S); i++)
+            HIP_TRY(hipMemcpyAsync((char *)d_stage + i * colb, cols_in[i], colb, hipMemcpyHostToDevice, ctx->copy_stream));
+        HIP_TRY(hipEventRecord(ctx->seg_events[g], ctx->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(st, ctx->seg_events[g], 0));
+        rc = run_xpose<F>(ctx, st, true, d_stage, b.segA, R, 1, b.total_base_cols, b.n_seg, g, 1);
+        if (rc) return rc;
+        SegDesc<F> d;
+        memset(&d, 0, sizeof(d));
+        d.in = b.segA + (size_t)g * R * S;
+        d.work = (T *)d.in;
+        d.out = b.segB + (size_t)g * R * S;
+        d.logN = p->log2_trace_len;
+        d.n_seg = 1;
+        d.n_cosets = 1;
+        d.rows_out = false;
+        if ((rc = run_seg_transform<F>(ctx, st, d))) return rc;
+        if ((rc = evaluate_and_commit<F>(ctx, st, p, b, d_lde, d_leaves, d_nodes, 0, 0, false, 1, g, 1))) return rc;
+    }
+    if ((rc = run_xpose<F>(ctx, st, false, b.segB, d_polys, R, 1, b.total_base_cols, b.n_seg))) return rc;
+    return evaluate_and_commit<F>(ctx, st, p, b, d_lde, d_leaves, d_nodes, 0, 0, false, 2);
+}
+
+static bool pipelined_upload_ok(const wf_params *p, size_t colb) {
+    if (getenv("WF_EXP_NO_PIPELINE")) return false;
+    if (p->ext_degree != 1) return false;
+    const uint32_t S = p->field == WF_FIELD_F64 ? SegCfg<F64>::S : SegCfg<F128>::S;
+    const uint32_t n_seg = (p->n_cols * p->n_traces + S - 1) / S;
+    if (n_seg < 2) return false;
+    const int n_pass = p->field == WF_FIELD_F64 ? seg_plan<F64>(p->log2_trace_len, n_seg).n_pass : seg_plan<F128>(p->log2_trace_len, n_seg).n_pass;
+    if (n_pass < 2) return false;
+    static const size_t min_bytes = [] {
+        const char *e = getenv("WF_EXP_PIPELINE_MIN_BYTES");  // tests lower it; below ~1 MiB per column the events cost more than they hide
+        return e ? (size_t)atoll(e) : (size_t)1 << 20;
+    }();
+    return colb >= min_bytes;
 }
 
 // Prover::build_constraint_commitment on device buffers
@@ -1241,6 +1326,8 @@ void wf_ctx_destroy(wf_ctx *ctx) {
     if (ctx->hash_tmp.p) (void)hipFree(ctx->hash_tmp.p);
     if (ctx->tickets.p) (void)hipFree(ctx->tickets.p);
     for (auto &b : ctx->pool) (void)hipFree(b.first);
+    for (hipEvent_t e : ctx->seg_events) (void)hipEventDestroy(e);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->qpin) (void)hipHostFree(ctx->qpin);
     for (auto e : ctx->prof_ev) (void)hipEventDestroy(e);
@@ -1526,11 +1613,22 @@ static int commit_resident(wf_ctx *ctx, const wf_params *p, bool constraint, con
     }
     hipStream_t st = ctx->stream;
     void *stage = constraint ? c->polys : ctx->io[0].p;  // composition polys are the input themselves
-    if ((rc = upload_columns(ctx, stage, cols_in, TC, colb, st))) {
+    const bool pipelined = !constraint && pipelined_upload_ok(p, colb);
+    if (pipelined) {
+        rc = p->field == WF_FIELD_F64 ? trace_commit_pipelined<F64>(ctx, p, cols_in, stage, c->polys, c->lde, c->leaves, c->nodes, st)
+                                      : trace_commit_pipelined<F128>(ctx, p, cols_in, stage, c->polys, c->lde, c->leaves, c->nodes, st);
+        if (rc) (void)hipStreamSynchronize(ctx->copy_stream ? ctx->copy_stream : st);
+    } else if ((rc = upload_columns(ctx, stage, cols_in, TC, colb, st))) {
         free_commitment(c);
         return rc;
     }
-    if (constraint)
+    if (rc) {
+        free_commitment(c);
+        return rc;
+    }
+    if (pipelined)
+        ;
+    else if (constraint)
         rc = p->field == WF_FIELD_F64 ? constraint_commit_dev<F64>(ctx, p, c->polys, c->lde, c->leaves, c->nodes, st, dense)
                                       : constraint_commit_dev<F128>(ctx, p, c->polys, c->lde, c->leaves, c->nodes, st, dense);
     else

@@ -31,3 +31,24 @@ def test_parity_under_forced_plans(capi, switch):
                           os.path.join(ROOT, "tests", "test_gpu_golden.py")],
                          env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("switches", ["WF_EXP_PIPELINE_MIN_BYTES=0", "WF_EXP_PIPELINE_MIN_BYTES=0 WF_EXP_MAX_DIGIT=5",
+                                      "WF_EXP_NO_PIPELINE=1"])
+def test_resident_suites_with_pipelined_upload(capi, switches):
+    """Resident trace commitments of several segments upload segment by segment under the kernels of the previous segments
+    (trace_commit_pipelined) once a column is a MiB or more; WF_EXP_PIPELINE_MIN_BYTES=0 sends the small multi-segment
+    shapes of the resident test suites down that route (with WF_EXP_MAX_DIGIT=5: also those below 2^11 rows, which are
+    single-pass otherwise), WF_EXP_NO_PIPELINE switches it off: same roots, rows, proofs and polynomials every way."""
+    capi.load()
+    env = dict(os.environ)
+    for sw in switches.split():
+        name, value = sw.split("=")
+        env[name] = value
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                          os.path.join(ROOT, "tests", "test_gpu_queries.py"),
+                          os.path.join(ROOT, "tests", "test_gpu_deep.py"),
+                          os.path.join(ROOT, "tests", "test_gpu_pipeline.py"),
+                          os.path.join(ROOT, "tests", "test_gpu_wide_resident.py")],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
