@@ -40,3 +40,23 @@ def test_wide_resident_commitment(ctx, orc, capi, field, logR, logB, n_cols, n_t
     assert com2.root() == want["root"]
     com.close()
     com2.close()
+
+
+@pytest.mark.parametrize("field,logR,n_cols", [(F64, 17, 24), (F64, 18, 20), (F128, 16, 10)])
+def test_wide_resident_commitment_at_the_default_threshold(ctx, orc, capi, field, logR, n_cols):
+    """Columns of 1 MiB and more take the pipelined route without any switch: root, polynomials and sampled rows against the
+    threaded oracle."""
+    rng = np.random.default_rng(logR + n_cols)
+    off = 7 if field == F64 else 3
+    trace = rand_cols(rng, field, n_cols, 1 << logR)
+    want = orc.build_trace_commitment(field, [trace], 1, logR, 3, off, threads=16)
+    com, polys = ctx.trace_commit_resident(capi.make_params(field, 1, logR, 3, n_cols, 1), trace, want_polys=True)
+    assert com.root() == want["root"]
+    for c in range(n_cols):
+        assert np.array_equal(polys[c], want["polys"][0][c])
+    N = 1 << (logR + 3)
+    pos = np.unique(rng.integers(0, N, size=32))
+    rows, proof = com.query(pos)
+    assert np.array_equal(rows.reshape(len(pos), -1), want["lde"][0].reshape(N, -1)[pos][:, :rows.reshape(len(pos), -1).shape[1]])
+    assert proof == orc.merkle_prove_batch(want["nodes"], want["leaves"], [int(p) for p in pos])
+    com.close()
