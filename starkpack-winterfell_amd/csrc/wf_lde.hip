@@ -1188,7 +1188,7 @@ static int trace_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_trace
 // base column); the results are the same launches' results in another order.
 template <class F>
 static int trace_commit_pipelined(wf_ctx *ctx, const wf_params *p, const void *const *cols_in, void *d_stage, void *d_polys,
-                                  void *d_lde, void *d_leaves, void *d_nodes, hipStream_t st) {
+                                  void *d_lde, void *d_leaves, void *d_nodes, hipStream_t st, void *const *polys_out) {
     typedef typename F::T T;
     constexpr uint32_t S = SegCfg<F>::S;
     PathBufs<F> b;
@@ -1225,7 +1225,14 @@ static int trace_commit_pipelined(wf_ctx *ctx, const wf_params *p, const void *c
         if ((rc = evaluate_and_commit<F>(ctx, st, p, b, d_lde, d_leaves, d_nodes, 0, 0, false, 1, g, 1))) return rc;
     }
     if ((rc = run_xpose<F>(ctx, st, false, b.segB, d_polys, R, 1, b.total_base_cols, b.n_seg))) return rc;
-    return evaluate_and_commit<F>(ctx, st, p, b, d_lde, d_leaves, d_nodes, 0, 0, false, 2);
+    if (polys_out) HIP_TRY(hipEventRecord(ctx->seg_events[b.n_seg], st));  // the polynomials are complete here
+    if ((rc = evaluate_and_commit<F>(ctx, st, p, b, d_lde, d_leaves, d_nodes, 0, 0, false, 2))) return rc;
+    if (polys_out) {  // their way back to the host runs under the last evaluation pass and the tree
+        HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->seg_events[b.n_seg], 0));
+        if ((rc = download_columns(ctx, polys_out, d_polys, TC, colb, ctx->copy_stream))) return rc;
+        HIP_TRY(hipStreamSynchronize(ctx->copy_stream));
+    }
+    return 0;
 }
 
 static bool pipelined_upload_ok(const wf_params *p, size_t colb) {
@@ -1615,8 +1622,9 @@ static int commit_resident(wf_ctx *ctx, const wf_params *p, bool constraint, con
     void *stage = constraint ? c->polys : ctx->io[0].p;  // composition polys are the input themselves
     const bool pipelined = !constraint && pipelined_upload_ok(p, colb);
     if (pipelined) {
-        rc = p->field == WF_FIELD_F64 ? trace_commit_pipelined<F64>(ctx, p, cols_in, stage, c->polys, c->lde, c->leaves, c->nodes, st)
-                                      : trace_commit_pipelined<F128>(ctx, p, cols_in, stage, c->polys, c->lde, c->leaves, c->nodes, st);
+        rc = p->field == WF_FIELD_F64
+                 ? trace_commit_pipelined<F64>(ctx, p, cols_in, stage, c->polys, c->lde, c->leaves, c->nodes, st, polys_out)
+                 : trace_commit_pipelined<F128>(ctx, p, cols_in, stage, c->polys, c->lde, c->leaves, c->nodes, st, polys_out);
         if (rc) (void)hipStreamSynchronize(ctx->copy_stream ? ctx->copy_stream : st);
     } else if ((rc = upload_columns(ctx, stage, cols_in, TC, colb, st))) {
         free_commitment(c);
@@ -1637,7 +1645,7 @@ static int commit_resident(wf_ctx *ctx, const wf_params *p, bool constraint, con
         free_commitment(c);
         return rc;
     }
-    if (polys_out && !constraint && (rc = download_columns(ctx, polys_out, c->polys, TC, colb, st))) {
+    if (polys_out && !constraint && !pipelined && (rc = download_columns(ctx, polys_out, c->polys, TC, colb, st))) {
         free_commitment(c);
         return rc;
     }
