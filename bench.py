@@ -232,8 +232,40 @@ def with_transfers(ctx, capi, params, trace_host, gpu_root):
         out["resident_pipelined_pinned_ms_per_commit"], _ = pipelined(pinned)
     except Exception as e:  # noqa: BLE001 -- an optional figure
         out["resident_from_pinned_host_ms"] = f"not measured: {e}"
+    # a WIDE trace (2^20 x 64: eight segments) from host columns: the upload runs segment by segment under the kernels of the
+    # previous segments (the single-segment metric workload above has nothing to run it under); same call with the overlap
+    # switched off for comparison
+    try:
+        import numpy as np
+        rng = np.random.default_rng(7)
+        wide = [rng.integers(0, 2**62, size=1 << LOG_R, dtype=np.uint64) for _ in range(64)]
+        wp = capi.make_params(capi.F64, 1, LOG_R, LOG_B, 64, 1)
+
+        def wide_commit():
+            t0 = time.perf_counter()
+            com, _ = ctx.trace_commit_resident(wp, wide)
+            ms = (time.perf_counter() - t0) * 1e3
+            root = com.root()
+            com.close()
+            return ms, root
+
+        wide_commit()
+        a = sorted(wide_commit() for _ in range(3))[1]
+        os.environ["WF_EXP_NO_PIPELINE"] = "1"
+        try:
+            wide_commit()
+            b = sorted(wide_commit() for _ in range(3))[1]
+        finally:
+            del os.environ["WF_EXP_NO_PIPELINE"]
+        out["wide_2p20x64_from_host_ms"] = a[0]
+        out["wide_2p20x64_from_host_serial_upload_ms"] = b[0]
+        out["wide_roots_match"] = a[1] == b[1]
+        ctx.release_cached()
+    except Exception as e:  # noqa: BLE001 -- a side measurement must not take the benchmark line down
+        out["wide_error"] = f"{type(e).__name__}: {e}"
     out["note"] = ("wall clock around the C call, PCIe included; median of 3; host columns pageable numpy arrays unless 'pinned'; "
-                   "pipelined = two host threads with a context each committing back to back, wall / commitments")
+                   "pipelined = two host threads with a context each committing back to back, wall / commitments; wide = 2^20 x 64 "
+                   "f64 (512 MiB of columns) with the upload under the kernels vs in front of them")
     return out
 
 
