@@ -303,13 +303,96 @@ def free_port():
 
 def launch_ranks(n):
     """`python bench.py --gpus N` as a plain command: start one rank per GPU and get out of the way.  This process has
-    not imported torch or touched the GPU; the ranks are children, not an exec of this process."""
+    not imported torch or touched the GPU; the ranks are children, not an exec of this process.  The children run in
+    their own process group under a wall-clock limit (WF_BENCH_LAUNCH_TIMEOUT_S, default 900 s): on expiry exactly that
+    group is ended and this process exits non-zero -- a rank stuck in a collective cannot hang the caller."""
+    import signal
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this host driver
     env.setdefault("OMP_NUM_THREADS", "8")
-    return subprocess.run(cmd, env=env).returncode
+    limit = float(os.environ.get("WF_BENCH_LAUNCH_TIMEOUT_S", "900"))
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return child.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the {n} ranks did not finish within {limit:.0f} s; ending their process group", file=sys.stderr, flush=True)
+        for sig, grace in ((signal.SIGTERM, 10), (signal.SIGKILL, 10)):
+            try:
+                os.killpg(child.pid, sig)  # the group this call created (start_new_session): the launcher and its ranks
+            except ProcessLookupError:
+                break
+            try:
+                child.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return 124
+
+
+def verify_multi_rank(torch, capi, shard, ctx, comm, args, packed, params, rank, world, device, stream, trace, roots, all_roots, top,
+                      bufs):
+    """Parity gates of a multi-rank run, outside the timed region.  Collective: every rank calls it.
+      proofs : the gathered roots must be, for every rank r and timed step k, the root of rank r's proof -- rank 0 commits
+               each rank's trace (same seed) once more on its own GPU through the single-GPU entry point (itself checked
+               against the CPU oracle by the N = 1 run and the parity tests) and compares; every rank also checks that
+               its own slice of the gathered array is what it sent.
+      packed : rank 0 commits the same packed traces unsharded (wf_trace_commit_dev) and compares the root with the
+               sharded one; the roots of all ranks are gathered and must be identical.
+    Returns (ok, details); the verdict is agreed over all ranks (max), so that every rank exits with the same code."""
+    n_steps = args.steps
+    bad = []
+    R, N = 1 << LOG_R, 1 << (LOG_R + LOG_B)
+    torch.cuda.synchronize()
+    if not packed:
+        got = all_roots[:world * n_steps].cpu().numpy().reshape(world, n_steps, 32)
+        mine = roots[:n_steps].cpu().numpy()
+        if not (got[rank] == mine).all():
+            bad.append(f"rank {rank}: its slice of the gathered roots differs from the roots it sent")
+        if rank == 0:
+            polys, lde, leaves, nodes = bufs
+            for r in range(world):
+                pid = shard.proofs_of_rank(world, r, world)[0]
+                t = trace if r == 0 else rand_f64_dev(torch, N_COLS * R, shard.seed_of_proof(0x57415446, pid), device)
+                with torch.cuda.stream(stream):
+                    ctx.trace_commit_dev(params, t.data_ptr(), polys.data_ptr(), lde.data_ptr(), leaves.data_ptr(),
+                                         nodes.data_ptr(), stream.cuda_stream)
+                    torch.cuda.synchronize()
+                want = nodes[1].cpu().numpy()
+                wrong = [k for k in range(n_steps) if not (got[r, k] == want).all()]
+                if wrong:
+                    bad.append(f"rank {r}: gathered root of step(s) {wrong[:4]} != root of its proof recomputed on rank 0 "
+                               f"({bytes(got[r, wrong[0]]).hex()[:16]} vs {bytes(want).hex()[:16]})")
+        what = f"{world} x {n_steps} gathered roots == each rank's proof re-committed on rank 0"
+    else:
+        my_root = top[1:2].contiguous()
+        every = torch.zeros((world, 32), dtype=torch.uint8, device=device)
+        with torch.cuda.stream(stream):
+            comm.all_gather_roots(my_root.data_ptr(), 1, every.data_ptr(), stream.cuda_stream)
+            comm.stream_wait(stream.cuda_stream)
+        ev = every.cpu().numpy()
+        if not (ev == ev[rank]).all():
+            bad.append(f"rank {rank}: the ranks hold different roots of the one packed commitment")
+        if rank == 0:
+            n_traces = PACKED_TRACES
+            full_lde = torch.empty(n_traces * N * 8, dtype=torch.int64, device=device)
+            full_leaves = torch.empty((N, 32), dtype=torch.uint8, device=device)
+            full_nodes = torch.empty((N, 32), dtype=torch.uint8, device=device)
+            polys = bufs[0]
+            with torch.cuda.stream(stream):
+                ctx.trace_commit_dev(params, trace.data_ptr(), polys.data_ptr(), full_lde.data_ptr(), full_leaves.data_ptr(),
+                                     full_nodes.data_ptr(), stream.cuda_stream)
+                torch.cuda.synchronize()
+            want = full_nodes[1].cpu().numpy()
+            if not (ev[0] == want).all():
+                bad.append(f"sharded root {bytes(ev[0]).hex()[:16]} != unsharded commitment of the same traces {bytes(want).hex()[:16]}")
+            del full_lde, full_leaves, full_nodes
+        what = f"sharded root on all {world} ranks == unsharded wf_trace_commit_dev of the same traces on rank 0"
+    for line in bad:
+        print("PARITY FAILURE:", line, file=sys.stderr, flush=True)
+    failed = comm.max_f64(1.0 if bad else 0.0) > 0.0
+    return (not failed), {"checked": what, "ok": not failed}
 
 
 def main():
@@ -321,6 +404,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-transfers", action="store_true")
     ap.add_argument("--per-launch", action="store_true", help="also report HIP-event times of every kernel launch")
+    ap.add_argument("--inject-fault", choices=("root", "hang"), default=None,
+                    help="test hook (tests/test_gpu_multi_device.py), applied AFTER the timed region: 'root' flips a byte of a "
+                         "root on rank 1 so that the parity gate must fire; 'hang' makes rank 1 sleep so that the launcher's limit must")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -424,6 +510,8 @@ def main():
         for k in range(args.steps):
             step(k)
         gather(args.steps)
+        if comm is not None and comm.transport != "torch":
+            comm.stream_wait(stream.cuda_stream)  # the same wait under wf_comm's watchdog: an error, not a hang, if a peer died
         torch.cuda.synchronize()
         if comm is not None:
             comm.barrier()
@@ -435,6 +523,24 @@ def main():
 
     if comm is not None:
         elapsed = comm.max_f64(elapsed)  # MAX over ranks
+    verified = None
+    if args.inject_fault == "hang" and rank == world - 1 and world > 1:
+        time.sleep(3600)
+    if args.inject_fault == "root" and world > 1:
+        torch.cuda.synchronize()
+        if packed and rank == world - 1:
+            top[1, 0] ^= 1                                  # the last rank's copy of the packed commitment's root
+        if not packed and rank == 0:
+            all_roots[(world - 1) * args.steps, 0] ^= 1     # what rank 0 received as the last rank's first root
+        torch.cuda.synchronize()
+    if comm is not None:
+        # a multi-rank number is only printed for results that are right: root parity gates, outside the timed region
+        ok, verified = verify_multi_rank(torch, capi, shard, ctx, comm, args, packed, params, rank, world, device, stream, trace,
+                                         roots, all_roots, top, (polys, lde, leaves, nodes))
+        if not ok:
+            comm.close()
+            ctx.close()
+            raise SystemExit("PARITY FAILURE in the multi-rank run (see stderr): no benchmark line is printed")
     root_hex = bytes(roots[args.steps - 1].cpu().numpy()).hex()
     n_roots = world * args.steps if (comm is not None and not packed) else args.steps
 
@@ -508,6 +614,8 @@ def main():
                             else ("FALLBACK: torch.distributed nccl (= RCCL), wf_comm failed: " + comm.reason) if comm.transport == "torch"
                             else "wf_transport over torch.distributed gloo (rehearsal)",
                             "rccl_version": capi.load().wf_comm_rccl_version() if comm.transport == "rccl" else None,
+                            "rccl_path": (capi.load().wf_comm_rccl_path() or b"").decode() if comm.transport == "rccl" else None,
+                            "verified": verified,
                             "calls": "all-to-all of leaf digests + all-gather of sub-roots per step" if packed
                             else "one all-gather of roots per run"}),
             # the path is integer-VALU bound: time of its butterflies and BLAKE3 compressions at the rates the same

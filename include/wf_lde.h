@@ -201,6 +201,9 @@ int wf_comm_rank(const wf_comm *comm);
 int wf_comm_world(const wf_comm *comm);
 /* Version code of the RCCL library that was loaded (ncclGetVersion), 0 if none could be. */
 int wf_comm_rccl_version(void);
+/* The file the RCCL symbols were resolved from (dladdr), "" if none was loaded: inside a process that also holds
+ * PyTorch's bundled copy this says which of the two the collectives really run on. */
+const char *wf_comm_rccl_path(void);
 /* ncclAllGather of raw bytes, asynchronous on `stream` (NULL = the context's stream). */
 int wf_comm_all_gather(wf_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream);
 /* The one collective of sharding (1): every rank's n_roots roots (32 bytes each, device memory) -> d_all, rank-major. */
@@ -209,6 +212,12 @@ int wf_comm_all_gather_roots(wf_comm *comm, const void *d_roots, size_t n_roots,
  * the context's stream has finished when it returns) and the maximum of one double over all ranks (in place). */
 int wf_comm_barrier(wf_comm *comm);
 int wf_comm_max_f64(wf_comm *comm, double *value);
+/* Host-blocking wait for everything queued on `stream` (NULL = the context's stream), collectives included, under the
+ * communicator's watchdog: after WF_COMM_TIMEOUT_S seconds (environment, read at wf_comm_create; default 300) without
+ * completion -- a peer died or never entered the collective -- the communicator is aborted (ncclCommAbort) and
+ * WF_ERR_COMM is returned instead of waiting for ever; every later collective on it fails with WF_ERR_COMM.
+ * wf_comm_barrier, wf_comm_max_f64, wf_trace_commit_sharded_resident and wf_sharded_commitment_query wait the same way. */
+int wf_comm_stream_wait(wf_comm *comm, void *stream);
 
 /* Partition rules (no device needed; what wf_trace_commit_sharded_dev and the tests use):
  *   proofs : contiguous blocks of proof ids, the first ranks take the remainder

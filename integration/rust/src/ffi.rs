@@ -156,6 +156,10 @@ extern "C" {
         comm: *mut WfComm, d_roots: *const c_void, n_roots: usize, d_all: *mut c_void, stream: *mut c_void,
     ) -> c_int;
     pub fn wf_comm_barrier(comm: *mut WfComm) -> c_int;
+    /// Blocking wait on `stream` under the communicator's watchdog (WF_COMM_TIMEOUT_S): WF_ERR_COMM instead of a hang.
+    pub fn wf_comm_stream_wait(comm: *mut WfComm, stream: *mut c_void) -> c_int;
+    /// The file the RCCL symbols were resolved from (NUL-terminated, static storage).
+    pub fn wf_comm_rccl_path() -> *const std::os::raw::c_char;
     pub fn wf_trace_commit_sharded_dev(
         comm: *mut WfComm, p: *const WfParams, d_trace: *const c_void, d_polys: *mut c_void, d_lde_shard: *mut c_void,
         d_leaves: *mut c_void, d_nodes: *mut c_void, d_top: *mut c_void, stream: *mut c_void,

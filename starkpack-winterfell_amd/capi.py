@@ -30,7 +30,7 @@ SYMBOLS = [
     "wf_fft_evaluate_poly", "wf_fft_evaluate_poly_with_offset", "wf_fft_interpolate_poly",
     "wf_fft_interpolate_poly_with_offset", "wf_evaluate_polys_over", "wf_hash_rows", "wf_merkle_build",
     "wf_comm_unique_id", "wf_comm_create", "wf_comm_create_with_transport", "wf_comm_destroy", "wf_comm_rank",
-    "wf_comm_world", "wf_comm_rccl_version", "wf_comm_all_gather", "wf_comm_all_gather_roots", "wf_comm_barrier",
+    "wf_comm_world", "wf_comm_rccl_version", "wf_comm_rccl_path", "wf_comm_stream_wait", "wf_comm_all_gather", "wf_comm_all_gather_roots", "wf_comm_barrier",
     "wf_comm_max_f64", "wf_shard_proofs", "wf_shard_cosets", "wf_shard_route", "wf_comm_all_gather_leaf_shards",
     "wf_trace_commit_sharded_dev", "wf_trace_commit_sharded_resident", "wf_sharded_commitment_destroy",
     "wf_sharded_commitment_root", "wf_sharded_commitment_query", "wf_sharded_commitment_polys",
@@ -207,6 +207,9 @@ def load():
         L.wf_comm_rank.argtypes = [vp]
         L.wf_comm_world.argtypes = [vp]
         L.wf_comm_rccl_version.argtypes = []
+        L.wf_comm_rccl_path.argtypes = []
+        L.wf_comm_rccl_path.restype = C.c_char_p
+        L.wf_comm_stream_wait.argtypes = [vp, vp]
         L.wf_comm_all_gather.argtypes = [vp, vp, vp, sz, vp]
         L.wf_comm_all_gather_roots.argtypes = [vp, vp, sz, vp, vp]
         L.wf_comm_barrier.argtypes = [vp]

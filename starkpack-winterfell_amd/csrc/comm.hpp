@@ -14,6 +14,7 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
 #include <mutex>
 #include <rccl/rccl.h>
 
@@ -28,6 +29,10 @@ struct Rccl {
     decltype(&ncclAllToAll) AllToAll = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;                  // optional: the watchdog of the blocking calls
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;  // optional
+    char path[512] = "";         // the file the symbols came from (dladdr): which copy of RCCL a process really runs
+    char load_error[256] = "";   // dlerror() of the failed load, kept (dlerror() itself reports an error only once)
 };
 
 static bool rccl_load(Rccl &r) {
@@ -37,13 +42,16 @@ static bool rccl_load(Rccl &r) {
         if (!n || !*n) continue;
         h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (h) break;
+        const char *e = dlerror();
+        snprintf(r.load_error, sizeof(r.load_error), "%s", e ? e : "dlopen failed");
     }
     if (!h) return false;
-#define WF_SYM(field, sym)                                   \
-    r.field = (decltype(r.field))dlsym(h, #sym);             \
-    if (!r.field) {                                          \
-        dlclose(h);                                          \
-        return false;                                        \
+#define WF_SYM(field, sym)                                                          \
+    r.field = (decltype(r.field))dlsym(h, #sym);                                    \
+    if (!r.field) {                                                                 \
+        snprintf(r.load_error, sizeof(r.load_error), "symbol %s not found", #sym);  \
+        dlclose(h);                                                                 \
+        return false;                                                               \
     }
     WF_SYM(GetUniqueId, ncclGetUniqueId)
     WF_SYM(CommInitRank, ncclCommInitRank)
@@ -53,16 +61,29 @@ static bool rccl_load(Rccl &r) {
     WF_SYM(GetErrorString, ncclGetErrorString)
     WF_SYM(GetVersion, ncclGetVersion)
 #undef WF_SYM
+    r.CommAbort = (decltype(r.CommAbort))dlsym(h, "ncclCommAbort");
+    r.CommGetAsyncError = (decltype(r.CommGetAsyncError))dlsym(h, "ncclCommGetAsyncError");
+    Dl_info info;
+    if (dladdr((const void *)r.AllGather, &info) && info.dli_fname) snprintf(r.path, sizeof(r.path), "%s", info.dli_fname);
+    r.load_error[0] = 0;
     r.handle = h;
     return true;
 }
 
 // loaded once, by whichever thread needs it first (several host threads may create communicators at the same time)
-static Rccl *rccl() {
+static Rccl &rccl_state() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] { (void)rccl_load(r); });
+    return r;
+}
+static Rccl *rccl() {
+    Rccl &r = rccl_state();
     return r.handle ? &r : nullptr;
+}
+static const char *rccl_load_error() {
+    const Rccl &r = rccl_state();
+    return r.load_error[0] ? r.load_error : "no error recorded";
 }
 
 }  // namespace wfcomm
@@ -75,7 +96,55 @@ struct wf_comm {
     wf_transport tr{};
     DevBuf stage;  // receive staging of the leaf exchanges ([world][...] rank-major, before the interleave)
     DevBuf small;  // barrier / reduction words
+    // Watchdog of the host-blocking calls (barrier, reductions, collective queries, wf_comm_stream_wait): a rank that died
+    // or never arrives must not leave the others waiting for ever.  WF_COMM_TIMEOUT_S, read once at creation.
+    double timeout_s = 300.0;
+    bool dead = false;  // a collective timed out or failed asynchronously: the communicator was aborted
 };
+
+static double comm_timeout_from_env() {
+    const char *e = getenv("WF_COMM_TIMEOUT_S");
+    const double v = e ? atof(e) : 0.0;
+    return v > 0.0 ? v : 300.0;
+}
+
+// Host-blocking wait for everything queued on `st`, with the communicator's watchdog: polls the stream (and RCCL's
+// asynchronous error state); on expiry the communicator is aborted (ncclCommAbort ends the kernels of a collective whose
+// peer never came) and WF_ERR_COMM is returned.  A dead communicator refuses further collectives.
+static int comm_wait(wf_comm *c, hipStream_t st) {
+    using clock = std::chrono::steady_clock;
+    const auto t0 = clock::now();
+    wfcomm::Rccl *R = (c->nccl && !c->custom) ? wfcomm::rccl() : nullptr;
+    unsigned spins = 0;
+    for (;;) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) return fail(WF_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+        if (R && R->CommGetAsyncError && (spins & 1023) == 1023) {
+            ncclResult_t ae = ncclSuccess;
+            if (R->CommGetAsyncError(c->nccl, &ae) == ncclSuccess && ae != ncclSuccess && ae != ncclInProgress) {
+                if (R->CommAbort) (void)R->CommAbort(c->nccl);
+                c->nccl = nullptr;
+                c->dead = true;
+                return fail(WF_ERR_COMM, "RCCL reported an asynchronous error on rank %d: %s", c->rank, R->GetErrorString(ae));
+            }
+        }
+        const double waited = std::chrono::duration<double>(clock::now() - t0).count();
+        if (waited > c->timeout_s) {
+            if (R && R->CommAbort && c->nccl) {
+                (void)R->CommAbort(c->nccl);
+                c->nccl = nullptr;
+            }
+            c->dead = true;
+            return fail(WF_ERR_COMM, "collective timed out after %.0f s on rank %d of %d (a peer died or never arrived); the communicator was aborted",
+                        waited, c->rank, c->world);
+        }
+        if (++spins < 2000)
+            std::this_thread::yield();
+        else
+            std::this_thread::sleep_for(std::chrono::microseconds(spins < 20000 ? 20 : 500));
+    }
+}
 
 #define RCCL_TRY(expr)                                                                                   \
     do {                                                                                                 \
@@ -85,6 +154,7 @@ struct wf_comm {
 
 // every rank contributes `bytes` at d_send; d_recv receives world * bytes, rank-major
 static int comm_all_gather(wf_comm *c, const void *d_send, void *d_recv, size_t bytes, hipStream_t st) {
+    if (c->dead) return fail(WF_ERR_COMM, "the communicator was aborted after a failed or timed-out collective");
     if (c->world == 1) {
         if (d_send != d_recv) HIP_TRY(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, st));
         return 0;
@@ -100,6 +170,7 @@ static int comm_all_gather(wf_comm *c, const void *d_send, void *d_recv, size_t 
 
 // block s (`bytes` bytes at d_send + s * bytes) of rank r lands at d_recv + r * bytes on rank s
 static int comm_all_to_all(wf_comm *c, const void *d_send, void *d_recv, size_t bytes, hipStream_t st) {
+    if (c->dead) return fail(WF_ERR_COMM, "the communicator was aborted after a failed or timed-out collective");
     if (c->world == 1) {
         if (d_send != d_recv) HIP_TRY(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, st));
         return 0;
@@ -228,7 +299,7 @@ extern "C" {
 int wf_comm_unique_id(uint8_t id_out[WF_COMM_ID_BYTES]) {
     if (!id_out) return fail(WF_ERR_ARG, "id_out is null");
     wfcomm::Rccl *R = wfcomm::rccl();
-    if (!R) return fail(WF_ERR_COMM, "RCCL (librccl.so.1) could not be loaded: %s", dlerror());
+    if (!R) return fail(WF_ERR_COMM, "RCCL (librccl.so.1) could not be loaded: %s", wfcomm::rccl_load_error());
     static_assert(sizeof(ncclUniqueId) == WF_COMM_ID_BYTES, "unique id size");
     ncclUniqueId id;
     RCCL_TRY(R->GetUniqueId(&id));
@@ -247,7 +318,7 @@ int wf_comm_create(wf_ctx *ctx, const uint8_t id[WF_COMM_ID_BYTES], int rank, in
     if (rc) return rc;
     if (!id) return fail(WF_ERR_ARG, "id is null");
     wfcomm::Rccl *R = wfcomm::rccl();
-    if (!R) return fail(WF_ERR_COMM, "RCCL (librccl.so.1) could not be loaded: %s", dlerror());
+    if (!R) return fail(WF_ERR_COMM, "RCCL (librccl.so.1) could not be loaded: %s", wfcomm::rccl_load_error());
     HIP_TRY(hipSetDevice(ctx->device));
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof(uid));
@@ -255,6 +326,7 @@ int wf_comm_create(wf_ctx *ctx, const uint8_t id[WF_COMM_ID_BYTES], int rank, in
     c->ctx = ctx;
     c->rank = rank;
     c->world = world;
+    c->timeout_s = comm_timeout_from_env();
     ncclResult_t e = R->CommInitRank(&c->nccl, world, uid, rank);
     if (e != ncclSuccess) {
         delete c;
@@ -272,6 +344,7 @@ int wf_comm_create_with_transport(wf_ctx *ctx, const wf_transport *t, int rank, 
     c->ctx = ctx;
     c->rank = rank;
     c->world = world;
+    c->timeout_s = comm_timeout_from_env();
     c->custom = true;
     c->tr = *t;
     *out = c;
@@ -282,7 +355,7 @@ void wf_comm_destroy(wf_comm *c) {
     if (!c) return;
     if (ctx_alive(c->ctx)) {
         (void)hipSetDevice(c->ctx->device);
-        (void)hipStreamSynchronize(c->ctx->stream);
+        if (!c->dead) (void)hipStreamSynchronize(c->ctx->stream);
     }
     if (c->nccl) {
         wfcomm::Rccl *R = wfcomm::rccl();
@@ -301,6 +374,17 @@ int wf_comm_rccl_version(void) {
     int v = 0;
     if (!R || R->GetVersion(&v) != ncclSuccess) return 0;
     return v;
+}
+
+const char *wf_comm_rccl_path(void) {
+    wfcomm::Rccl *R = wfcomm::rccl();
+    return R ? R->path : "";
+}
+
+int wf_comm_stream_wait(wf_comm *c, void *stream) {
+    if (!c) return fail(WF_ERR_ARG, "comm is null");
+    HIP_TRY(hipSetDevice(c->ctx->device));
+    return comm_wait(c, stream ? (hipStream_t)stream : c->ctx->stream);
 }
 
 int wf_comm_all_gather(wf_comm *c, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream) {
@@ -325,7 +409,21 @@ static int comm_gather_words(wf_comm *c, uint64_t mine, std::vector<uint64_t> &a
     if (rc) return rc;
     all.resize(c->world);
     HIP_TRY(hipMemcpyAsync(all.data(), d + 1, 8 * (size_t)c->world, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    return comm_wait(c, st);
+}
+
+// Collective entry points agree on a status word before their data exchange: a rank that failed locally (allocation, a
+// HIP error in its gathers) reports it here, and EVERY rank returns an error instead of the others waiting inside RCCL
+// for a peer that has already left the call.
+static int comm_agree(wf_comm *c, int local_rc, const char *what) {
+    char local_msg[sizeof(g_err)];
+    snprintf(local_msg, sizeof(local_msg), "%s", g_err);
+    std::vector<uint64_t> all;
+    int rc = comm_gather_words(c, (uint64_t)(uint32_t)local_rc, all);
+    if (rc) return rc;
+    if (local_rc) return fail(local_rc, "%s", local_msg);
+    for (size_t r = 0; r < all.size(); r++)
+        if (all[r]) return fail(WF_ERR_COMM, "%s failed on rank %zu with status %d", what, r, (int)(int32_t)(uint32_t)all[r]);
     return 0;
 }
 
@@ -498,18 +596,19 @@ int wf_trace_commit_sharded_resident(wf_comm *comm, const wf_params *p, const vo
     c->lde_bytes = (size_t)p->n_traces * R * per * c->row_width * wf_elem_bytes(p->field);
     c->dig_bytes = (size_t)(N / W) * 32;
     c->polys_bytes = TC * colb;
-    hipError_t e;
-    if ((e = pool_alloc(ctx, &c->lde_shard, c->lde_bytes)) != hipSuccess || (e = pool_alloc(ctx, &c->leaves, c->dig_bytes)) != hipSuccess ||
-        (e = pool_alloc(ctx, &c->nodes, c->dig_bytes)) != hipSuccess || (e = pool_alloc(ctx, &c->polys, c->polys_bytes)) != hipSuccess) {
-        free_sharded(c);
-        return fail(WF_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
-    }
-    if ((rc = ensure(ctx, ctx->io[0], TC * colb)) || (rc = ensure(ctx, ctx->io[4], (size_t)2 * W * 32))) {
-        free_sharded(c);
-        return rc;
-    }
     hipStream_t st = ctx->stream;
-    if ((rc = upload_columns(ctx, ctx->io[0].p, trace_cols, TC, colb, st))) {
+    // local stage (allocations, upload), then the ranks agree that all of them got this far before the first exchange
+    const int local_rc = [&]() -> int {
+        hipError_t e;
+        if ((e = pool_alloc(ctx, &c->lde_shard, c->lde_bytes)) != hipSuccess || (e = pool_alloc(ctx, &c->leaves, c->dig_bytes)) != hipSuccess ||
+            (e = pool_alloc(ctx, &c->nodes, c->dig_bytes)) != hipSuccess || (e = pool_alloc(ctx, &c->polys, c->polys_bytes)) != hipSuccess)
+            return fail(WF_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+        int rl;
+        if ((rl = ensure(ctx, ctx->io[0], TC * colb)) || (rl = ensure(ctx, ctx->io[4], (size_t)2 * W * 32))) return rl;
+        if ((rl = ensure(ctx, comm->stage, 2 * (size_t)R * per * 32))) return rl;  // (the exchange staging of trace_commit_sharded)
+        return upload_columns(ctx, ctx->io[0].p, trace_cols, TC, colb, st);
+    }();
+    if ((rc = comm_agree(comm, local_rc, "wf_trace_commit_sharded_resident"))) {
         free_sharded(c);
         return rc;
     }
@@ -517,9 +616,9 @@ int wf_trace_commit_sharded_resident(wf_comm *comm, const wf_params *p, const vo
              ? trace_commit_sharded<F64>(comm, p, ctx->io[0].p, c->polys, c->lde_shard, c->leaves, c->nodes, ctx->io[4].p, st)
              : trace_commit_sharded<F128>(comm, p, ctx->io[0].p, c->polys, c->lde_shard, c->leaves, c->nodes, ctx->io[4].p, st);
     c->top.resize((size_t)2 * W * 32);
-    if (rc == 0 && (hipMemcpyAsync(c->top.data(), ctx->io[4].p, c->top.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                    hipStreamSynchronize(st) != hipSuccess))
+    if (rc == 0 && hipMemcpyAsync(c->top.data(), ctx->io[4].p, c->top.size(), hipMemcpyDeviceToHost, st) != hipSuccess)
         rc = fail(WF_ERR_HIP, "commitment failed: %s", hipGetErrorString(hipGetLastError()));
+    if (rc == 0) rc = comm_wait(comm, st);  // (with the watchdog: a peer that failed inside the exchanges never arrives)
     if (rc) {
         free_sharded(c);
         return rc;
@@ -600,43 +699,50 @@ int wf_sharded_commitment_query(wf_sharded_commitment *c, const uint64_t *positi
     std::vector<uint8_t> mine(msg, 0), all(msg * W);
     const size_t nd = my_dig_local.size(), nr = my_row_local.size();
     const size_t idx_bytes = (nd + nr) * 8, dig_off = (idx_bytes + 255) / 256 * 256, row_off = dig_off + (nd * 32 + 255) / 256 * 256;
-    if ((rc = ensure(ctx, ctx->io[3], row_off + nr * row_bytes + 256))) return rc;
-    if ((rc = ensure(ctx, ctx->io[4], msg * (W + 1)))) return rc;
     hipStream_t st = ctx->stream;
-    char *work = (char *)ctx->io[3].p;
-    if (nd + nr) {
-        std::vector<uint64_t> idx(my_dig_local);
-        idx.insert(idx.end(), my_row_local.begin(), my_row_local.end());
-        HIP_TRY(hipMemcpyAsync(work, idx.data(), idx_bytes, hipMemcpyHostToDevice, st));
-        if (nd) {
-            hipLaunchKernelGGL(k_gather_digests, dim3((uint32_t)((2 * nd + 255) / 256)), dim3(256), 0, st, (const uint4 *)c->leaves,
-                               (const uint4 *)c->nodes, nl, (const uint64_t *)work, (uint32_t)nd, (uint4 *)(work + dig_off));
-            HIP_TRY(hipGetLastError());
+    char *d_msg = nullptr;
+    // local stage: nothing below the agreement may fail on one rank alone
+    const int local_rc = [&]() -> int {
+        int rl;
+        if ((rl = ensure(ctx, ctx->io[3], row_off + nr * row_bytes + 256))) return rl;
+        if ((rl = ensure(ctx, ctx->io[4], msg * (W + 1)))) return rl;
+        char *work = (char *)ctx->io[3].p;
+        if (nd + nr) {
+            std::vector<uint64_t> idx(my_dig_local);
+            idx.insert(idx.end(), my_row_local.begin(), my_row_local.end());
+            HIP_TRY(hipMemcpyAsync(work, idx.data(), idx_bytes, hipMemcpyHostToDevice, st));
+            if (nd) {
+                hipLaunchKernelGGL(k_gather_digests, dim3((uint32_t)((2 * nd + 255) / 256)), dim3(256), 0, st, (const uint4 *)c->leaves,
+                                   (const uint4 *)c->nodes, nl, (const uint64_t *)work, (uint32_t)nd, (uint4 *)(work + dig_off));
+                HIP_TRY(hipGetLastError());
+            }
+            if (nr) {
+                const uint64_t trace_elems = (N / blowup) * c->per * c->row_width;  // one trace's shard
+                if (c->p.field == WF_FIELD_F64)
+                    hipLaunchKernelGGL(k_gather_rows<F64>, dim3((uint32_t)nr, c->p.n_traces), dim3(64), 0, st, (const uint64_t *)c->lde_shard,
+                                       trace_elems, (uint32_t)c->row_width, (uint32_t)c->epr, (const uint64_t *)work + nd,
+                                       (uint64_t *)(work + row_off));
+                else
+                    hipLaunchKernelGGL(k_gather_rows<F128>, dim3((uint32_t)nr, c->p.n_traces), dim3(64), 0, st, (const U128 *)c->lde_shard,
+                                       trace_elems, (uint32_t)c->row_width, (uint32_t)c->epr, (const uint64_t *)work + nd,
+                                       (U128 *)(work + row_off));
+                HIP_TRY(hipGetLastError());
+            }
+            std::vector<uint8_t> got(nd * 32 + nr * row_bytes);
+            if (nd) HIP_TRY(hipMemcpyAsync(got.data(), work + dig_off, nd * 32, hipMemcpyDeviceToHost, st));
+            if (nr) HIP_TRY(hipMemcpyAsync(got.data() + nd * 32, work + row_off, nr * row_bytes, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            for (size_t q = 0; q < nd; q++) memcpy(&mine[my_dig_at[q] * 32], &got[q * 32], 32);
+            for (size_t q = 0; q < nr; q++) memcpy(&mine[ids.size() * 32 + my_row_at[q] * row_bytes], &got[nd * 32 + q * row_bytes], row_bytes);
         }
-        if (nr) {
-            const uint64_t trace_elems = (N / blowup) * c->per * c->row_width;  // one trace's shard
-            if (c->p.field == WF_FIELD_F64)
-                hipLaunchKernelGGL(k_gather_rows<F64>, dim3((uint32_t)nr, c->p.n_traces), dim3(64), 0, st, (const uint64_t *)c->lde_shard,
-                                   trace_elems, (uint32_t)c->row_width, (uint32_t)c->epr, (const uint64_t *)work + nd,
-                                   (uint64_t *)(work + row_off));
-            else
-                hipLaunchKernelGGL(k_gather_rows<F128>, dim3((uint32_t)nr, c->p.n_traces), dim3(64), 0, st, (const U128 *)c->lde_shard,
-                                   trace_elems, (uint32_t)c->row_width, (uint32_t)c->epr, (const uint64_t *)work + nd,
-                                   (U128 *)(work + row_off));
-            HIP_TRY(hipGetLastError());
-        }
-        std::vector<uint8_t> got(nd * 32 + nr * row_bytes);
-        if (nd) HIP_TRY(hipMemcpyAsync(got.data(), work + dig_off, nd * 32, hipMemcpyDeviceToHost, st));
-        if (nr) HIP_TRY(hipMemcpyAsync(got.data() + nd * 32, work + row_off, nr * row_bytes, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        for (size_t q = 0; q < nd; q++) memcpy(&mine[my_dig_at[q] * 32], &got[q * 32], 32);
-        for (size_t q = 0; q < nr; q++) memcpy(&mine[ids.size() * 32 + my_row_at[q] * row_bytes], &got[nd * 32 + q * row_bytes], row_bytes);
-    }
-    char *d_msg = (char *)ctx->io[4].p;
-    HIP_TRY(hipMemcpyAsync(d_msg, mine.data(), msg, hipMemcpyHostToDevice, st));
+        d_msg = (char *)ctx->io[4].p;
+        HIP_TRY(hipMemcpyAsync(d_msg, mine.data(), msg, hipMemcpyHostToDevice, st));
+        return 0;
+    }();
+    if ((rc = comm_agree(comm, local_rc, "wf_sharded_commitment_query"))) return rc;
     if ((rc = comm_all_gather(comm, d_msg, d_msg + msg, msg, st))) return rc;
     HIP_TRY(hipMemcpyAsync(all.data(), d_msg + msg, msg * W, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if ((rc = comm_wait(comm, st))) return rc;
 
     // every entry from its owner's message
     std::vector<uint8_t> dig(ids.size() * 32);

@@ -76,16 +76,31 @@ class Comm:
         self.transport = "transport" if keep else "rccl"
         ctx._adopt(self)  # closed before the context (capi.Context.close), whatever order finalisers run in
 
+    _store_seq = 0  # communicators created through a store by this process: part of the key (no stale ids)
+
     @classmethod
-    def with_store(cls, ctx, store, rank: int, world: int, key: str = "wf_comm_id"):
-        """RCCL communicator; the unique id travels through `store` (set/get of bytes)."""
+    def with_store(cls, ctx, store, rank: int, world: int, key: str | None = None):
+        """RCCL communicator; the unique id travels through `store` (set/get of bytes).  Rank 0 ALWAYS publishes
+        something under the key -- the id, or an error marker that every peer turns into an exception -- so a rank 0
+        that cannot load RCCL does not leave the others waiting for the store's timeout.  The default key carries a
+        per-process sequence number (every rank creates its communicators in the same order), so a second communicator
+        on the same store never reads the first one's id."""
         L = capi.load()
+        if key is None:
+            key = f"wf_comm_id/{cls._store_seq}"
+        cls._store_seq += 1
         if rank == 0:
             uid = (C.c_uint8 * 128)()
-            capi._check(L.wf_comm_unique_id(uid))
-            store.set(key, bytes(uid))
+            rc = L.wf_comm_unique_id(uid)
+            if rc != 0:
+                msg = L.wf_last_error().decode()
+                store.set(key, b"ERR:" + msg.encode())
+                raise capi.WfError(rc, msg)
+            store.set(key, b"UID:" + bytes(uid))
         raw = bytes(store.get(key))
-        uid = (C.c_uint8 * 128).from_buffer_copy(raw[:128])
+        if raw[:4] != b"UID:":
+            raise capi.WfError(-32, "rank 0 could not draw an RCCL unique id: " + raw[4:].decode(errors="replace"))
+        uid = (C.c_uint8 * 128).from_buffer_copy(raw[4:132])
         h = C.c_void_p()
         capi._check(L.wf_comm_create(ctx._h, uid, rank, world, C.byref(h)))
         return cls(h, ctx)
@@ -124,6 +139,10 @@ class Comm:
     # -- collectives (device pointers: e.g. torch.Tensor.data_ptr()) ---------------------------------------------------
     def barrier(self):
         capi._check(capi.load().wf_comm_barrier(self._h))
+
+    def stream_wait(self, stream: int = 0):
+        """Blocking wait on `stream` under the communicator's watchdog (WfError -32 instead of a hang)."""
+        capi._check(capi.load().wf_comm_stream_wait(self._h, stream or None))
 
     def max_f64(self, value: float) -> float:
         v = C.c_double(value)
@@ -281,7 +300,14 @@ def _hip_runtime():
     global _hip
     if _hip is None:
         capi.load()
-        _hip = C.CDLL("libamdhip64.so.7")
+        for name in ("libamdhip64.so.7", "libamdhip64.so"):  # already mapped by libwf_lde.so: dlopen returns that copy
+            try:
+                _hip = C.CDLL(name)
+                break
+            except OSError:
+                continue
+        if _hip is None:
+            raise RuntimeError("the HIP runtime (libamdhip64.so) could not be opened")
         _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         _hip.hipStreamSynchronize.argtypes = [C.c_void_p]
     return _hip

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(capi):
         assert hasattr(lib, n), f"libwf_lde.so does not export {n}"
     assert set(capi.SYMBOLS) == set(names)
     # every binding declares its argument types: an undeclared size_t argument would travel as a 32-bit int
-    no_args = {"wf_last_error", "wf_device_count", "wf_comm_rccl_version"}
+    no_args = {"wf_last_error", "wf_device_count", "wf_comm_rccl_version", "wf_comm_rccl_path"}
     for n in names:
         assert getattr(lib, n).argtypes is not None or n in no_args, f"capi.load() sets no argtypes for {n}"
 
