@@ -218,6 +218,22 @@ def with_transfers(ctx, capi, params, trace_host, gpu_root):
         return ms, all(x == gpu_root for x in roots) and len(roots) == 2 * n_each
 
     out["resident_pipelined_ms_per_commit"], out["resident_pipelined_roots_match"] = pipelined(cols)
+
+    # The stream of proofs the way the library offers it (wf_trace_commit_resident_async): ONE context, the columns of
+    # proof k + 1 on the copy stream under the kernels of proof k, roots through pinned slots.
+    def streamed(columns, n=12):
+        warm = ctx.trace_commit_resident_batch(params, [columns] * 2)
+        for c in warm:
+            c.close()
+        t0 = time.perf_counter()
+        coms = ctx.trace_commit_resident_batch(params, [columns] * n)
+        ms = (time.perf_counter() - t0) * 1e3 / n
+        ok = all(c.root().hex() == gpu_root for c in coms)
+        for c in coms:
+            c.close()
+        return ms, ok
+
+    out["resident_stream_ms_per_commit"], out["resident_stream_roots_match"] = streamed(cols)
     # the same with the host columns in PINNED memory (what a host gets from hipHostMalloc): asynchronous DMA
     try:
         import torch
@@ -230,6 +246,7 @@ def with_transfers(ctx, capi, params, trace_host, gpu_root):
             com.close()
         out["resident_from_pinned_host_ms"] = sorted(ts[1:])[1]
         out["resident_pipelined_pinned_ms_per_commit"], _ = pipelined(pinned)
+        out["resident_stream_pinned_ms_per_commit"], out["resident_stream_pinned_roots_match"] = streamed(pinned)
     except Exception as e:  # noqa: BLE001 -- an optional figure
         out["resident_from_pinned_host_ms"] = f"not measured: {e}"
     # a WIDE trace (2^20 x 64: eight segments) from host columns: the upload runs segment by segment under the kernels of the
@@ -264,7 +281,8 @@ def with_transfers(ctx, capi, params, trace_host, gpu_root):
     except Exception as e:  # noqa: BLE001 -- a side measurement must not take the benchmark line down
         out["wide_error"] = f"{type(e).__name__}: {e}"
     out["note"] = ("wall clock around the C call, PCIe included; median of 3; host columns pageable numpy arrays unless 'pinned'; "
-                   "pipelined = two host threads with a context each committing back to back, wall / commitments; wide = 2^20 x 64 "
+                   "pipelined = two host threads with a context each committing back to back, wall / commitments; stream = ONE context, "
+                   "wf_trace_commit_resident_async (upload of proof k + 1 under the kernels of proof k), wall / commitments; wide = 2^20 x 64 "
                    "f64 (512 MiB of columns) with the upload under the kernels vs in front of them")
     return out
 

@@ -286,6 +286,16 @@ typedef struct wf_commitment wf_commitment;
 /* build_trace_commitment with host inputs; polys_out (host, [n_traces*n_cols] pointers) may be NULL. */
 int wf_trace_commit_resident(wf_ctx *ctx, const wf_params *p, const void *const *trace_cols, void *const *polys_out,
                              wf_commitment **out);
+/* A STREAM of proofs from host memory -- STARKPack's workload is many proofs one after the other
+ * (examples/src/lib.rs:97-135, winterfell/src/main.rs:105-160): the same build_trace_commitment, but the call returns as
+ * soon as the columns are on their way and the kernels are queued; the columns of the next proof travel on the copy stream
+ * while the kernels of this one run (two staging buffers in the context).  Pageable host columns: the call returns once
+ * they are staged.  Pinned (hipHostMalloc'd / registered) columns: it returns at once and the caller keeps them alive and
+ * unchanged until wf_commitment_wait.  The handle can be passed to every wf_commitment_* function straight away (they are
+ * ordered behind its kernels on the context's stream); wf_commitment_wait -- or the first wf_commitment_root -- blocks
+ * until the root is there and reports a failure of the kernels.  At most 256 commitments in flight (WF_ERR_BUSY). */
+int wf_trace_commit_resident_async(wf_ctx *ctx, const wf_params *p, const void *const *trace_cols, wf_commitment **out);
+int wf_commitment_wait(wf_commitment *c);
 /* build_constraint_commitment with host inputs. */
 int wf_constraint_commit_resident(wf_ctx *ctx, const wf_params *p, const void *const *poly_cols, wf_commitment **out);
 /* The constraint side from the combined constraint EVALUATIONS on, without the composition polynomial visiting the host:

@@ -21,7 +21,7 @@ SYMBOLS = [
     "wf_ctx_create", "wf_ctx_destroy", "wf_last_error", "wf_device_count", "wf_ctx_synchronize", "wf_ctx_stream",
     "wf_ctx_release_cached", "wf_plan_digits", "wf_commitment_query", "wf_ctx_profile_enable", "wf_ctx_profile_read", "wf_params_check", "wf_elem_bytes", "wf_row_width", "wf_column_bytes", "wf_lde_bytes", "wf_digests_bytes",
     "wf_trace_commit", "wf_constraint_commit", "wf_trace_commit_dev", "wf_constraint_commit_dev",
-    "wf_trace_commit_shard_dev", "wf_merkle_build_dev", "wf_trace_commit_resident", "wf_constraint_commit_resident", "wf_commitment_destroy", "wf_commitment_root",
+    "wf_trace_commit_shard_dev", "wf_merkle_build_dev", "wf_trace_commit_resident", "wf_trace_commit_resident_async", "wf_commitment_wait", "wf_constraint_commit_resident", "wf_commitment_destroy", "wf_commitment_root",
     "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_read_lde", "wf_commitment_read_lde_strided", "wf_deep_compose", "wf_commitment_evaluate_polys_at_points", "wf_constraint_commit_from_evaluations", "wf_constraint_commit_from_tables", "wf_commitment_query_many", "wf_commitment_prove", "wf_commitment_prove_batch",
     "wf_evaluate_columns_at", "wf_commitment_evaluate_polys_at", "wf_fri_layer_commit", "wf_fri_apply_drp", "wf_fri_layer_commit_dev", "wf_fri_apply_drp_dev",
     "wf_fri_prover_create", "wf_fri_prover_destroy", "wf_fri_num_layers", "wf_fri_prover_begin", "wf_fri_prover_begin_dev", "wf_fri_prover_begin_poly",
@@ -207,6 +207,8 @@ def load():
         L.wf_comm_rank.argtypes = [vp]
         L.wf_comm_world.argtypes = [vp]
         L.wf_comm_rccl_version.argtypes = []
+        L.wf_trace_commit_resident_async.argtypes = [vp, PP, vp, C.POINTER(vp)]
+        L.wf_commitment_wait.argtypes = [vp]
         L.wf_comm_rccl_path.argtypes = []
         L.wf_comm_rccl_path.restype = C.c_char_p
         L.wf_comm_stream_wait.argtypes = [vp, vp]
@@ -387,6 +389,26 @@ class Context:
                                           _ptr_array(polys) if polys else None, C.byref(h)))
         return Commitment(h, params.field, keep_alive=self), polys
 
+    def trace_commit_resident_async(self, params: Params, trace_cols):
+        """wf_trace_commit_resident_async: returns a Commitment whose kernels may still run; .wait() / .root() complete it.
+        The column arrays are kept alive by the returned object (pinned columns are read by the DMA engine after the
+        call has returned)."""
+        L = load()
+        cols = [np.ascontiguousarray(c, dtype=np.uint64) for c in trace_cols]
+        h = C.c_void_p()
+        _check(L.wf_trace_commit_resident_async(self._h, C.byref(params), _ptr_array(cols), C.byref(h)))
+        com = Commitment(h, params.field, keep_alive=self)
+        com._inputs = cols
+        return com
+
+    def trace_commit_resident_batch(self, params: Params, proofs):
+        """A stream of proofs: proofs = [columns of proof 0, columns of proof 1, ...] -> their Commitments, all complete.
+        Upload of proof k + 1 under the kernels of proof k (wf_trace_commit_resident_async + wf_commitment_wait)."""
+        coms = [self.trace_commit_resident_async(params, cols) for cols in proofs]
+        for c in coms:
+            c.wait()
+        return coms
+
     def constraint_commit_resident(self, params: Params, poly_cols):
         L = load()
         _check(L.wf_params_check(C.byref(params), 1))
@@ -559,6 +581,7 @@ class Commitment:
         self.field = field
         self._owned = owned  # layers of a FriProver belong to the prover
         self._keep_alive = keep_alive  # the Context (or FriProver) this handle lives in: destroyed after it, never before
+        self._inputs = None  # host columns of an asynchronous commitment, until it has completed
         if owned and isinstance(keep_alive, Context):
             keep_alive._adopt(self)
         n_rows, row_elems, depth = C.c_uint64(), C.c_uint64(), C.c_uint32()
@@ -582,7 +605,13 @@ class Commitment:
     def root(self) -> bytes:
         out = (C.c_uint8 * 32)()
         _check(load().wf_commitment_root(self._h, out))
+        self._inputs = None
         return bytes(out)
+
+    def wait(self):
+        """Completes a commitment made by trace_commit_resident_async (no-op otherwise)."""
+        _check(load().wf_commitment_wait(self._h))
+        self._inputs = None
 
     def read_rows(self, positions) -> np.ndarray:
         pos = np.ascontiguousarray(positions, dtype=np.uint64)

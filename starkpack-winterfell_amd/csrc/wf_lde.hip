@@ -90,7 +90,19 @@ struct wf_ctx {
     // to the context, so a call on ANOTHER stream first waits (on the device) for everything queued on that one.
     hipStream_t last_stream = nullptr;
     hipEvent_t order_ev = nullptr;
+    // A stream of proofs from host memory (wf_trace_commit_resident_async): two input staging buffers, so that proof
+    // k + 1 goes up on the copy stream while the kernels of proof k run; stage_free[i] is recorded on the compute stream
+    // behind the one kernel that reads staging buffer i, upload_done[i] on the copy stream behind its upload.  The roots
+    // come back through a ring of pinned 32-byte slots (a copy into pageable memory would block the host until the
+    // kernels in front of it have finished).
+    DevBuf stage[2];
+    hipEvent_t stage_free[2] = {nullptr, nullptr}, upload_done[2] = {nullptr, nullptr};
+    bool stage_busy[2] = {false, false};
+    uint64_t async_seq = 0;
+    uint8_t *root_pin = nullptr;
+    std::vector<uint8_t> root_used;
 };
+static constexpr size_t WF_ROOT_SLOTS = 256;
 
 // RAII entry of every ctx-taking entry point (see the two comments above).  Re-entrant for the owning thread: the
 // host-buffer forms call the device-buffer forms.
@@ -1155,7 +1167,7 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
 // Prover::build_trace_commitment on device buffers
 template <class F>
 static int trace_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_trace, void *d_polys, void *d_lde,
-                            void *d_leaves, void *d_nodes, hipStream_t st) {
+                            void *d_leaves, void *d_nodes, hipStream_t st, hipEvent_t input_read = nullptr) {
     PathBufs<F> b;
     int rc = path_buffers<F>(ctx, p, b);
     if (rc) return rc;
@@ -1163,6 +1175,7 @@ static int trace_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_trace
     // columns -> segments
     rc = run_xpose<F>(ctx, st, true, d_trace, b.segA, R, p->ext_degree, b.total_base_cols, b.n_seg);
     if (rc) return rc;
+    if (input_read) HIP_TRY(hipEventRecord(input_read, st));  // nothing below reads d_trace: its buffer may be refilled
     // ColMatrix::interpolate_columns (col_matrix.rs:196-206)
     SegDesc<F> d;
     memset(&d, 0, sizeof(d));
@@ -1322,6 +1335,7 @@ void wf_ctx_destroy(wf_ctx *ctx) {
         if (!g_live_ctx.erase(ctx)) return;  // not a live context (destroyed twice)
     }
     (void)hipSetDevice(ctx->device);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->tables) {
         if (kv.second.lo) (void)hipFree(kv.second.lo);
@@ -1337,6 +1351,12 @@ void wf_ctx_destroy(wf_ctx *ctx) {
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->qpin) (void)hipHostFree(ctx->qpin);
+    if (ctx->root_pin) (void)hipHostFree(ctx->root_pin);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->stage[i].p) (void)hipFree(ctx->stage[i].p);
+        if (ctx->stage_free[i]) (void)hipEventDestroy(ctx->stage_free[i]);
+        if (ctx->upload_done[i]) (void)hipEventDestroy(ctx->upload_done[i]);
+    }
     for (auto e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
     (void)hipStreamDestroy(ctx->stream);
@@ -1553,11 +1573,37 @@ struct wf_commitment {
     uint8_t root[32];
     bool borrowed;  // lde / leaves / nodes live in an arena of their owner (FRI layers): not freed one by one
     size_t lde_bytes, dig_bytes, polys_bytes;  // allocation sizes when they come from the context's buffer pool (else 0)
+    // wf_trace_commit_resident_async: the kernels may still be running; `done` is recorded behind the copy of the root into
+    // pinned slot root_slot1 - 1 of the context; wf_commitment_wait (or the first wf_commitment_root) completes the handle
+    bool pending;
+    hipEvent_t done;
+    uint32_t root_slot1;
 };
+
+// completes an asynchronous commitment: waits for its kernels, fetches the root, gives the pinned slot back
+static int commitment_wait(wf_commitment *c) {
+    if (!c->pending) return 0;
+    int rc = 0;
+    if (ctx_alive(c->ctx)) {
+        (void)hipSetDevice(c->ctx->device);
+        const hipError_t e = hipEventSynchronize(c->done);
+        if (e != hipSuccess) rc = fail(WF_ERR_HIP, "the commitment's kernels failed: %s", hipGetErrorString(e));
+        if (c->root_slot1) {
+            if (rc == 0) memcpy(c->root, c->ctx->root_pin + (size_t)(c->root_slot1 - 1) * 32, 32);
+            c->ctx->root_used[c->root_slot1 - 1] = 0;
+        }
+    }
+    if (c->done) (void)hipEventDestroy(c->done);
+    c->done = nullptr;
+    c->root_slot1 = 0;
+    c->pending = false;
+    return rc;
+}
 
 static void free_commitment(wf_commitment *c) {
     if (!c) return;
     if (ctx_alive(c->ctx)) (void)hipSetDevice(c->ctx->device);
+    if (c->pending) (void)commitment_wait(c);
     if (!c->borrowed) {
         pool_free(c->ctx, c->lde, c->lde_bytes);
         pool_free(c->ctx, c->leaves, c->dig_bytes);
@@ -1668,10 +1714,93 @@ int wf_constraint_commit_resident(wf_ctx *ctx, const wf_params *p, const void *c
     return commit_resident(ctx, p, true, poly_cols, nullptr, out);
 }
 
+// A stream of proofs from host columns: Prover::build_trace_commitment (prover/src/lib.rs:615-670) of STARKPack's many
+// proofs (examples/src/lib.rs:97-135, winterfell/src/main.rs:105-160) one after the other, the upload of proof k + 1 on
+// the copy stream under the kernels of proof k.  Returns once the columns are on their way (pageable memory: once they
+// are staged; pinned memory: at once -- the caller keeps pinned columns alive until wf_commitment_wait).
+static int commit_resident_async(wf_ctx *ctx, const wf_params *p, const void *const *cols_in, wf_commitment **out) {
+    if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
+    if (!out) return fail(WF_ERR_ARG, "out is null");
+    int rc = check_params(p, false);
+    if (rc) return rc;
+    if (!cols_in) return fail(WF_ERR_ARG, "column pointer array is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    WF_ENTER(ctx, st);
+    const size_t colb = wf_column_bytes(p), TC = (size_t)p->n_cols * p->n_traces;
+    for (size_t i = 0; i < TC; i++)
+        if (!cols_in[i]) return fail(WF_ERR_ARG, "column %zu is null", i);
+    if (!ctx->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->root_pin) {
+        HIP_TRY(hipHostMalloc((void **)&ctx->root_pin, WF_ROOT_SLOTS * 32, hipHostMallocDefault));
+        ctx->root_used.assign(WF_ROOT_SLOTS, 0);
+    }
+    for (int i = 0; i < 2; i++) {
+        if (!ctx->stage_free[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->stage_free[i], hipEventDisableTiming));
+        if (!ctx->upload_done[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->upload_done[i], hipEventDisableTiming));
+    }
+    uint32_t slot1 = 0;
+    for (size_t i = 0; i < WF_ROOT_SLOTS && !slot1; i++)
+        if (!ctx->root_used[i]) slot1 = (uint32_t)i + 1;
+    if (!slot1) return fail(WF_ERR_BUSY, "%zu asynchronous commitments are in flight: wait for (or destroy) some first", WF_ROOT_SLOTS);
+    const int sb = (int)(ctx->async_seq & 1);
+    if ((rc = ensure(ctx, ctx->stage[sb], TC * colb))) return rc;
+    wf_commitment *c = nullptr;
+    bool dense = false;
+    if ((rc = commitment_alloc(ctx, p, false, &c, &dense))) return rc;
+    hipError_t e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        free_commitment(c);
+        return fail(WF_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
+    }
+    // the staging buffer is free once the layout kernel of the commitment that used it two calls ago has read it
+    if (ctx->stage_busy[sb]) e = hipStreamWaitEvent(ctx->copy_stream, ctx->stage_free[sb], 0);
+    if (e == hipSuccess) {
+        rc = upload_columns(ctx, ctx->stage[sb].p, cols_in, TC, colb, ctx->copy_stream);
+        if (rc == 0) e = hipEventRecord(ctx->upload_done[sb], ctx->copy_stream);
+    }
+    if (rc == 0 && e == hipSuccess) e = hipStreamWaitEvent(st, ctx->upload_done[sb], 0);
+    if (rc == 0 && e == hipSuccess)
+        rc = p->field == WF_FIELD_F64
+                 ? trace_commit_dev<F64>(ctx, p, ctx->stage[sb].p, c->polys, c->lde, c->leaves, c->nodes, st, ctx->stage_free[sb])
+                 : trace_commit_dev<F128>(ctx, p, ctx->stage[sb].p, c->polys, c->lde, c->leaves, c->nodes, st, ctx->stage_free[sb]);
+    if (rc == 0 && e == hipSuccess)
+        e = hipMemcpyAsync(ctx->root_pin + (size_t)(slot1 - 1) * 32, (char *)c->nodes + 32, 32, hipMemcpyDeviceToHost, st);
+    if (rc == 0 && e == hipSuccess) e = hipEventRecord(c->done, st);
+    if (rc || e != hipSuccess) {
+        // whatever was queued from the caller's columns or into this handle's buffers must have drained before either goes away
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamSynchronize(st);
+        ctx->stage_busy[sb] = false;
+        free_commitment(c);
+        return rc ? rc : fail(WF_ERR_HIP, "queueing the commitment failed: %s", hipGetErrorString(e));
+    }
+    ctx->stage_busy[sb] = true;
+    ctx->async_seq++;
+    ctx->root_used[slot1 - 1] = 1;
+    c->root_slot1 = slot1;
+    c->pending = true;
+    *out = c;
+    return 0;
+}
+
+int wf_trace_commit_resident_async(wf_ctx *ctx, const wf_params *p, const void *const *trace_cols, wf_commitment **out) {
+    return commit_resident_async(ctx, p, trace_cols, out);
+}
+
+int wf_commitment_wait(wf_commitment *c) {
+    if (!c) return fail(WF_ERR_ARG, "commitment is null");
+    return commitment_wait(c);
+}
+
 void wf_commitment_destroy(wf_commitment *c) { free_commitment(c); }
 
 int wf_commitment_root(const wf_commitment *c, uint8_t root_out[32]) {
     if (!c || !root_out) return fail(WF_ERR_ARG, "null argument");
+    if (c->pending) {  // an asynchronous commitment asked for its root: this is where the host waits for it
+        int rc = commitment_wait(const_cast<wf_commitment *>(c));
+        if (rc) return rc;
+    }
     memcpy(root_out, c->root, 32);
     return 0;
 }
