@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json metric on MI355X: trace-LDE + Merkle-commit of a 2^20 x 8 f64 trace at blowup 8.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode proofs|packed]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode proofs|packed] [--config cfg2|cfg3|cfg5|dowork]
 
 A "step" is one pass of the hot path (Prover::build_trace_commitment, /root/reference/prover/src/lib.rs:615-670)
 over one synthetic trace that is already resident in HBM: interpolate 8 columns -> evaluate over the 8 cosets into
@@ -19,7 +19,12 @@ environment) it is a rank.
 WF_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks: the ranks share
 the device and the bytes of the collectives travel over a torch.distributed gloo group (wf_transport).
 
+--config (single GPU) prints the same line for the other workloads of the record: cfg3 (2^22 x 64 f64), cfg5 (f128 2^18 x 10),
+dowork (the reference's example at its defaults: 512 packed f128 traces of 2^10); the headline stays cfg2.
+
 Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
+  alu            : the step against the time its butterflies and BLAKE3 compressions take at the rates the same instruction
+                   sequences reach in isolation -- measured IN THIS RUN (csrc/yardstick.hip), with the clocks both ran at
   roofline       : dominant logical kernel, its algorithmic bytes per launch
                    / its HIP-event duration measured inside the timed region, against the 8 TB/s HBM peak
   cpu_baseline   : the CPU oracle (oracle/, "port" of the reference's concurrent path) timed on this box's host
@@ -39,14 +44,32 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-LOG_R, LOG_B, N_COLS = 20, 3, 8
+LOG_R, LOG_B, N_COLS = 20, 3, 8   # the metric's configuration (cfg 2); --config selects another single-GPU workload
 PACKED_TRACES = 8
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-# integer-VALU rates of the path's two instruction sequences in isolation on one MI355X (scripts/microbench.hip; the
-# better of the boxes measured, profiles/r01_microbench.txt): Goldilocks butterflies, BLAKE3 compressions.  Constants,
-# not measured in this run: `alu.frac` is the step against THAT yardstick.
-ALU_BFLY_PER_S = 1.59e12
-ALU_COMPRESS_PER_S = 57.0e9
+
+# Workloads.  cfg2 is the configuration BASELINE.json's metric is quoted on and the only one the driver's contract runs
+# (python bench.py [--gpus N]); the others print the same JSON line for the record (profiles/r03_cfg3_*, r03_cfg5_*).
+CONFIGS = {
+    "cfg2": dict(field="f64", log_r=20, log_b=3, n_cols=8, n_traces=1,
+                 label="BASELINE.json configs[1]: 2^20 rows x 8 cols f64, blowup 8, BLAKE3-256 Merkle"),
+    "cfg3": dict(field="f64", log_r=22, log_b=3, n_cols=64, n_traces=1,
+                 label="BASELINE.json configs[2], trace side: 2^22 rows x 64 cols f64, blowup 8 (16 GiB LDE)"),
+    "cfg5": dict(field="f128", log_r=18, log_b=3, n_cols=10, n_traces=1,
+                 label="BASELINE.json configs[4] substitute (SURVEY.md §8d): do_work-shaped f128 trace, 2^18 rows x 10 cols, blowup 8, path only"),
+    "dowork": dict(field="f128", log_r=10, log_b=3, n_cols=10, n_traces=512,
+                   label="the reference's own example at its defaults (examples/src/lib.rs:97-135): 512 packed do_work traces of "
+                         "2^10 rows x 10 cols f128 under ONE tree (80-chunk rows), blowup 8"),
+}
+
+
+def row_compressions(row_bytes):
+    """BLAKE3 compressions of one hashed row: 64-byte blocks, plus the parent nodes of a row longer than a chunk."""
+    if row_bytes <= 1024:
+        return max(1, (row_bytes + 63) // 64)
+    chunks = (row_bytes + 1023) // 1024
+    last = row_bytes - (chunks - 1) * 1024
+    return (chunks - 1) * 16 + (last + 63) // 64 + (chunks - 1)
 
 
 def work_model(log_r=LOG_R, log_b=LOG_B, c=N_COLS, e=8, n_traces=1):
@@ -64,9 +87,83 @@ def work_model(log_r=LOG_R, log_b=LOG_B, c=N_COLS, e=8, n_traces=1):
     butterflies = C * (R // 2) * log_r * (1 + beta)
     muls = butterflies + C * R + beta * C * R
     field_ops = 3 * butterflies + C * R + beta * C * R
-    compressions = N * ((C * e + 63) // 64) + (N - 1)
+    compressions = N * row_compressions(C * e) + (N - 1)
     return dict(bytes_per_kernel=bytes_k, b_alg=b_alg, field_ops=field_ops, modmuls=muls, compressions=compressions,
                 butterflies=butterflies)
+
+
+def gpu_clock_files(torch, dev_index):
+    """hwmon files with the current shader clock of device dev_index (Hz), matched by PCI address; [] if unreadable."""
+    import glob
+    files = glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input")
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+        mine = [f for f in files if addr in os.path.realpath(f)]
+        if mine:
+            return mine[:1]
+    except Exception:  # noqa: BLE001 -- older torch: no PCI ids
+        pass
+    return files
+
+
+class ClockSampler:
+    """Reads the driver's current shader clock (hwmon freq1_input, what the SMU reports) in a thread while a measurement
+    runs.  With several candidate cards (no PCI match) the highest reading of a sweep is the busy GPU: ours."""
+
+    def __init__(self, files):
+        import threading
+        self.files, self.samples, self._stop = files, [], threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            best = 0
+            for f in self.files:
+                try:
+                    best = max(best, int(open(f).read()))
+                except (OSError, ValueError):
+                    pass
+            if best:
+                self.samples.append(best / 1e6)
+
+    def __enter__(self):
+        if self.files:
+            self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self.files:
+            self._t.join(timeout=2)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        v = sorted(self.samples)
+        return {"mean_mhz": round(sum(v) / len(v), 1), "min_mhz": v[0], "max_mhz": v[-1], "samples": len(v)}
+
+
+def yardstick(torch, dev_index, clock_files, is64):
+    """The integer-VALU rates of the path's own instruction sequences in isolation, measured NOW on this GPU
+    (csrc/yardstick.hip: Goldilocks or f128 butterflies, BLAKE3 compressions; register-only loops, 8 waves per SIMD),
+    each with the driver's shader-clock reading sampled while exactly that loop ran."""
+    import ctypes as C
+    from starkpack_winterfell_amd.build import yardstick_path
+    path = yardstick_path()
+    if not os.path.exists(path):
+        return {"error": "libwf_yardstick.so has not been built"}
+    Y = C.CDLL(path)
+    Y.wf_yardstick_run.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double)]
+    res = {}
+    for name, which in (("butterflies", 0 if is64 else 1), ("blake3_compressions", 2)):
+        out = (C.c_double * 2)()
+        with ClockSampler(clock_files) as cs:
+            rc = Y.wf_yardstick_run(dev_index, which, out)
+        if rc:
+            return {"error": f"wf_yardstick_run({which}) failed with {rc}"}
+        res[name] = {"per_s": out[0], "kernel_ms": round(out[1], 3), "clock_driver": cs.summary()}
+    return res
 
 
 def rand_f64_dev(torch, n, seed, device):
@@ -76,6 +173,15 @@ def rand_f64_dev(torch, n, seed, device):
     v = torch.randint(-2**63, 2**63 - 1, (n,), dtype=torch.int64, device=device, generator=gen)
     bad = (v >> 32) == -1  # top 32 bits all ones: may be >= p = 2^64 - 2^32 + 1
     return torch.where(bad, v & 0x7FFFFFFFFFFFFFFF, v)
+
+
+def rand_f128_dev(torch, n, seed, device):
+    """n canonical elements of the 128-bit field (< 2^127 < p) as int64 pairs (lo, hi)."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    v = torch.randint(-2**63, 2**63 - 1, (n, 2), dtype=torch.int64, device=device, generator=gen)
+    v[:, 1] &= 0x7FFFFFFFFFFFFFFF
+    return v.reshape(-1)
 
 
 def csrc_sha():
@@ -108,10 +214,11 @@ def probe(cmd):
         return None
 
 
-def cpu_baseline(model, trace_host=None, gpu_root=None, runs=5, warmups=2):
-    """Full commitments of the bench workload (the very trace rank 0 committed on the GPU) with the threaded CPU
+def cpu_baseline(model, wl, traces_host, gpu_root=None, runs=5, warmups=2):
+    """Full commitments of the bench workload (the very traces rank 0 committed on the GPU) with the threaded CPU
     oracle -- test infrastructure, used here only as the reported CPU baseline and as a last parity gate.  The C
-    entry point is timed on preallocated, already faulted-in outputs (no Python allocation inside the clock)."""
+    entry point is timed on preallocated, already faulted-in outputs (no Python allocation inside the clock).
+    traces_host: [n_traces][n_cols] arrays.  Phases (ms) and ns per BLAKE3 compression are those of the median run."""
     threads = min(os.cpu_count() or 1, 64)
     try:
         threads = min(threads, len(os.sched_getaffinity(0)))
@@ -123,32 +230,38 @@ def cpu_baseline(model, trace_host=None, gpu_root=None, runs=5, warmups=2):
     import numpy as np
     from oracle import oracle as O
     O.build()
-    rng = np.random.default_rng(0x57415446)
-    p = np.uint64(2**64 - 2**32 + 1)
-
-    def cols(log_r):
-        out = []
-        for _ in range(N_COLS):
-            v = rng.integers(0, 2**64 - 1, size=1 << log_r, dtype=np.uint64, endpoint=True)
-            v[v >= p] -= p
-            out.append(v)
-        return out
-
-    data = cols(LOG_R) if trace_host is None else [np.ascontiguousarray(c) for c in trace_host]
+    field = O.F64 if wl["field"] == "f64" else O.F128
+    offset = 7 if wl["field"] == "f64" else 3
+    data = [[np.ascontiguousarray(c) for c in t] for t in traces_host]
     res = None
     for _ in range(warmups):  # threads, page cache, output pages
-        res = O.build_trace_commitment(O.F64, [data], 1, LOG_R, LOG_B, 7, threads=threads, out=res)
+        res = O.build_trace_commitment(field, data, 1, wl["log_r"], wl["log_b"], offset, threads=threads, out=res)
     times = []
     for _ in range(runs):
         t0 = time.perf_counter()
-        res = O.build_trace_commitment(O.F64, [data], 1, LOG_R, LOG_B, 7, threads=threads, out=res)
-        times.append((time.perf_counter() - t0) * 1e3)
-    times.sort()
-    median = times[len(times) // 2]
+        res = O.build_trace_commitment(field, data, 1, wl["log_r"], wl["log_b"], offset, threads=threads, out=res)
+        times.append(((time.perf_counter() - t0) * 1e3, O.last_phase_ms()))
+    times.sort(key=lambda x: x[0])
+    median, phases = times[len(times) // 2]
+    ms = [t for t, _ in times]
+    N = 1 << (wl["log_r"] + wl["log_b"])
+    leaf_comp = model["compressions"] - (N - 1)
+    # one thread's time per compression (the phase's wall clock x threads / compressions): comparable with the reference's
+    # published single-thread 2-to-1 hash latency -- the tree phase is exactly N - 1 such hashes
+    ns_tree = phases[3] * 1e6 * threads / (N - 1)
+    ns_leaf = phases[2] * 1e6 * threads / leaf_comp
     return dict(value=model["field_ops"] / (median * 1e-3), unit="field-ops/s", cores=threads, kind="port",
-                sample=f"{runs} full commitments (2^{LOG_R} x {N_COLS} f64, blowup {1 << LOG_B}) after {warmups} warm-ups, "
-                       f"outputs preallocated; median {median:.0f} ms, min {times[0]:.0f} ms",
-                median_ms=median, min_ms=times[0], max_ms=times[-1], runs=runs, warmups=warmups,
+                label="C restatement of the reference's concurrent CPU path (oracle/, OpenMP; BLAKE3 compression vectorised as in the "
+                      "blake3 crate's single-compression SSE form) -- not the Rust binary, which cannot be built here",
+                sample=f"{runs} full commitments ({wl['n_traces']} x 2^{wl['log_r']} x {wl['n_cols']} {wl['field']}, blowup {1 << wl['log_b']}) "
+                       f"after {warmups} warm-ups, outputs preallocated; median {median:.0f} ms, min {ms[0]:.0f} ms",
+                median_ms=median, min_ms=ms[0], max_ms=ms[-1], runs=runs, warmups=warmups,
+                phase_ms={"interpolate": round(phases[0], 2), "evaluate": round(phases[1], 2), "hash_rows": round(phases[2], 2),
+                          "merkle": round(phases[3], 2)},
+                ns_per_compression={"merkle_2_to_1": round(ns_tree, 1), "leaf_rows": round(ns_leaf, 1), "threads": threads,
+                                    "reference_published_2_to_1_ns": "62-106 (single thread; /root/reference/crypto/README.md:69-75)",
+                                    "note": "wall clock of the phase x threads / compressions: an upper bound on the per-thread cost "
+                                            "(includes imbalance and memory stalls of the 64-thread run)"},
                 cpu_model=cpu_model(), threads_pinned=os.environ.get("OMP_PROC_BIND") == "close",
                 omp_places=os.environ.get("OMP_PLACES"), root=res["root"].hex(),
                 root_matches_gpu=(None if gpu_root is None else res["root"].hex() == gpu_root),
@@ -419,6 +532,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=("proofs", "packed"), default="proofs")
+    ap.add_argument("--config", choices=tuple(CONFIGS), default="cfg2",
+                    help="workload (single GPU for all but cfg2): cfg2 = the metric; cfg3 = 2^22 x 64 f64; cfg5 = f128 2^18 x 10; "
+                         "dowork = the reference's example defaults (512 packed f128 traces of 2^10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-transfers", action="store_true")
     ap.add_argument("--per-launch", action="store_true", help="also report HIP-event times of every kernel launch")
@@ -427,6 +543,8 @@ def main():
                          "root on rank 1 so that the parity gate must fire; 'hang' makes rank 1 sleep so that the launcher's limit must")
     args = ap.parse_args()
 
+    if args.config != "cfg2" and (args.gpus > 1 or args.mode != "proofs"):
+        sys.exit("--config other than cfg2 is a single-GPU record of the default mode (the multi-GPU modes run the metric's workload)")
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
 
@@ -473,22 +591,32 @@ def main():
                 comm = TorchRcclComm(torch, device, next(x for x in status if x != "ok"))
 
     packed = args.mode == "packed"
-    n_traces = PACKED_TRACES if packed else 1
-    model = work_model(n_traces=n_traces)
-    params = capi.make_params(capi.F64, 1, LOG_R, LOG_B, N_COLS, n_traces)
-    R, N = 1 << LOG_R, 1 << (LOG_R + LOG_B)
+    wl = dict(CONFIGS[args.config])
+    if packed:
+        wl["n_traces"] = PACKED_TRACES
+    n_traces, n_cols, log_r, log_b = wl["n_traces"], wl["n_cols"], wl["log_r"], wl["log_b"]
+    is64 = wl["field"] == "f64"
+    elem_bytes, words = (8, 1) if is64 else (16, 2)
+    model = work_model(log_r, log_b, n_cols, elem_bytes, n_traces)
+    params = capi.make_params(capi.F64 if is64 else capi.F128, 1, log_r, log_b, n_cols, n_traces)
+    R, N = 1 << log_r, 1 << (log_r + log_b)
+    row_width = 8 * ((n_cols + 7) // 8)
     # packed: every rank holds the same traces (one proof); proofs: a trace of its own per rank
     proof_id = 0 if packed else shard.proofs_of_rank(world, rank, world)[0]
-    trace = rand_f64_dev(torch, n_traces * N_COLS * R, shard.seed_of_proof(0x57415446, proof_id), device)
+    seed = shard.seed_of_proof(0x57415446, proof_id)
+    trace = (rand_f64_dev if is64 else rand_f128_dev)(torch, n_traces * n_cols * R, seed, device)
     polys = torch.empty_like(trace)
     share = world if packed else 1  # a rank's part of the LDE rows and of the tree
-    lde = torch.empty(n_traces * (N // share) * 8, dtype=torch.int64, device=device)
+    lde = torch.empty(n_traces * (N // share) * row_width * words, dtype=torch.int64, device=device)
     leaves = torch.empty((N // share, 32), dtype=torch.uint8, device=device)
     nodes = torch.empty((N // share, 32), dtype=torch.uint8, device=device)
     top = torch.zeros((2 * world, 32), dtype=torch.uint8, device=device)
 
     stream = torch.cuda.Stream(device=device)
     torch.cuda.synchronize()
+    clock_files = gpu_clock_files(torch, dev_index) if rank == 0 else []
+    # the yardstick of the `alu` object: measured in THIS run on THIS GPU, before the timed region
+    yard = yardstick(torch, dev_index, clock_files, CONFIGS[args.config]['field'] == 'f64') if rank == 0 else None
     ctx.profile_enable(1)  # HIP events at the logical-kernel boundaries of every timed step (5 per step, ~1 %)
     per_launch = {}
 
@@ -524,6 +652,8 @@ def main():
         if comm is not None:
             comm.barrier()
         torch.cuda.synchronize()
+        sampler = ClockSampler(clock_files)
+        sampler.__enter__()  # the driver's clock reading while the timed steps run (a reader thread; no GPU work)
         t0 = time.perf_counter()
         for k in range(args.steps):
             step(k)
@@ -535,6 +665,7 @@ def main():
             comm.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        sampler.__exit__()
         # HIP events recorded on the launch stream in front of every kernel of the K timed steps
         for name, ms in ctx.profile_read():
             per_launch.setdefault(name, []).append(ms)
@@ -597,7 +728,7 @@ def main():
         # HBM-side bytes of the dominant kernel from the PMC passes of scripts/profile_round.sh -- quoted only while the
         # kernel sources are the ones they were measured on
         traffic, traffic_sha = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "traffic.json" if args.config == "cfg2" else f"traffic_{args.config}.json")
         if os.path.exists(tpath) and not packed and world == 1:
             try:
                 tj = json.load(open(tpath))
@@ -608,11 +739,27 @@ def main():
                 traffic = None
         workload = (f"{PACKED_TRACES} packed traces of 2^20 rows x 8 cols f64 under ONE tree (STARKPack), blowup 8, sharded "
                     f"by coset over {world} GPU(s)" if packed else
-                    "BASELINE.json configs[1]: 2^20 rows x 8 cols f64, blowup 8, BLAKE3-256 Merkle; one independent "
-                    "commitment per GPU per step"
+                    wl["label"] + "; one independent commitment per GPU per step"
                     + (", the roots of all steps all-gathered over RCCL once per run (configs[3])" if world > 1 else ""))
+        # `alu`: the step against the time its butterflies and compressions take at the rates the same instruction
+        # sequences reach in isolation -- measured in this run (yardstick above), with the clocks both ran at
+        alu = {"butterflies": model["butterflies"], "blake3_compressions": model["compressions"]}
+        if yard and "error" not in yard:
+            b_rate, c_rate = yard["butterflies"]["per_s"], yard["blake3_compressions"]["per_s"]
+            ideal = (model["butterflies"] / b_rate + model["compressions"] / c_rate) * 1e3 / (world if packed else 1)
+            alu.update({"yardstick_butterflies_per_s": b_rate, "yardstick_compressions_per_s": c_rate,
+                        "rates": "measured in this run before the timed region (csrc/yardstick.hip: register-only loops of the kernels' own "
+                                 "device functions, 8 waves per SIMD; " + ("Goldilocks" if is64 else "f128") + " butterflies)",
+                        "clock_mhz_driver_reading": {"yardstick_butterflies": yard["butterflies"]["clock_driver"],
+                                                     "yardstick_compressions": yard["blake3_compressions"]["clock_driver"],
+                                                     "timed_steps": sampler.summary(),
+                                                     "source": "hwmon freq1_input (sclk) of this GPU, read in a loop by a host thread"},
+                        "ideal_ms": ideal, "frac": ideal / ms_per_step})
+        else:
+            alu["error"] = (yard or {}).get("error", "not measured")
         out = {
-            "metric": "trace-LDE + Merkle-commit field-ops/s (wall-clock ms in ms_per_step), 2^20x8 f64 trace blowup=8",
+            "metric": ("trace-LDE + Merkle-commit field-ops/s (wall-clock ms in ms_per_step), 2^20x8 f64 trace blowup=8" if args.config == "cfg2"
+                       else f"trace-LDE + Merkle-commit field-ops/s (wall-clock ms in ms_per_step), {args.config} (not the headline metric)"),
             "value": value,
             "unit": "field-ops/s",
             "n_gpus": world,
@@ -622,10 +769,10 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if packed else "weak",
             "vs_baseline": None,
-            "dtype": "u64 (Goldilocks, Montgomery form) + u32 (BLAKE3)",
+            "dtype": ("u64 (Goldilocks, Montgomery form)" if is64 else "u128 (p = 2^128 - 45 * 2^40 + 1, canonical; 32-bit limbs)") + " + u32 (BLAKE3)",
             "data": "synthetic (seeded uniform field elements, resident in HBM)",
-            "config": {"workload": workload, "mode": args.mode, "log2_trace_len": LOG_R, "n_cols": N_COLS,
-                       "blowup": 1 << LOG_B, "n_traces": n_traces},
+            "config": {"workload": workload, "name": args.config, "mode": args.mode, "field": wl["field"], "log2_trace_len": log_r,
+                       "n_cols": n_cols, "blowup": 1 << log_b, "n_traces": n_traces},
             "commits_per_s": commits / elapsed,
             "collective": (None if comm is None else
                            {"transport": "RCCL inside libwf_lde.so (wf_comm, C ABI)" if comm.transport == "rccl"
@@ -636,13 +783,7 @@ def main():
                             "verified": verified,
                             "calls": "all-to-all of leaf digests + all-gather of sub-roots per step" if packed
                             else "one all-gather of roots per run"}),
-            # the path is integer-VALU bound: time of its butterflies and BLAKE3 compressions at the rates the same
-            # instruction sequences reach in isolation (scripts/microbench.hip, profiles/r01_microbench.txt) vs the step
-            "alu": {"butterflies": model["butterflies"], "blake3_compressions": model["compressions"],
-                    "microbench_butterflies_per_s": ALU_BFLY_PER_S, "microbench_compressions_per_s": ALU_COMPRESS_PER_S,
-                    "rates": "constants from profiles/r01_microbench.txt, not measured in this run",
-                    "ideal_ms": (model["butterflies"] / ALU_BFLY_PER_S + model["compressions"] / ALU_COMPRESS_PER_S) * 1e3 / per_rank,
-                    "frac": (model["butterflies"] / ALU_BFLY_PER_S + model["compressions"] / ALU_COMPRESS_PER_S) * 1e3 / per_rank / ms_per_step},
+            "alu": alu,
             "path": {"b_alg_bytes": model["b_alg"], "hbm_frac": model["b_alg"] / per_rank / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "field_ops": model["field_ops"], "blake3_compressions": model["compressions"]},
             "roofline": {"bound": "hbm", "kernel": dom + (" (leaf hashing fused into its last pass)" if fused_hash and dom == "evaluate" else ""),
@@ -655,16 +796,19 @@ def main():
             "roots_gathered": n_roots,
         }
         if world == 1 and not packed:
-            th = trace.cpu().numpy().view("uint64").reshape(N_COLS, R)
+            th = trace.cpu().numpy().view("uint64")
+            th = th.reshape(n_traces, n_cols, R) if is64 else th.reshape(n_traces, n_cols, R, 2)
             # the two side measurements must not cost the line its timed result: a failure in them is reported in place
-            if not args.no_transfers:
+            if not args.no_transfers and args.config == "cfg2":
                 try:
-                    out["with_transfers"] = with_transfers(ctx, capi, params, th, root_hex)
+                    out["with_transfers"] = with_transfers(ctx, capi, params, th[0], root_hex)
                 except Exception as e:  # noqa: BLE001
                     out["with_transfers"] = {"error": f"{type(e).__name__}: {e}"}
             if not args.no_cpu_baseline:
+                big = model["butterflies"] > 4e9   # cfg 3: ~15 s of 64 cores per commitment -- one run is the bounded sample
                 try:
-                    out["cpu_baseline"] = cpu_baseline(model, th, root_hex)
+                    out["cpu_baseline"] = cpu_baseline(model, wl, [list(t) for t in th], root_hex, runs=1 if big else 5,
+                                                       warmups=0 if big else 2)
                 except Exception as e:  # noqa: BLE001
                     out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}", "kind": "port"}
                 if out["cpu_baseline"].get("root_matches_gpu") is False:

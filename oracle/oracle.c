@@ -204,6 +204,13 @@ int orc_build_merkle_nodes(const uint8_t *leaves, size_t n_leaves, uint8_t *node
     return 0;
 }
 
+/* Wall clock of the phases of the last orc_build_trace_commitment / orc_build_constraint_commitment of this process
+ * (the reference logs the same phases with debug!, prover/src/lib.rs:628-667): interpolate, evaluate, hash rows, tree.
+ * For bench.py's cpu_baseline record; not thread-safe across concurrent commitments. */
+static double g_phase_ms[4];
+static double now_ms(void) { return omp_get_wtime() * 1e3; }
+void orc_last_phase_ms(double out[4]) { memcpy(out, g_phase_ms, sizeof(g_phase_ms)); }
+
 /* RowMatrix::commit_to_comb_rows (row_matrix.rs:204-238); with n_traces == 1 it is commit_to_rows (:183-203).
  * lde[t]: row-major matrices of n_rows x row_width base values; a row contributes its first elements_per_row. */
 int orc_commit_to_comb_rows(int field, const void *const *lde, size_t n_traces, size_t n_rows, size_t row_width,
@@ -211,6 +218,7 @@ int orc_commit_to_comb_rows(int field, const void *const *lde, size_t n_traces, 
     size_t eb = field == ORC_FIELD_F128 ? 16 : 8;
     if (threads < 1) threads = 1;
     int err = 0;
+    const double t_hash0 = now_ms();
 #pragma omp parallel num_threads(threads) if (threads > 1)
     {
         uint8_t *comb = (uint8_t *)malloc(n_traces * elements_per_row * eb);
@@ -226,7 +234,11 @@ int orc_commit_to_comb_rows(int field, const void *const *lde, size_t n_traces, 
         free(comb);
     }
     if (err) return -3;
-    return orc_build_merkle_nodes(leaves, n_rows, nodes, threads);
+    const double t_tree0 = now_ms();
+    g_phase_ms[2] = t_tree0 - t_hash0;
+    int rc = orc_build_merkle_nodes(leaves, n_rows, nodes, threads);
+    g_phase_ms[3] = now_ms() - t_tree0;
+    return rc;
 }
 
 /* ------------------------------------------------------------------ the path */
@@ -256,20 +268,26 @@ int orc_build_trace_commitment(int field, size_t ext, unsigned log2_R, unsigned 
     f128e off128;
     memcpy(&off128, offset_le, 16);
     if (off128 == 0) return -17; /* fft/mod.rs:201 */
+    g_phase_ms[0] = g_phase_ms[1] = 0.0;
     for (size_t t = 0; t < n_traces; t++) {
+        const double t_int0 = now_ms();
         if (field == ORC_FIELD_F64) {
             orc_f64_interpolate_columns((const uint64_t *const *)(trace_cols + t * n_cols), n_cols, ext, R,
                                         (uint64_t *const *)(polys_out + t * n_cols), threads);
+            g_phase_ms[0] += now_ms() - t_int0;
             rc = orc_f64_evaluate_polys_over((const uint64_t *const *)(polys_out + t * n_cols), n_cols, ext, R, blowup,
                                              f64_new((uint64_t)off128), (uint64_t *)lde_out[t], threads);
         } else {
             orc_f128_interpolate_columns((const f128e *const *)(trace_cols + t * n_cols), n_cols, ext, R,
                                          (f128e *const *)(polys_out + t * n_cols), threads);
+            g_phase_ms[0] += now_ms() - t_int0;
             rc = orc_f128_evaluate_polys_over((const f128e *const *)(polys_out + t * n_cols), n_cols, ext, R, blowup,
                                               off128, (f128e *)lde_out[t], threads);
         }
         if (rc) return rc;
+        g_phase_ms[1] += now_ms() - t_int0;
     }
+    g_phase_ms[1] -= g_phase_ms[0];
     return orc_commit_to_comb_rows(field, (const void *const *)lde_out, n_traces, R * blowup, row_width, base_cols,
                                    leaves, nodes, threads);
 }

@@ -137,4 +137,10 @@ int orc_max_threads(void);
 #ifdef __cplusplus
 }
 #endif
+/* phases of the last commitment of this process, ms: interpolate, evaluate, hash rows, tree (bench.py's record) */
+void orc_last_phase_ms(double out[4]);
+/* one BLAKE3 compression through the SIMD and the scalar form (test hook) */
+void orc_blake3_compress_both(const uint32_t cv[8], const uint32_t block[16], uint64_t counter, uint32_t block_len,
+                              uint32_t flags, uint32_t out_simd[8], uint32_t out_scalar[8]);
+
 #endif

@@ -302,6 +302,22 @@ def build_trace_commitment(field: int, traces, ext: int, log2_R: int, log2_blowu
     return dict(polys=polys, lde=lde, leaves=leaves, nodes=nodes, root=bytes(nodes[1]))
 
 
+def last_phase_ms():
+    """(interpolate, evaluate, hash rows, tree) wall clock in ms of the last build_*_commitment of this process."""
+    out = (C.c_double * 4)()
+    lib().orc_last_phase_ms(out)
+    return tuple(out)
+
+
+def blake3_compress_both(cv, block, counter: int, block_len: int, flags: int):
+    """One compression through the SIMD and the scalar form of oracle/blake3_ref.c (test hook)."""
+    cv = np.ascontiguousarray(cv, dtype=np.uint32)
+    block = np.ascontiguousarray(block, dtype=np.uint32)
+    a, b = np.zeros(8, np.uint32), np.zeros(8, np.uint32)
+    lib().orc_blake3_compress_both(_p(cv), _p(block), C.c_uint64(counter), C.c_uint32(block_len), C.c_uint32(flags), _p(a), _p(b))
+    return a, b
+
+
 def build_constraint_commitment(field: int, poly_cols, ext: int, log2_R: int, log2_blowup: int, offset: int,
                                 threads: int = 1):
     R, blowup = 1 << log2_R, 1 << log2_blowup

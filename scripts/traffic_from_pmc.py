@@ -1,7 +1,8 @@
 """Builds profiles/traffic.json from two rocprofv3 --pmc runs of bench.py (FETCH_SIZE and WRITE_SIZE in separate
 passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes).
 
-    python scripts/traffic_from_pmc.py <fetch counter_collection.csv> <write counter_collection.csv> <round tag>
+    python scripts/traffic_from_pmc.py <fetch counter_collection.csv> <write counter_collection.csv> <round tag> [config]
+(config: cfg2 -> profiles/traffic.json, else profiles/traffic_<config>.json -- the files bench.py --config reads)
 
 gfx950 corrections (guide, section HBM): WRITE_SIZE is exact for 16-byte-per-lane streaming stores.  FETCH_SIZE
 tallies 128-byte requests at 64 bytes, so it is doubled for kernels whose wave-instructions read >= 128 contiguous
@@ -30,9 +31,11 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 LOGICAL = [
-    ("interpolate", ["k_cols_to_seg", "k_seg_strided<wf::F64, 0,", "k_seg_last<wf::F64, 0,", "k_seg_to_cols"]),
-    ("evaluate", ["k_seg_strided<wf::F64, 1,", "k_seg_last<wf::F64, 1,", "k_seg_last_hash<wf::F64,"]),
-    ("hash_rows", ["k_hash_rows"]),
+    ("interpolate", ["k_cols_to_seg", "k_seg_strided<wf::F64, 0,", "k_seg_last<wf::F64, 0,", "k_seg_strided<wf::F128, 0,",
+                     "k_seg_last<wf::F128, 0,", "k_seg_to_cols"]),
+    ("evaluate", ["k_seg_strided<wf::F64, 1,", "k_seg_last<wf::F64, 1,", "k_seg_last_hash<wf::F64,", "k_seg_strided<wf::F128, 1,",
+                  "k_seg_last<wf::F128, 1,", "k_seg_last_hash<wf::F128,"]),
+    ("hash_rows", ["k_hash_rows", "k_hash_chunks", "k_hash_merge_chunks"]),
     ("merkle", ["k_merkle_level", "k_merkle_subtree"])  # k_merkle_level also matches k_merkle_level2,
 ]
 NO_DOUBLE = ("k_seg_strided", "k_merkle_level2")
@@ -52,7 +55,8 @@ def main():
     fetch, fcalls = per_kernel(sys.argv[1], "FETCH_SIZE")
     write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
     steps = fcalls[next(k for k in fcalls if "k_cols_to_seg" in k)]  # one launch per commitment
-    out = {"_note": "HBM bytes per commitment (cfg 2) from rocprofv3 PMC; see scripts/traffic_from_pmc.py for the "
+    config = sys.argv[4] if len(sys.argv) > 4 else "cfg2"
+    out = {"_note": f"HBM bytes per commitment ({config}) from rocprofv3 PMC; see scripts/traffic_from_pmc.py for the "
                     "gfx950 corrections", "_round": sys.argv[3], "_steps_profiled": steps, "_csrc_sha": csrc_sha()}
     for name, pats in LOGICAL:
         rd = wr = 0.0
@@ -63,7 +67,7 @@ def main():
                 wr += write.get(k, 0.0) * 1024 / steps
         out[name] = {"read_bytes_per_step": rd, "write_bytes_per_step": wr, "hbm_bytes_per_step": rd + wr}
     out["path_total"] = sum(v["hbm_bytes_per_step"] for k, v in out.items() if not k.startswith("_"))
-    json.dump(out, open("profiles/traffic.json", "w"), indent=1)
+    json.dump(out, open("profiles/traffic.json" if config == "cfg2" else f"profiles/traffic_{config}.json", "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 

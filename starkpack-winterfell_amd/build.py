@@ -7,11 +7,16 @@ LIB = os.path.join(CSRC, "libwf_lde.so")
 
 
 def build(force: bool = False) -> str:
-    args = ["make", "-C", CSRC, "libwf_lde.so"]
+    args = ["make", "-C", CSRC, "libwf_lde.so", "libwf_yardstick.so"]
     if force:
         args.insert(1, "-B")
     subprocess.check_call(args, stdout=subprocess.DEVNULL)
     return LIB
+
+
+def yardstick_path() -> str:
+    """bench.py's measurement helper (isolated rates of the path's instruction sequences); not a product library."""
+    return os.path.join(CSRC, "libwf_yardstick.so")
 
 
 def lib_path() -> str:

@@ -63,3 +63,19 @@ def test_bench_line_contract(capi):
         assert k in j, k
     assert j["n_gpus"] == 1 and j["steps"] == 3 and j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
     assert j["roots_gathered"] == 3
+
+
+@pytest.mark.parametrize("config", ["cfg5", "dowork"])
+def test_bench_other_configs_print_the_same_line(capi, config):
+    """bench.py --config: the f128 workloads print the contract's line with in-run `alu` rates and pass their CPU-oracle
+    root gate (cfg3 -- 2^22 x 64 -- runs the same code at a size kept for the profiling scripts)."""
+    capi.load()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout + out.stderr
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["config"]["name"] == config and j["config"]["field"] == "f128"
+    assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
+    assert j["alu"]["yardstick_butterflies_per_s"] > 1e10 and 0 < j["alu"]["frac"] < 1.5
+    assert j["cpu_baseline"]["root_matches_gpu"] is True
+    assert set(j["cpu_baseline"]["phase_ms"]) == {"interpolate", "evaluate", "hash_rows", "merkle"}

@@ -458,3 +458,22 @@ def test_reference_literal_inputs_golden(orc):
     layer = orc.fri_layer_commit(orc.F128, ev, n, 1, folding)
     assert orc.f128_to_ints(layer["transposed"].reshape(-1, 2)) == [int(v) for r in f["transposed"] for v in r]
     assert G.hexrows(layer["leaves"]) == f["leaves"] and layer["root"].hex() == f["root"]
+
+
+def test_blake3_simd_compression_equals_the_scalar_definition(orc):
+    """oracle/blake3_ref.c computes one compression with the state's columns side by side in SSE vectors (the speed of the
+    `blake3` crate the reference links); the scalar transcription of the specification stays as its cross-check."""
+    rng = np.random.default_rng(2024)
+    for _ in range(500):
+        cv = rng.integers(0, 2**32, 8, dtype=np.uint32)
+        blk = rng.integers(0, 2**32, 16, dtype=np.uint32)
+        a, b = orc.blake3_compress_both(cv, blk, int(rng.integers(0, 2**63)), int(rng.integers(0, 65)), int(rng.integers(0, 16)))
+        assert np.array_equal(a, b)
+
+
+def test_phase_clock_of_the_commitment(orc):
+    rng = np.random.default_rng(1)
+    cols = [rng.integers(0, 2**62, size=1 << 10, dtype=np.uint64) for _ in range(4)]
+    orc.build_trace_commitment(1, [cols], 1, 10, 3, 7)
+    ph = orc.last_phase_ms()
+    assert len(ph) == 4 and all(x >= 0 for x in ph) and sum(ph) > 0
