@@ -1,13 +1,24 @@
 #!/bin/bash
 # Tuning aid: build variants of libwf_lde.so with experiment macros into build/exp_<name>/ and time cfg 2 with each
 # (run the timing part on the GPU box:  WF_LDE_LIB=build/exp_<name>/libwf_lde.so python scripts/time_config.py 1 1 20 3 8 1).
+#   scripts/exp_variants.sh [name "flags"]...   (default: the time-attribution set of DESIGN.md §4)
 set -e
 cd "$(dirname "$0")/.."
 build_variant() {  # name, extra flags
-    mkdir -p build/exp_$1
-    /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-function -Wno-pass-failed -ffp-contract=off \
-        $2 -shared -o build/exp_$1/libwf_lde.so starkpack-winterfell_amd/csrc/wf_lde.hip
+    rm -rf build/exp_$1
+    mkdir -p build/exp_$1/pkg
+    cp -r include build/exp_$1/include
+    cp -r starkpack-winterfell_amd/csrc build/exp_$1/pkg/csrc
+    rm -rf build/exp_$1/pkg/csrc/obj build/exp_$1/pkg/csrc/*.so
+    make -s -j8 -C build/exp_$1/pkg/csrc libwf_lde.so \
+        HIPFLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-function -Wno-pass-failed -ffp-contract=off $2"
+    cp build/exp_$1/pkg/csrc/libwf_lde.so build/exp_$1/libwf_lde.so
+    rm -rf build/exp_$1/pkg build/exp_$1/include
 }
+if [ $# -ge 2 ]; then
+    while [ $# -ge 2 ]; do build_variant "$1" "$2"; shift 2; done
+    exit 0
+fi
 build_variant skip_ntt "-DWF_EXP_SKIP_NTT"
 build_variant no_xcd "-DWF_EXP_NO_XCD_REMAP"
 build_variant skip_store "-DWF_EXP_SKIP_STORE"

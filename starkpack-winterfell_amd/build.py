@@ -7,7 +7,7 @@ LIB = os.path.join(CSRC, "libwf_lde.so")
 
 
 def build(force: bool = False) -> str:
-    args = ["make", "-C", CSRC, "libwf_lde.so", "libwf_yardstick.so"]
+    args = ["make", "-j8", "-C", CSRC, "libwf_lde.so", "libwf_yardstick.so"]
     if force:
         args.insert(1, "-B")
     subprocess.check_call(args, stdout=subprocess.DEVNULL)

@@ -25,32 +25,6 @@ namespace wf {
 #endif
 constexpr uint32_t DEEP_RUN_LOG = WF_DEEP_RUN_LOG, DEEP_RUN = 1u << DEEP_RUN_LOG, DEEP_BLOCK = 256 * DEEP_RUN;
 
-template <class F, int WE>
-__device__ __forceinline__ Ext<F, WE> ext_zero() {
-    Ext<F, WE> r;
-#pragma unroll
-    for (int w = 0; w < WE; w++) r.c[w] = F::zero();
-    return r;
-}
-template <class F, int WE>
-__device__ __forceinline__ Ext<F, WE> ext_add(Ext<F, WE> a, const Ext<F, WE> &b) {
-#pragma unroll
-    for (int w = 0; w < WE; w++) a.c[w] = F::add(a.c[w], b.c[w]);
-    return a;
-}
-template <class F, int WE>
-__device__ __forceinline__ Ext<F, WE> ext_load(const typename F::T *p) {
-    Ext<F, WE> r;
-#pragma unroll
-    for (int w = 0; w < WE; w++) r.c[w] = p[w];
-    return r;
-}
-template <class F, int WE>
-__device__ __forceinline__ void ext_store(typename F::T *p, const Ext<F, WE> &v) {
-#pragma unroll
-    for (int w = 0; w < WE; w++) p[w] = v.c[w];
-}
-
 // The column table, sorted by the host (a sum does not care about the order): base-field trace columns, then trace
 // columns over E, then the constraint composition columns (over E); coeffs[] follows the same order.
 struct DeepTable {

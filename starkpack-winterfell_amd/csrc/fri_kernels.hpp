@@ -20,6 +20,32 @@ struct Ext {
     T c[W];
 };
 
+template <class F, int WE>
+__device__ __forceinline__ Ext<F, WE> ext_zero() {
+    Ext<F, WE> r;
+#pragma unroll
+    for (int w = 0; w < WE; w++) r.c[w] = F::zero();
+    return r;
+}
+template <class F, int WE>
+__device__ __forceinline__ Ext<F, WE> ext_add(Ext<F, WE> a, const Ext<F, WE> &b) {
+#pragma unroll
+    for (int w = 0; w < WE; w++) a.c[w] = F::add(a.c[w], b.c[w]);
+    return a;
+}
+template <class F, int WE>
+__device__ __forceinline__ Ext<F, WE> ext_load(const typename F::T *p) {
+    Ext<F, WE> r;
+#pragma unroll
+    for (int w = 0; w < WE; w++) r.c[w] = p[w];
+    return r;
+}
+template <class F, int WE>
+__device__ __forceinline__ void ext_store(typename F::T *p, const Ext<F, WE> &v) {
+#pragma unroll
+    for (int w = 0; w < WE; w++) p[w] = v.c[w];
+}
+
 template <class F, int W>
 __host__ __device__ __forceinline__ Ext<F, W> ext_mul(const Ext<F, W> &a, const Ext<F, W> &b) {
     typedef typename F::T T;

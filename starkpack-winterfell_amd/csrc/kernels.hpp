@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(1024) k_ntt_last(NttArgs<F> a) {
 
 // Zero fill (n 16-byte words) -- a kernel rather than hipMemsetAsync: memset nodes of a captured graph were seen to
 // replay wrongly on this ROCm (tests/test_gpu_graph.py), kernels replay as launched.
-__global__ void __launch_bounds__(256) k_zero16(uint4 *__restrict__ dst, uint64_t n) {
+static __global__ void __launch_bounds__(256) k_zero16(uint4 *__restrict__ dst, uint64_t n) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = make_uint4(0, 0, 0, 0);
 }
@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(256) k_hash_chunks(HashArgs<F> a, uint32_t chu
     dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
 }
 
-__global__ void __launch_bounds__(256) k_hash_merge_chunks(const uint32_t *__restrict__ cvs, uint32_t chunks_per_row,
+static __global__ void __launch_bounds__(256) k_hash_merge_chunks(const uint32_t *__restrict__ cvs, uint32_t chunks_per_row,
                                                            uint64_t n_rows, uint32_t *__restrict__ leaves) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_rows) return;
@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(256) k_hash_merge_chunks(const uint32_t *__res
 // by level in place -- adjacent pairs, an odd last one carried up, which is BLAKE3's left-full tree.  One lane per row
 // (above) leaves the chip idle when there are few long rows: 8192 rows of 80 chunks are 79 dependent compressions on 128
 // waves.  Dynamic LDS: 16 * n * 32 bytes (the launcher uses this kernel for n <= 128).
-__global__ void __launch_bounds__(256) k_hash_merge_chunks_par(const uint32_t *__restrict__ cvs, uint32_t n, uint64_t n_rows,
+static __global__ void __launch_bounds__(256) k_hash_merge_chunks_par(const uint32_t *__restrict__ cvs, uint32_t n, uint64_t n_rows,
                                                                uint32_t *__restrict__ leaves) {
     extern __shared__ __attribute__((aligned(16))) unsigned char merge_smem[];
     const uint32_t lane = threadIdx.x & 15, r = threadIdx.x >> 4;
@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(256) k_hash_merge_chunks_par(const uint32_t *_
 // through up to `levels` levels, keeping the intermediate digests in LDS and writing every level to `nodes`.
 // children: digests of the level below (n_children of them); the parents level has n_children/2 nodes stored at
 // nodes[n_children/2 .. n_children).
-__global__ void __launch_bounds__(256) k_merkle_subtree(const uint32_t *__restrict__ children,
+static __global__ void __launch_bounds__(256) k_merkle_subtree(const uint32_t *__restrict__ children,
                                                         uint32_t *__restrict__ nodes, uint64_t n_children,
                                                         uint32_t levels) {
     __shared__ uint32_t sh[256 * 8];
@@ -558,7 +558,7 @@ __global__ void __launch_bounds__(256) k_merkle_subtree(const uint32_t *__restri
 }
 
 // One Merkle level per launch (used while a level still fills the chip): parents[i] = merge(children[2i], children[2i+1]).
-__global__ void __launch_bounds__(256) k_merkle_level(const uint32_t *__restrict__ children,
+static __global__ void __launch_bounds__(256) k_merkle_level(const uint32_t *__restrict__ children,
                                                       uint32_t *__restrict__ parents, uint64_t n_parents) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_parents) return;
@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(256) k_gather_rows(const typename F::T *__rest
 }
 
 // gather 32-byte digests: src id = index < n_leaves ? leaves[index] : nodes[index - n_leaves]
-__global__ void __launch_bounds__(256) k_gather_digests(const uint4 *__restrict__ leaves, const uint4 *__restrict__ nodes,
+static __global__ void __launch_bounds__(256) k_gather_digests(const uint4 *__restrict__ leaves, const uint4 *__restrict__ nodes,
                                                         uint64_t n_leaves, const uint64_t *__restrict__ ids,
                                                         uint32_t n, uint4 *__restrict__ out) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -605,7 +605,7 @@ __global__ void __launch_bounds__(256) k_gather_digests(const uint4 *__restrict_
 #define WF_EXP_MERKLE_WAVES 6
 #endif
 __attribute__((amdgpu_waves_per_eu(WF_EXP_MERKLE_WAVES, WF_EXP_MERKLE_WAVES)))
-__global__ void __launch_bounds__(256) k_merkle_level2(const uint32_t *__restrict__ children,
+static __global__ void __launch_bounds__(256) k_merkle_level2(const uint32_t *__restrict__ children,
                                                        uint32_t *__restrict__ parents,
                                                        uint32_t *__restrict__ grandparents, uint64_t n_grand) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_grand; i += (uint64_t)gridDim.x * blockDim.x) {

@@ -1,4 +1,4 @@
-"""Multi-GPU layout of the path -- a thin caller of the wf_comm part of the C ABI (include/wf_lde.h, csrc/comm.hpp).
+"""Multi-GPU layout of the path -- a thin caller of the wf_comm part of the C ABI (include/wf_lde.h, csrc/comm.hip).
 
 The reference has no distributed code ("Distributed communication backend: none").  One process per
 GPU; the partition rules (wf_shard_*), the exchanges (RCCL inside libwf_lde.so) and the kernels around them all

@@ -140,3 +140,34 @@ def test_handles_destroyed_after_their_context_do_not_touch_it(orc, capi):
     want = orc.build_trace_commitment(F64, [cols], 1, 9, 2, 7)
     assert c2.trace_commit(params, cols)["root"] == want["root"]
     c2.close()
+
+
+def test_failed_pipelined_upload_drains_its_streams_and_leaves_the_context_usable(orc, capi):
+    """The pipelined upload of a multi-segment trace (trace_commit_pipelined) fails part-way -- WF_EXP_FAIL_AFTER_SEGMENT, a
+    switch the library reads once at wf_ctx_create -- with copies of the caller's columns and kernels already queued.  The
+    call must come back with the error AFTER both streams have drained (the columns may be freed at once), release what
+    it allocated, and leave the context serving other shapes."""
+    import os
+    from conftest import rand_cols
+    os.environ["WF_EXP_FAIL_AFTER_SEGMENT"] = "2"
+    os.environ["WF_EXP_PIPELINE_MIN_BYTES"] = "0"
+    try:
+        ctx = capi.Context(0)
+    finally:
+        del os.environ["WF_EXP_FAIL_AFTER_SEGMENT"], os.environ["WF_EXP_PIPELINE_MIN_BYTES"]
+    rng = np.random.default_rng(9)
+    wide = capi.make_params(1, 1, 12, 3, 40, 1)      # five segments, two passes: the pipelined route
+    cols = rand_cols(rng, 1, 40, 1 << 12)
+    for _ in range(3):
+        with pytest.raises(capi.WfError) as e:
+            ctx.trace_commit_resident(wide, cols)
+        assert e.value.code == -30 and "injected failure" in str(e.value)
+        cols = rand_cols(rng, 1, 40, 1 << 12)          # the old columns are garbage-collected while nothing may still read them
+    # other routes of the same context are untouched: one segment (not pipelined), and the host-buffer form of the wide shape
+    narrow = capi.make_params(1, 1, 12, 3, 8, 1)
+    com, _ = ctx.trace_commit_resident(narrow, cols[:8])
+    assert com.root() == orc.build_trace_commitment(1, [cols[:8]], 1, 12, 3, 7)["root"]
+    com.close()
+    got = ctx.trace_commit(wide, cols)
+    assert got["root"] == orc.build_trace_commitment(1, [cols], 1, 12, 3, 7)["root"]
+    ctx.close()

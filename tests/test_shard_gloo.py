@@ -49,7 +49,7 @@ def _init(rank, world, port):
 
 
 def interleave(recv: np.ndarray, n_k: int, world: int, per: int) -> np.ndarray:
-    """numpy restatement of k_interleave_leaves (csrc/comm.hpp): src[s][k][lc] -> dst[k][s * per + lc]."""
+    """numpy restatement of k_interleave_leaves (csrc/comm.hip): src[s][k][lc] -> dst[k][s * per + lc]."""
     return recv.reshape(world, n_k, per, 32).transpose(1, 0, 2, 3).reshape(n_k * world * per, 32)
 
 
