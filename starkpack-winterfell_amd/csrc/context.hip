@@ -34,6 +34,7 @@ wf_tuning tuning_from_env() {
         if (v >= 10 && v <= 30) t.merkle_l2_min = (uint32_t)v;
     }
     t.no_pipeline = getenv("WF_EXP_NO_PIPELINE") != nullptr;
+    t.single_fused = getenv("WF_EXP_SINGLE_FUSED") != nullptr;
     if (const char *e = getenv("WF_EXP_PIPELINE_MIN_BYTES")) t.pipeline_min_bytes = (size_t)atoll(e);
     if (const char *e = getenv("WF_EXP_FAIL_AFTER_SEGMENT")) t.fail_after_segment = atoi(e);
     return t;
@@ -319,6 +320,7 @@ void wf_ctx_destroy(wf_ctx *ctx) {
         if (b.p) (void)hipFree(b.p);
     if (ctx->hash_tmp.p) (void)hipFree(ctx->hash_tmp.p);
     if (ctx->tickets.p) (void)hipFree(ctx->tickets.p);
+    if (ctx->chain_flags.p) (void)hipFree(ctx->chain_flags.p);
     for (auto &b : ctx->pool) (void)hipFree(b.first);
     for (hipEvent_t e : ctx->seg_events) (void)hipEventDestroy(e);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
@@ -350,7 +352,7 @@ int wf_ctx_release_cached(wf_ctx *ctx) {
 int wf_ctx_synchronize(wf_ctx *ctx) {
     if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return 0;
+    return path_device_error(ctx);
 }
 
 void *wf_ctx_stream(wf_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }

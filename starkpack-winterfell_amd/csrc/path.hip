@@ -188,6 +188,15 @@ static int seg_launch_dims(uint32_t logD, uint32_t &threads, size_t &lds, bool l
 
 static void launch_merge_chunks(hipStream_t st, const void *cvs, uint32_t n_chunks, uint64_t n_rows, void *leaves);
 
+// per-XCD ticket / exit counters of the persistent kernels + their error word; zeroed once (the kernels leave them at zero)
+static int ensure_tickets(wf_ctx *ctx, hipStream_t st) {
+    if (ctx->tickets.p) return 0;
+    int rc = ensure(ctx, ctx->tickets, 128);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->tickets.p, 0, 128, st));  // ordered on the launch stream (first use only)
+    return 0;
+}
+
 // Coset packing of narrow evaluations (<= S/2 base columns in one segment, an even number of cosets): 2^cpr cosets of
 // 2^lg lanes each share the lanes of a row.
 template <class F>
@@ -396,6 +405,41 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         a.leaves = fuse ? (uint32_t *)d.leaves : nullptr;
         a.hash_epr = d.hash_epr;
         if (d.fused) *d.fused = fuse;
+        // single pass, rows of several BLAKE3 chunks (many packed traces of few steps: the reference's own example): every
+        // tile its own ticket, chunk chaining values handed from work-group to work-group (k_seg_single_hash).  OPT-IN
+        // (wf_tuning::single_fused): bit-exact, but measured SLOWER than the separate chunk kernels on the shape it was
+        // built for (512 x 2^10 x 10 f128: 1.63 ms against 0.76 + 0.38 ms; DESIGN.md §9 has the breakdown)
+        const uint64_t resident_single = (uint64_t)ctx->num_cus * std::max<size_t>(1, (160 * 1024) / lds);
+        const bool single_fused = single && may_fuse && chunked && threads * 2 == (1u << a.logD) && threads <= 512 &&
+                                  (uint64_t)d.n_cosets * d.n_seg >= 2 * resident_single && launch_rows * n_chunks * 32 < (1ull << 40) &&
+                                  (uint64_t)d.n_cosets * n_chunks * 16 < (1ull << 28) && ctx->tune.single_fused;
+        if (single_fused) {
+            a.leaves = (uint32_t *)d.leaves;
+            a.hash_epr = d.hash_epr;
+            if (d.fused) *d.fused = true;
+            prof_mark(ctx, st, tag_l);
+            int rcs = ensure(ctx, ctx->hash_tmp, (size_t)launch_rows * n_chunks * 32);
+            if (rcs) return rcs;
+            if ((rcs = ensure_tickets(ctx, st))) return rcs;
+            const size_t flag_bytes = (size_t)d.n_cosets * n_chunks * 16 * 4;
+            if (flag_bytes > ctx->chain_flags.cap || ctx->chain_epoch == 0xFFFFFFFFu) {  // new (or exhausted) flags start at zero
+                if ((rcs = ensure(ctx, ctx->chain_flags, flag_bytes))) return rcs;
+                HIP_TRY(hipMemsetAsync(ctx->chain_flags.p, 0, ctx->chain_flags.cap, st));
+                ctx->chain_epoch = 0;
+            }
+            a.chunk_cvs = (uint32_t *)ctx->hash_tmp.p;
+            a.n_chunks = n_chunks;
+            a.tile_counters = (uint32_t *)ctx->tickets.p;
+            a.chain_flags = (uint32_t *)ctx->chain_flags.p;
+            a.chain_epoch = ++ctx->chain_epoch;
+            const void *kern = a.pad_traces ? (const void *)k_seg_single_hash<F, true> : (const void *)k_seg_single_hash<F, false>;
+            if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            void *kargs[] = {&a};
+            HIP_TRY(hipLaunchKernel(kern, dim3((uint32_t)std::min<uint64_t>((uint64_t)d.n_cosets * d.n_seg, resident_single)), dim3(threads), kargs, lds, st));
+            launch_merge_chunks(st, ctx->hash_tmp.p, n_chunks, launch_rows, d.leaves);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
         prof_mark(ctx, st, tag_l);
         if (persistent) {
             const bool multi = d.n_seg > 1 || d.total_base_cols != d.base_cols;
@@ -415,11 +459,8 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             const size_t lds_p = lds;  // (the two ticket words live in the unused last twiddle slot)
             const uint64_t resident = (uint64_t)ctx->num_cus * std::max<size_t>(1, (160 * 1024) / lds_p);
-            if (!ctx->tickets.p) {  // zeroed once: the kernel leaves its counters at zero
-                int rcq = ensure(ctx, ctx->tickets, 64);
-                if (rcq) return rcq;
-                HIP_TRY(hipMemsetAsync(ctx->tickets.p, 0, 64, st));  // ordered on the launch stream (first use only)
-            }
+            int rcq = ensure_tickets(ctx, st);
+            if (rcq) return rcq;
             a.tile_counters = (uint32_t *)ctx->tickets.p;
 #ifdef WF_EXP_STAMPS
             a.stamps = exp_stamps_buffer();
@@ -522,7 +563,10 @@ static int run_merkle(wf_ctx *ctx, hipStream_t st, const void *leaves, uint64_t 
         const uint32_t l2_min = ctx->tune.merkle_l2_min;
         if (n_par >= ((uint64_t)1 << l2_min)) {  // two levels that still fill the chip: one lane per grandparent
             const uint64_t n_grand = n_par >> 1;
-            const uint64_t blocks2 = std::min<uint64_t>((n_grand + threads - 1) / threads, 256 * 8);  // grid-stride
+#ifndef WF_EXP_MERKLE_GRID_WAVES
+#define WF_EXP_MERKLE_GRID_WAVES 8
+#endif
+            const uint64_t blocks2 = std::min<uint64_t>((n_grand + threads - 1) / threads, (uint64_t)ctx->num_cus * WF_EXP_MERKLE_GRID_WAVES);  // grid-stride
             hipLaunchKernelGGL(k_merkle_level2, dim3((uint32_t)blocks2), dim3(threads), 0, st,
                                children, (uint32_t *)nodes + n_par * 8, (uint32_t *)nodes + n_grand * 8, n_grand);
             HIP_TRY(hipGetLastError());
@@ -1281,6 +1325,15 @@ int path_hash_rows(wf_ctx *ctx, hipStream_t st, uint32_t field, const void *lde,
 
 int path_merkle(wf_ctx *ctx, hipStream_t st, const void *leaves, uint64_t n_leaves, void *nodes) {
     return run_merkle(ctx, st, leaves, n_leaves, nodes);
+}
+
+int path_device_error(wf_ctx *ctx) {
+    if (!ctx->tickets.p) return 0;
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpy(&err, (const char *)ctx->tickets.p + 64, 4, hipMemcpyDeviceToHost));
+    if (!err) return 0;
+    (void)hipMemset((char *)ctx->tickets.p + 64, 0, 4);
+    return fail(WF_ERR_HIP, "a persistent kernel gave up waiting for the chaining values of a preceding block (internal error)");
 }
 
 int path_trace_commit_sharded(wf_comm *c, const wf_params *p, const void *d_trace, void *d_polys, void *d_lde_shard,

@@ -132,6 +132,10 @@ static int commit_resident(wf_ctx *ctx, const wf_params *p, bool constraint, con
         free_commitment(c);
         return fail(WF_ERR_HIP, "commitment failed: %s", hipGetErrorString(e));
     }
+    if ((rc = path_device_error(ctx))) {
+        free_commitment(c);
+        return rc;
+    }
     *out = c;
     return 0;
 }

@@ -63,6 +63,7 @@ struct wf_tuning {
     uint32_t merkle_l2_min = 18;      // WF_EXP_MERKLE_L2_MIN: log2 of the narrowest level the two-level launches take
     bool no_pipeline = false;         // WF_EXP_NO_PIPELINE: host columns uploaded in front of the kernels, never under them
     size_t pipeline_min_bytes = (size_t)1 << 20;  // WF_EXP_PIPELINE_MIN_BYTES
+    bool single_fused = false;        // WF_EXP_SINGLE_FUSED: single-pass long rows hashed inside the pass (k_seg_single_hash: measured slower, off)
     int fail_after_segment = -1;      // WF_EXP_FAIL_AFTER_SEGMENT: the pipelined upload fails after that many segments (error-path test)
 };
 wf_tuning tuning_from_env();
@@ -84,7 +85,9 @@ struct wf_ctx {
     DevBuf scratch;   // evaluation intermediate [cosets][columns][R]
     DevBuf io[5];     // staging for the host-buffer API: trace, polys, lde, leaves, nodes
     DevBuf hash_tmp;  // chunk chaining values of rows longer than one BLAKE3 chunk
-    DevBuf tickets;   // per-XCD tile counters of the persistent last pass
+    DevBuf tickets;   // per-XCD tile counters of the persistent last passes (+ word 16: their error flag)
+    DevBuf chain_flags;  // k_seg_single_hash: per (coset, chunk, block) publication flags, compared with chain_epoch
+    uint32_t chain_epoch = 0;
     // Buffers of destroyed resident commitments, kept for the next commitment of the same shape (four hipFree + four
     // hipMalloc of 64..512 MiB cost about as much as the commitment itself); released by wf_ctx_release_cached / destroy.
     // Guarded by pool_mutex: a handle may be destroyed by another thread (a finaliser, Rust's Drop) while a call runs.
@@ -220,6 +223,9 @@ bool path_dense_matrix_ok(const wf_params *p);
 int path_hash_rows(wf_ctx *ctx, hipStream_t st, uint32_t field, const void *lde, uint64_t trace_elems, uint64_t n_rows,
                    uint32_t row_width, uint32_t epr, uint32_t n_traces, void *leaves);
 int path_merkle(wf_ctx *ctx, hipStream_t st, const void *leaves, uint64_t n_leaves, void *nodes);
+// after a synchronisation: WF_ERR_HIP if a persistent kernel of this context flagged a chaining time-out (cannot happen
+// while the whole grid is resident; the flag exists so that a wrong assumption shows up as an error, not as wrong leaves)
+int path_device_error(wf_ctx *ctx);
 // one packed commitment sharded over the ranks of a communicator (segment-sharded interpolation, coset-sharded evaluation)
 int path_trace_commit_sharded(wf_comm *c, const wf_params *p, const void *d_trace, void *d_polys, void *d_lde_shard,
                               void *d_leaves, void *d_nodes, void *d_top, hipStream_t st);
