@@ -1,8 +1,9 @@
 """GPU: single-pass evaluations whose combined rows are longer than one BLAKE3 chunk -- many packed traces of few steps,
 the reference's own example at its defaults (examples/src/lib.rs:97-135: 512 do_work traces of 2^10 steps, 80-chunk rows).
-These shapes hash their leaves inside the evaluation pass with the chunk chaining values handed from work-group to
-work-group through memory (k_seg_single_hash): every leaf, node and LDE row against the oracle, both ways of covering the
-(coset, chunk) pairs over the XCDs, both fields, ragged last chunks, and the same commitment with the fusion switched off."""
+Default route: plain evaluation pass + the chunk hashing kernels.  Opt-in route (WF_EXP_SINGLE_FUSED, read at wf_ctx_create):
+leaves hashed inside the evaluation pass with the chunk chaining values handed from work-group to work-group through memory
+(k_seg_single_hash -- bit-exact but measured slower): every leaf, node and LDE row against the oracle both
+ways, both ways of dealing the (coset, chunk) pairs to the XCDs, both fields, ragged last chunks."""
 import os
 
 import numpy as np
@@ -24,7 +25,11 @@ SHAPES = [
 
 @pytest.mark.parametrize("field,logR,logB,n_cols,n_traces", SHAPES)
 def test_single_pass_long_rows(orc, capi, field, logR, logB, n_cols, n_traces):
-    ctx = capi.Context(0)
+    os.environ["WF_EXP_SINGLE_FUSED"] = "1"
+    try:
+        ctx = capi.Context(0)
+    finally:
+        del os.environ["WF_EXP_SINGLE_FUSED"]
     rng = np.random.default_rng(logR * 1000 + n_cols * 10 + n_traces)
     R = 1 << logR
     traces = [rand_cols(rng, field, n_cols, R) for _ in range(n_traces)]
@@ -43,11 +48,7 @@ def test_single_pass_long_rows(orc, capi, field, logR, logB, n_cols, n_traces):
     assert com.root() == want["root"]
     com.close()
     ctx.close()
-    os.environ["WF_EXP_NO_SINGLE_FUSED"] = "1"
-    try:
-        plain = capi.Context(0)
-    finally:
-        del os.environ["WF_EXP_NO_SINGLE_FUSED"]
+    plain = capi.Context(0)  # the default route
     got2 = plain.trace_commit(params, cols, want_lde=False, want_polys=False)
     assert got2["root"] == want["root"] and np.array_equal(got2["leaves"], want["leaves"])
     plain.close()
