@@ -64,7 +64,12 @@ typedef struct wf_params {
     uint32_t log2_blowup;    /* log2 of StarkDomain::trace_to_lde_blowup() */
     uint32_t n_cols;         /* columns of E per trace (ColMatrix::num_cols) */
     uint32_t n_traces;       /* STARKPack: traces committed under one tree (>= 1) */
-    uint32_t digest_bytes;   /* 32 (Blake3_256) */
+    uint32_t digest_bytes;   /* the hasher: 32 = Blake3_256 (crypto/src/hash/blake/mod.rs:20-59), 24 = Blake3_192 (:68-114: the same
+                              * BLAKE3 output truncated to 24 bytes, merge = hash of the 48 bytes of two digests).  HOST arrays
+                              * of digests (leaves_out, nodes_out, query outputs) hold digest_bytes per entry, like the
+                              * reference's Vec<ByteDigest<N>>; DEVICE arrays (d_leaves, d_nodes of the *_dev forms, resident
+                              * handles) are always 32-byte slots with the digest in front and zeros behind; root_out[32]
+                              * is the digest zero-padded (Digest::as_bytes, crypto/src/hash/mod.rs:107-113) */
     uint32_t reserved;       /* must be 0 */
     uint8_t domain_offset[16]; /* StarkDomain::offset() as a canonical little-endian integer (7 for f64, 3 for f128) */
 } wf_params;
@@ -87,6 +92,10 @@ void wf_ctx_destroy(wf_ctx *ctx);
 /* A context parks the device buffers of destroyed resident commitments (up to 16) for the next commitment of the same
  * shape -- a prover producing proof after proof allocates once.  This returns them to the driver. */
 int wf_ctx_release_cached(wf_ctx *ctx);
+/* The hasher of the entry points that take no wf_params -- wf_hash_rows, wf_merkle_build, wf_merkle_build_dev and the FRI
+ * functions (the reference's `H: ElementHasher` type parameter, one per Prover): 32 = Blake3_256 (default), 24 =
+ * Blake3_192.  Layout rules as for wf_params::digest_bytes. */
+int wf_ctx_set_digest_bytes(wf_ctx *ctx, uint32_t digest_bytes);
 /* Diagnostic (needs no device): the digit passes the commitment path uses for a transform of 2^log2_n rows over
  * n_segments segments (a segment = 8 f64 / 4 f128 base columns); returns the number of passes (<= 4), digits_out[i] =
  * log2 of the tile rows of pass i (the last one is the pass that writes the row-major LDE), or a negative status. */

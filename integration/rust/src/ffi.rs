@@ -155,6 +155,12 @@ extern "C" {
     pub fn wf_comm_all_gather_roots(
         comm: *mut WfComm, d_roots: *const c_void, n_roots: usize, d_all: *mut c_void, stream: *mut c_void,
     ) -> c_int;
+    pub fn wf_ctx_set_digest_bytes(ctx: *mut WfCtx, digest_bytes: u32) -> c_int;
+    /// A stream of proofs: returns once the columns are on their way; `wf_commitment_wait` (or `wf_commitment_root`) completes it.
+    pub fn wf_trace_commit_resident_async(
+        ctx: *mut WfCtx, p: *const WfParams, trace_cols: *const *const c_void, out: *mut *mut WfCommitment,
+    ) -> c_int;
+    pub fn wf_commitment_wait(c: *mut WfCommitment) -> c_int;
     pub fn wf_comm_barrier(comm: *mut WfComm) -> c_int;
     /// Blocking wait on `stream` under the communicator's watchdog (WF_COMM_TIMEOUT_S): WF_ERR_COMM instead of a hang.
     pub fn wf_comm_stream_wait(comm: *mut WfComm, stream: *mut c_void) -> c_int;

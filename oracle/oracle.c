@@ -155,9 +155,24 @@ void orc_f128_get_root_of_unity(uint32_t n, void *out) {
 /* Blake3_256::hash_elements, crypto/src/hash/blake/mod.rs:46-59.
  * f128 (IS_CANONICAL): raw element bytes.  f64: every element's canonical as_int() as 8 LE bytes
  * (f64/mod.rs:605-610 via utils/core/src/serde/mod.rs:38-42,82-86; no length prefix). */
-void orc_hash_elements(int field, const void *elems, size_t n_base, uint8_t out[32]) {
+/* Digest size of the hasher: 32 = Blake3_256 (blake/mod.rs:20-59), 24 = Blake3_192 (blake/mod.rs:68-114: the same BLAKE3
+ * output truncated to its first 24 bytes; merge hashes the 48 bytes of two digests; leaves / nodes are arrays of
+ * ByteDigest<24>, 24 bytes apart).  Process-wide setting of the checker (tests select it around a call). */
+static size_t g_db = 32;
+int orc_set_digest_bytes(int db) {
+    if (db != 24 && db != 32) return -1;
+    g_db = (size_t)db;
+    return 0;
+}
+static void hash_trunc(const uint8_t *in, size_t len, uint8_t *out) {
+    uint8_t full[32];
+    orc_blake3_hash(in, len, full);
+    memcpy(out, full, g_db);
+}
+
+void orc_hash_elements(int field, const void *elems, size_t n_base, uint8_t *out) {
     if (field == ORC_FIELD_F128) {
-        orc_blake3_hash((const uint8_t *)elems, n_base * 16, out);
+        hash_trunc((const uint8_t *)elems, n_base * 16, out);
         return;
     }
     const uint64_t *e = (const uint64_t *)elems;
@@ -167,24 +182,24 @@ void orc_hash_elements(int field, const void *elems, size_t n_base, uint8_t out[
         uint64_t v = f64_as_int(e[i]);
         for (int b = 0; b < 8; b++) buf[8 * i + b] = (uint8_t)(v >> (8 * b));
     }
-    orc_blake3_hash(buf, n_base * 8, out);
+    hash_trunc(buf, n_base * 8, out);
     if (buf != stackbuf) free(buf);
 }
 
 /* Blake3_256::merge, blake/mod.rs:31-33 */
-void orc_merge(const uint8_t left[32], const uint8_t right[32], uint8_t out[32]) {
+void orc_merge(const uint8_t *left, const uint8_t *right, uint8_t *out) {
     uint8_t buf[64];
-    memcpy(buf, left, 32);
-    memcpy(buf + 32, right, 32);
-    orc_blake3_hash(buf, 64, out);
+    memcpy(buf, left, g_db);
+    memcpy(buf + g_db, right, g_db);
+    hash_trunc(buf, 2 * g_db, out);
 }
 
 /* Blake3_256::merge_with_int, blake/mod.rs:35-40 */
-void orc_merge_with_int(const uint8_t seed[32], uint64_t value, uint8_t out[32]) {
+void orc_merge_with_int(const uint8_t *seed, uint64_t value, uint8_t *out) {
     uint8_t buf[40];
-    memcpy(buf, seed, 32);
-    for (int b = 0; b < 8; b++) buf[32 + b] = (uint8_t)(value >> (8 * b));
-    orc_blake3_hash(buf, 40, out);
+    memcpy(buf, seed, g_db);
+    for (int b = 0; b < 8; b++) buf[g_db + b] = (uint8_t)(value >> (8 * b));
+    hash_trunc(buf, g_db + 8, out);
 }
 
 /* build_merkle_nodes, crypto/src/merkle/mod.rs:350-374 (threads<=1) and merkle/concurrent.rs:21-70 (threads>1).
@@ -193,13 +208,14 @@ int orc_build_merkle_nodes(const uint8_t *leaves, size_t n_leaves, uint8_t *node
     if (n_leaves < 2) return -1;                    /* merkle/mod.rs:118-120 */
     if (n_leaves & (n_leaves - 1)) return -2;       /* :121-123 */
     size_t n = n_leaves / 2;
-    memset(nodes, 0, 32);
+    const size_t db = g_db; /* two adjacent digests ARE the merge input (merkle/mod.rs:350-374: merge(&[l, r])) */
+    memset(nodes, 0, db);
 #pragma omp parallel for num_threads(threads) schedule(static) if (threads > 1 && n > 512)
-    for (size_t i = 0; i < n; i++) orc_blake3_hash(leaves + 64 * i, 64, nodes + 32 * (n + i));
+    for (size_t i = 0; i < n; i++) hash_trunc(leaves + 2 * db * i, 2 * db, nodes + db * (n + i));
     /* levels above: level with first index `lo` has `lo` nodes; children are already final */
     for (size_t lo = n / 2; lo >= 1; lo /= 2) {
 #pragma omp parallel for num_threads(threads) schedule(static) if (threads > 1 && lo > 512)
-        for (size_t i = lo; i < 2 * lo; i++) orc_blake3_hash(nodes + 64 * i, 64, nodes + 32 * i);
+        for (size_t i = lo; i < 2 * lo; i++) hash_trunc(nodes + 2 * db * i, 2 * db, nodes + db * i);
     }
     return 0;
 }
@@ -229,7 +245,7 @@ int orc_commit_to_comb_rows(int field, const void *const *lde, size_t n_traces, 
             for (size_t t = 0; t < n_traces; t++)
                 memcpy(comb + t * elements_per_row * eb, (const uint8_t *)lde[t] + i * row_width * eb,
                        elements_per_row * eb);
-            orc_hash_elements(field, comb, n_traces * elements_per_row, leaves + 32 * i);
+            orc_hash_elements(field, comb, n_traces * elements_per_row, leaves + g_db * i);
         }
         free(comb);
     }

@@ -66,9 +66,12 @@ int orc_f128_evaluate_polys_over_p(const void *const *polys, size_t n_cols, size
                                    const void *off, void *out, int threads);
 
 /* --- crypto::hash::Blake3_256 and crypto::merkle */
-void orc_hash_elements(int field, const void *elems, size_t n_base, uint8_t out[32]);
-void orc_merge(const uint8_t left[32], const uint8_t right[32], uint8_t out[32]);
-void orc_merge_with_int(const uint8_t seed[32], uint64_t value, uint8_t out[32]);
+/* digest size of every hashing function below: 32 (Blake3_256, default) or 24 (Blake3_192); outputs and the leaf / node
+ * arrays hold digests of that many bytes, that many bytes apart */
+int orc_set_digest_bytes(int digest_bytes);
+void orc_hash_elements(int field, const void *elems, size_t n_base, uint8_t *out);
+void orc_merge(const uint8_t *left, const uint8_t *right, uint8_t *out);
+void orc_merge_with_int(const uint8_t *seed, uint64_t value, uint8_t *out);
 int orc_build_merkle_nodes(const uint8_t *leaves, size_t n_leaves, uint8_t *nodes, int threads);
 int orc_commit_to_comb_rows(int field, const void *const *lde, size_t n_traces, size_t n_rows, size_t row_width,
                             size_t elements_per_row, uint8_t *leaves, uint8_t *nodes, int threads);

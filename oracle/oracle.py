@@ -66,6 +66,7 @@ def lib():
         L.orc_f128_evaluate_poly_with_offset_p.argtypes = [vp, sz, sz, vp, vp, sz, vp]
         L.orc_f128_interpolate_poly_with_offset_p.argtypes = [vp, sz, sz, vp, vp]
         L.orc_f128_evaluate_polys_over_p.argtypes = [vp, sz, sz, sz, sz, vp, vp, i32]
+        L.orc_set_digest_bytes.argtypes = [i32]
         L.orc_hash_elements.argtypes = [i32, vp, sz, vp]
         L.orc_merge.argtypes = [vp, vp, vp]
         L.orc_merge_with_int.argtypes = [vp, u64, vp]
@@ -220,27 +221,49 @@ def blake3(data: bytes) -> bytes:
     return bytes(out)
 
 
+class digest_size:
+    """`with digest_size(24):` -- the hashing functions below act as Blake3_192 (crypto/src/hash/blake/mod.rs:68-114)
+    inside the block: 24-byte digests, 48-byte merge inputs, leaf / node arrays of 24-byte entries.  Default 32."""
+
+    def __init__(self, n: int):
+        self.n = n
+
+    def __enter__(self):
+        if lib().orc_set_digest_bytes(self.n):
+            raise ValueError("digest size must be 24 or 32")
+        global _DB
+        self.prev, _DB = _DB, self.n
+
+    def __exit__(self, *a):
+        global _DB
+        _DB = self.prev
+        lib().orc_set_digest_bytes(self.prev)
+
+
+_DB = 32
+
+
 def hash_elements(field: int, elems: np.ndarray) -> bytes:
     out = (C.c_uint8 * 32)()
     e = np.ascontiguousarray(elems, dtype=np.uint64)
     lib().orc_hash_elements(field, _p(e), e.size // ELEM_WORDS[field], out)
-    return bytes(out)
+    return bytes(out)[:_DB]
 
 
 def merge(a: bytes, b: bytes) -> bytes:
     out = (C.c_uint8 * 32)()
-    lib().orc_merge((C.c_uint8 * 32).from_buffer_copy(a), (C.c_uint8 * 32).from_buffer_copy(b), out)
-    return bytes(out)
+    lib().orc_merge((C.c_uint8 * _DB).from_buffer_copy(a), (C.c_uint8 * _DB).from_buffer_copy(b), out)
+    return bytes(out)[:_DB]
 
 
 def merge_with_int(seed: bytes, value: int) -> bytes:
     out = (C.c_uint8 * 32)()
-    lib().orc_merge_with_int((C.c_uint8 * 32).from_buffer_copy(seed), value, out)
-    return bytes(out)
+    lib().orc_merge_with_int((C.c_uint8 * _DB).from_buffer_copy(seed), value, out)
+    return bytes(out)[:_DB]
 
 
 def build_merkle_nodes(leaves: np.ndarray, threads: int = 1) -> np.ndarray:
-    leaves = np.ascontiguousarray(leaves, dtype=np.uint8).reshape(-1, 32)
+    leaves = np.ascontiguousarray(leaves, dtype=np.uint8).reshape(-1, _DB)
     nodes = np.empty_like(leaves)
     rc = lib().orc_build_merkle_nodes(_p(leaves), leaves.shape[0], _p(nodes), threads)
     if rc:
@@ -291,8 +314,8 @@ def build_trace_commitment(field: int, traces, ext: int, log2_R: int, log2_blowu
     else:
         polys = [np.empty_like(c) for c in cols]
         lde = [np.zeros((N, rw, w) if w > 1 else (N, rw), dtype=np.uint64) for _ in range(n_traces)]
-        leaves = np.empty((N, 32), dtype=np.uint8)
-        nodes = np.empty((N, 32), dtype=np.uint8)
+        leaves = np.empty((N, _DB), dtype=np.uint8)
+        nodes = np.empty((N, _DB), dtype=np.uint8)
     rc = lib().orc_build_trace_commitment(field, ext, log2_R, log2_blowup, n_cols, n_traces, _p(_off_bytes(offset)),
                                           _ptr_array(cols), _ptr_array(polys), _ptr_array(lde), _p(leaves), _p(nodes),
                                           threads)
@@ -327,8 +350,8 @@ def build_constraint_commitment(field: int, poly_cols, ext: int, log2_R: int, lo
     N = R * blowup
     cols = [np.ascontiguousarray(c, dtype=np.uint64) for c in poly_cols]
     lde = np.zeros((N, rw, w) if w > 1 else (N, rw), dtype=np.uint64)
-    leaves = np.empty((N, 32), dtype=np.uint8)
-    nodes = np.empty((N, 32), dtype=np.uint8)
+    leaves = np.empty((N, _DB), dtype=np.uint8)
+    nodes = np.empty((N, _DB), dtype=np.uint8)
     rc = lib().orc_build_constraint_commitment(field, ext, log2_R, log2_blowup, n_cols, _p(_off_bytes(offset)),
                                                _ptr_array(cols), _p(lde), _p(leaves), _p(nodes), threads)
     if rc:
@@ -441,7 +464,7 @@ def fri_layer_commit(field: int, evaluations: np.ndarray, n: int, ext: int, N: i
     rows = n // N
     w = ELEM_WORDS[field]
     flat = tr.reshape(rows, -1)
-    leaves = np.empty((rows, 32), dtype=np.uint8)
+    leaves = np.empty((rows, _DB), dtype=np.uint8)
     for i in range(rows):
         leaves[i] = np.frombuffer(hash_elements(field, flat[i]), dtype=np.uint8)
     nodes = build_merkle_nodes(leaves, threads)

@@ -19,7 +19,7 @@ ELEM_WORDS = {F64: 1, F128: 2}
 
 SYMBOLS = [
     "wf_ctx_create", "wf_ctx_destroy", "wf_last_error", "wf_device_count", "wf_ctx_synchronize", "wf_ctx_stream",
-    "wf_ctx_release_cached", "wf_plan_digits", "wf_commitment_query", "wf_ctx_profile_enable", "wf_ctx_profile_read", "wf_params_check", "wf_elem_bytes", "wf_row_width", "wf_column_bytes", "wf_lde_bytes", "wf_digests_bytes",
+    "wf_ctx_release_cached", "wf_ctx_set_digest_bytes", "wf_plan_digits", "wf_commitment_query", "wf_ctx_profile_enable", "wf_ctx_profile_read", "wf_params_check", "wf_elem_bytes", "wf_row_width", "wf_column_bytes", "wf_lde_bytes", "wf_digests_bytes",
     "wf_trace_commit", "wf_constraint_commit", "wf_trace_commit_dev", "wf_constraint_commit_dev",
     "wf_trace_commit_shard_dev", "wf_merkle_build_dev", "wf_trace_commit_resident", "wf_trace_commit_resident_async", "wf_commitment_wait", "wf_constraint_commit_resident", "wf_commitment_destroy", "wf_commitment_root",
     "wf_commitment_info", "wf_commitment_read_rows", "wf_commitment_read_lde", "wf_commitment_read_lde_strided", "wf_deep_compose", "wf_commitment_evaluate_polys_at_points", "wf_constraint_commit_from_evaluations", "wf_constraint_commit_from_tables", "wf_commitment_query_many", "wf_commitment_prove", "wf_commitment_prove_batch",
@@ -77,10 +77,11 @@ class Query(C.Structure):
                 ("node_counts", C.c_void_p), ("n_vectors", C.c_size_t), ("n_nodes", C.c_size_t), ("depth", C.c_uint32)]
 
 
-def make_params(field, ext_degree, log2_trace_len, log2_blowup, n_cols, n_traces=1, offset=None) -> Params:
+def make_params(field, ext_degree, log2_trace_len, log2_blowup, n_cols, n_traces=1, offset=None, digest_bytes=32) -> Params:
+    """digest_bytes: 32 = Blake3_256, 24 = Blake3_192 (host arrays of digests are then 24 bytes per entry)."""
     if offset is None:
         offset = 7 if field == F64 else 3  # ProofOptions::domain_offset = B::GENERATOR, air/src/options.rs:199-201
-    p = Params(field, ext_degree, log2_trace_len, log2_blowup, n_cols, n_traces, 32, 0)
+    p = Params(field, ext_degree, log2_trace_len, log2_blowup, n_cols, n_traces, digest_bytes, 0)
     p.domain_offset[:] = list(int(offset).to_bytes(16, "little"))
     return p
 
@@ -196,6 +197,7 @@ def load():
         L.wf_merkle_build.argtypes = [vp, vp, sz, vp]
         L.wf_device_count.argtypes = []
         L.wf_ctx_release_cached.argtypes = [vp]
+        L.wf_ctx_set_digest_bytes.argtypes = [vp, u32]
         L.wf_plan_digits.argtypes = [u32, u32, u32, C.POINTER(u32)]
         L.wf_commitment_query.argtypes = [vp, vp, sz, vp, vp, vp, sz, vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(u32)]
         pu32, pu64 = C.POINTER(u32), C.POINTER(C.c_uint64)
@@ -272,6 +274,7 @@ class Context:
         self._h = C.c_void_p()
         _check(load().wf_ctx_create(device, C.byref(self._h)))
         self.device = device
+        self.digest_bytes = 32  # hasher of the entry points without wf_params (set_digest_bytes)
         # Handles created on this context (commitments, FRI provers, communicators): the C ABI wants them destroyed
         # before it.  References from the children keep the context alive in normal operation, but the interpreter's
         # final garbage collection runs the finalisers of a dead cycle in no particular order -- so close() takes the
@@ -282,6 +285,11 @@ class Context:
         self._children.append(weakref.ref(child))
         if len(self._children) > 64:
             self._children = [r for r in self._children if r() is not None]
+
+    def set_digest_bytes(self, n: int):
+        """wf_ctx_set_digest_bytes: 32 = Blake3_256 (default), 24 = Blake3_192 for hash_rows / merkle_build / the FRI entry points."""
+        _check(load().wf_ctx_set_digest_bytes(self._h, n))
+        self.digest_bytes = n
 
     def release_cached(self):
         """Return the parked buffers of destroyed resident commitments to the driver (wf_ctx_release_cached)."""
@@ -336,13 +344,14 @@ class Context:
         polys = [np.empty_like(c) for c in cols] if want_polys else None
         lde = ([np.empty((n_rows, rw, w) if w > 1 else (n_rows, rw), dtype=np.uint64) for _ in range(params.n_traces)]
                if want_lde else None)
-        leaves = np.empty((n_rows, 32), dtype=np.uint8)
-        nodes = np.empty((n_rows, 32), dtype=np.uint8)
+        db = params.digest_bytes
+        leaves = np.empty((n_rows, db), dtype=np.uint8)
+        nodes = np.empty((n_rows, db), dtype=np.uint8)
         root = np.empty(32, dtype=np.uint8)
         _check(L.wf_trace_commit(self._h, C.byref(params), _ptr_array(cols),
                                  _ptr_array(polys) if polys else None, _ptr_array(lde) if lde else None,
                                  _p(leaves), _p(nodes), _p(root)))
-        return dict(polys=polys, lde=lde, leaves=leaves, nodes=nodes, root=bytes(root))
+        return dict(polys=polys, lde=lde, leaves=leaves, nodes=nodes, root=bytes(root)[:db])
 
     def constraint_commit(self, params: Params, poly_cols, want_lde=True):
         L = load()
@@ -352,12 +361,13 @@ class Context:
         n_rows = 1 << (params.log2_trace_len + params.log2_blowup)
         rw = L.wf_row_width(C.byref(params))
         lde = np.empty((n_rows, rw, w) if w > 1 else (n_rows, rw), dtype=np.uint64) if want_lde else None
-        leaves = np.empty((n_rows, 32), dtype=np.uint8)
-        nodes = np.empty((n_rows, 32), dtype=np.uint8)
+        db = params.digest_bytes
+        leaves = np.empty((n_rows, db), dtype=np.uint8)
+        nodes = np.empty((n_rows, db), dtype=np.uint8)
         root = np.empty(32, dtype=np.uint8)
         _check(L.wf_constraint_commit(self._h, C.byref(params), _ptr_array(cols), _p(lde), _p(leaves), _p(nodes),
                                       _p(root)))
-        return dict(lde=lde, leaves=leaves, nodes=nodes, root=bytes(root))
+        return dict(lde=lde, leaves=leaves, nodes=nodes, root=bytes(root)[:db])
 
     # -- the path, device buffers (raw device addresses, e.g. torch.Tensor.data_ptr()) ---------------------------
     def trace_commit_dev(self, params: Params, d_trace: int, d_polys: int, d_lde: int, d_leaves: int, d_nodes: int,
@@ -387,7 +397,7 @@ class Context:
         h = C.c_void_p()
         _check(L.wf_trace_commit_resident(self._h, C.byref(params), _ptr_array(cols),
                                           _ptr_array(polys) if polys else None, C.byref(h)))
-        return Commitment(h, params.field, keep_alive=self), polys
+        return Commitment(h, params.field, keep_alive=self, digest_bytes=params.digest_bytes), polys
 
     def trace_commit_resident_async(self, params: Params, trace_cols):
         """wf_trace_commit_resident_async: returns a Commitment whose kernels may still run; .wait() / .root() complete it.
@@ -397,7 +407,7 @@ class Context:
         cols = [np.ascontiguousarray(c, dtype=np.uint64) for c in trace_cols]
         h = C.c_void_p()
         _check(L.wf_trace_commit_resident_async(self._h, C.byref(params), _ptr_array(cols), C.byref(h)))
-        com = Commitment(h, params.field, keep_alive=self)
+        com = Commitment(h, params.field, keep_alive=self, digest_bytes=params.digest_bytes)
         com._inputs = cols
         return com
 
@@ -415,7 +425,7 @@ class Context:
         cols = [np.ascontiguousarray(c, dtype=np.uint64) for c in poly_cols]
         h = C.c_void_p()
         _check(L.wf_constraint_commit_resident(self._h, C.byref(params), _ptr_array(cols), C.byref(h)))
-        return Commitment(h, params.field, keep_alive=self)
+        return Commitment(h, params.field, keep_alive=self, digest_bytes=params.digest_bytes)
 
     def constraint_commit_from_evaluations(self, params: Params, combined_evaluations, final_coeff=None, want_polys=False):
         """wf_constraint_commit_from_evaluations: [n_tables] combined constraint evaluations over the constraint evaluation
@@ -435,7 +445,7 @@ class Context:
         _check(L.wf_constraint_commit_from_evaluations(self._h, C.byref(params), _ptr_array(tabs), len(tabs), ce,
                                                        _p(fc) if fc is not None else None,
                                                        _ptr_array(polys) if polys else None, C.byref(h)))
-        return Commitment(h, params.field, keep_alive=self), polys
+        return Commitment(h, params.field, keep_alive=self, digest_bytes=params.digest_bytes), polys
 
     def constraint_commit_from_tables(self, params: Params, tables, final_coeff=None, want_polys=False):
         """wf_constraint_commit_from_tables: tables = [[(column, (a, b, exemptions)), ..] per packed trace] -- the whole of
@@ -474,7 +484,7 @@ class Context:
         _check(L.wf_constraint_commit_from_tables(self._h, C.byref(params), c_tables, len(tables), ce,
                                                   _p(fc) if fc is not None else None, _ptr_array(polys) if polys else None,
                                                   C.byref(h)))
-        return Commitment(h, params.field, keep_alive=self), polys
+        return Commitment(h, params.field, keep_alive=self, digest_bytes=params.digest_bytes), polys
 
     def deep_compose(self, field, ext, n, trace_commitments, constraint_commitment, z, trace_coeffs, constraint_coeffs=None,
                      want_poly=True, fri: "FriProver" = None, lde_blowup: int = 0):
@@ -544,12 +554,12 @@ class Context:
         n = a.size // (ELEM_WORDS[field] * ext)
         rows = max(1, n // max(1, folding))
         tr = np.empty_like(a)
-        leaves = np.empty((rows, 32), dtype=np.uint8)
-        nodes = np.empty((rows, 32), dtype=np.uint8)
+        leaves = np.empty((rows, self.digest_bytes), dtype=np.uint8)
+        nodes = np.empty((rows, self.digest_bytes), dtype=np.uint8)
         root = np.empty(32, dtype=np.uint8)
         _check(load().wf_fri_layer_commit(self._h, field, ext, _p(a), n, folding, _p(tr), _p(leaves), _p(nodes),
                                           _p(root)))
-        return dict(transposed=tr, leaves=leaves, nodes=nodes, root=bytes(root))
+        return dict(transposed=tr, leaves=leaves, nodes=nodes, root=bytes(root)[:self.digest_bytes])
 
     def fri_apply_drp(self, field, ext, transposed: np.ndarray, folding: int, offset: int, alpha: np.ndarray):
         a = np.ascontiguousarray(transposed, dtype=np.uint64)
@@ -562,12 +572,12 @@ class Context:
 
     def hash_rows(self, field, rows: np.ndarray, n_rows: int, row_elems: int) -> np.ndarray:
         a = np.ascontiguousarray(rows, dtype=np.uint64)
-        out = np.empty((n_rows, 32), dtype=np.uint8)
+        out = np.empty((n_rows, self.digest_bytes), dtype=np.uint8)
         _check(load().wf_hash_rows(self._h, field, _p(a), n_rows, row_elems, _p(out)))
         return out
 
     def merkle_build(self, leaves: np.ndarray) -> np.ndarray:
-        lv = np.ascontiguousarray(leaves, dtype=np.uint8).reshape(-1, 32)
+        lv = np.ascontiguousarray(leaves, dtype=np.uint8).reshape(-1, self.digest_bytes)
         nodes = np.empty_like(lv)
         _check(load().wf_merkle_build(self._h, _p(lv), lv.shape[0], _p(nodes)))
         return nodes
@@ -576,9 +586,10 @@ class Context:
 class Commitment:
     """wf_commitment wrapper: LDE + tree resident in HBM; rows and Merkle proofs are read from there."""
 
-    def __init__(self, handle, field, owned=True, keep_alive=None):
+    def __init__(self, handle, field, owned=True, keep_alive=None, digest_bytes=32):
         self._h = handle
         self.field = field
+        self.digest_bytes = digest_bytes  # entries of the digest arrays this handle's queries fill (32, or 24 for Blake3_192)
         self._owned = owned  # layers of a FriProver belong to the prover
         self._keep_alive = keep_alive  # the Context (or FriProver) this handle lives in: destroyed after it, never before
         self._inputs = None  # host columns of an asynchronous commitment, until it has completed
@@ -606,7 +617,7 @@ class Commitment:
         out = (C.c_uint8 * 32)()
         _check(load().wf_commitment_root(self._h, out))
         self._inputs = None
-        return bytes(out)
+        return bytes(out)[:self.digest_bytes]
 
     def wait(self):
         """Completes a commitment made by trace_commit_resident_async (no-op otherwise)."""
@@ -648,7 +659,7 @@ class Commitment:
         return out
 
     def prove(self, index: int):
-        out = np.empty((self.depth + 1, 32), dtype=np.uint8)
+        out = np.empty((self.depth + 1, self.digest_bytes), dtype=np.uint8)
         _check(load().wf_commitment_prove(self._h, index, _p(out)))
         return [bytes(x) for x in out]
 
@@ -657,8 +668,8 @@ class Commitment:
         pos = np.ascontiguousarray(positions, dtype=np.uint64)
         n = len(pos)
         cap = max(1, n) * (self.depth + 1)
-        leaves = np.empty((max(1, n), 32), dtype=np.uint8)
-        nodes = np.empty((cap, 32), dtype=np.uint8)
+        leaves = np.empty((max(1, n), self.digest_bytes), dtype=np.uint8)
+        nodes = np.empty((cap, self.digest_bytes), dtype=np.uint8)
         counts = np.zeros(max(1, n), dtype=np.uint32)
         n_vec, n_nodes, depth = C.c_size_t(), C.c_size_t(), C.c_uint32()
         _check(load().wf_commitment_prove_batch(self._h, _p(pos), n, _p(leaves), _p(nodes), cap, _p(counts),
@@ -676,8 +687,8 @@ class Commitment:
         w = ELEM_WORDS[self.field]
         rows = np.empty((n, self.row_elems, w) if w > 1 else (n, self.row_elems), dtype=np.uint64)
         cap = max(1, n) * (self.depth + 1)
-        leaves = np.empty((max(1, n), 32), dtype=np.uint8)
-        nodes = np.empty((cap, 32), dtype=np.uint8)
+        leaves = np.empty((max(1, n), self.digest_bytes), dtype=np.uint8)
+        nodes = np.empty((cap, self.digest_bytes), dtype=np.uint8)
         counts = np.zeros(max(1, n), dtype=np.uint32)
         n_vec, n_nodes, depth = C.c_size_t(), C.c_size_t(), C.c_uint32()
         _check(load().wf_commitment_query(self._h, _p(pos), n, _p(rows), _p(leaves), _p(nodes), cap, _p(counts),
@@ -701,8 +712,8 @@ def query_many(requests, parse=True):
         w = ELEM_WORDS[com.field]
         rows = np.empty((n, com.row_elems, w) if w > 1 else (n, com.row_elems), dtype=np.uint64) if want_rows else None
         cap = max(1, n) * (com.depth + 1)
-        leaves = np.empty((max(1, n), 32), dtype=np.uint8)
-        nodes = np.empty((cap, 32), dtype=np.uint8)
+        leaves = np.empty((max(1, n), com.digest_bytes), dtype=np.uint8)
+        nodes = np.empty((cap, com.digest_bytes), dtype=np.uint8)
         counts = np.zeros(max(1, n), dtype=np.uint32)
         q.commitment, q.positions, q.n = com._h, _p(pos), n
         q.rows_out = _p(rows) if rows is not None else None
@@ -781,7 +792,7 @@ class FriProver:
     def commit_layer(self) -> bytes:
         out = (C.c_uint8 * 32)()
         _check(load().wf_fri_prover_commit_layer(self._h, out))
-        return bytes(out)
+        return bytes(out)[:self._ctx.digest_bytes]
 
     def fold(self, alpha: np.ndarray):
         al = np.ascontiguousarray(alpha, dtype=np.uint64)
@@ -793,7 +804,7 @@ class FriProver:
         n = C.c_size_t()
         digest = (C.c_uint8 * 32)()
         _check(load().wf_fri_prover_set_remainder(self._h, _p(out), capacity, C.byref(n), digest))
-        return out[:n.value].copy(), bytes(digest)
+        return out[:n.value].copy(), bytes(digest)[:self._ctx.digest_bytes]
 
     def num_layers(self) -> int:
         return int(load().wf_fri_prover_num_layers(self._h))
@@ -801,7 +812,7 @@ class FriProver:
     def layer(self, i: int) -> Commitment:
         h = C.c_void_p()
         _check(load().wf_fri_prover_layer(self._h, i, C.byref(h)))
-        return Commitment(h, self.field, owned=False, keep_alive=self)
+        return Commitment(h, self.field, owned=False, keep_alive=self, digest_bytes=self._ctx.digest_bytes)
 
     def reset(self):
         _check(load().wf_fri_prover_reset(self._h))

@@ -86,6 +86,28 @@ __device__ __forceinline__ void merge(const uint32_t (&m)[16], uint32_t (&out)[8
     compress(out, m, 0, 0, 64, CHUNK_START | CHUNK_END | ROOT);
 }
 
+// The same for either hasher of the reference, on digests kept in 32-byte SLOTS (the device-side layout of leaves and nodes
+// whatever the digest size; s = the two child slots as loaded): DW = 8 is Blake3_256::merge, DW = 6 Blake3_192::merge
+// (blake/mod.rs:80-83: the hash of the 48 bytes of two 24-byte digests, truncated to 24 bytes -- words 6, 7 of the result
+// slot are written as zeros, Digest::as_bytes pads the same way, crypto/src/hash/mod.rs:107-113).
+template <int DW>
+__device__ __forceinline__ void merge_slots(const uint32_t (&s)[16], uint32_t (&out)[8]) {
+    if constexpr (DW == 8) {
+        merge(s, out);
+    } else {
+        uint32_t m[16];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            m[i] = s[i];
+            m[6 + i] = s[8 + i];
+        }
+        m[12] = m[13] = m[14] = m[15] = 0;
+        set_iv(out);
+        compress(out, m, 0, 0, 48, CHUNK_START | CHUNK_END | ROOT);
+        out[6] = out[7] = 0;
+    }
+}
+
 // ---- the same merge by FOUR lanes (a quad): lane q holds column q of the 4 x 4 state (a = v[q], b = v[4+q], c = v[8+q],
 // d = v[12+q]); the column step is lane-local, the diagonal step reaches the neighbours' b, c, d through DPP quad permutes.
 // A third of the instructions per lane (about 230 against 678): for the narrow top levels of a Merkle tree, where one
@@ -108,6 +130,7 @@ __device__ __forceinline__ uint32_t quad_perm(uint32_t x) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, false);
 }
 
+template <int DW = 8>
 __device__ __forceinline__ void merge_quad(const uint32_t *msg, uint32_t q, uint32_t &out_lo, uint32_t &out_hi) {
     // this lane's 28 message indices: one of four compile-time tables, selected by q
     uint32_t iw[4];
@@ -118,11 +141,17 @@ __device__ __forceinline__ void merge_quad(const uint32_t *msg, uint32_t q, uint
     }
     uint32_t mw[28];
 #pragma unroll
-    for (int j = 0; j < 28; j++) mw[j] = msg[(iw[j / 8] >> (4 * (j % 8))) & 15u];
+    for (int j = 0; j < 28; j++) {
+        const uint32_t i = (iw[j / 8] >> (4 * (j % 8))) & 15u;
+        if constexpr (DW == 8)
+            mw[j] = msg[i];
+        else  // 48-byte message: words 0..5 of the first slot, 0..5 of the second, zeros
+            mw[j] = i < 12 ? msg[i < 6 ? i : i + 2] : 0u;
+    }
     const uint32_t iv_lo = q == 0 ? 0x6A09E667u : q == 1 ? 0xBB67AE85u : q == 2 ? 0x3C6EF372u : 0xA54FF53Au;
     const uint32_t iv_hi = q == 0 ? 0x510E527Fu : q == 1 ? 0x9B05688Cu : q == 2 ? 0x1F83D9ABu : 0x5BE0CD19u;
     uint32_t a = iv_lo, b = iv_hi, c = iv_lo;
-    uint32_t d = q == 2 ? 64u : q == 3 ? (uint32_t)(CHUNK_START | CHUNK_END | ROOT) : 0u;  // counter = 0, block_len = 64, flags
+    uint32_t d = q == 2 ? (DW == 8 ? 64u : 48u) : q == 3 ? (uint32_t)(CHUNK_START | CHUNK_END | ROOT) : 0u;  // counter = 0, block_len, flags
 #pragma unroll
     for (int r = 0; r < 7; r++) {
         WF_B3_G(a, b, c, d, mw[4 * r], mw[4 * r + 1])
@@ -135,7 +164,7 @@ __device__ __forceinline__ void merge_quad(const uint32_t *msg, uint32_t q, uint
         d = quad_perm<0x39>(d);
     }
     out_lo = a ^ c;
-    out_hi = b ^ d;
+    out_hi = (DW == 6 && q >= 2) ? 0u : (b ^ d);  // (words 6, 7 of a 24-byte digest's slot are zero)
 }
 
 // Hash of a message of `len` <= 1024 bytes (one chunk; len a multiple of 4) delivered block by block:

@@ -25,6 +25,7 @@ wf_tuning tuning_from_env() {
     wf_tuning t;
     if (const char *e = getenv("WF_EXP_MAX_DIGIT")) t.max_digit = (uint32_t)atoi(e);
     t.no_specialized = getenv("WF_EXP_NO_SPECIALIZED") != nullptr;
+    t.full_tiles = getenv("WF_EXP_FULL_TILES") != nullptr;
     t.no_fused_hash = getenv("WF_EXP_NO_FUSED_HASH") != nullptr;
     t.no_chunked = getenv("WF_EXP_NO_CHUNKED") != nullptr;
     t.persistent_always = getenv("WF_EXP_PERSISTENT_ALWAYS") != nullptr;
@@ -255,7 +256,8 @@ int check_params(const wf_params *p, bool constraint) {
         return fail(WF_ERR_DOMAIN, "no multiplicative subgroup of size 2^%u in this field", p->log2_trace_len + p->log2_blowup);
     if (p->n_cols < 1 || p->n_cols > 255) return fail(WF_ERR_WIDTH, "number of columns must be in [1,255]");
     if (p->n_traces < 1 || (constraint && p->n_traces != 1)) return fail(WF_ERR_TRACES, "invalid number of traces %u", p->n_traces);
-    if (p->digest_bytes != 32) return fail(WF_ERR_DIGEST, "only 32-byte digests (Blake3_256) are supported");
+    if (p->digest_bytes != 32 && p->digest_bytes != 24)
+        return fail(WF_ERR_DIGEST, "digest_bytes must be 32 (Blake3_256) or 24 (Blake3_192), got %u", p->digest_bytes);
     if (p->reserved != 0) return fail(WF_ERR_ARG, "reserved field must be zero");
     u128 off;
     memcpy(&off, p->domain_offset, 16);
@@ -321,6 +323,7 @@ void wf_ctx_destroy(wf_ctx *ctx) {
     if (ctx->hash_tmp.p) (void)hipFree(ctx->hash_tmp.p);
     if (ctx->tickets.p) (void)hipFree(ctx->tickets.p);
     if (ctx->chain_flags.p) (void)hipFree(ctx->chain_flags.p);
+    if (ctx->pack_tmp.p) (void)hipFree(ctx->pack_tmp.p);
     for (auto &b : ctx->pool) (void)hipFree(b.first);
     for (hipEvent_t e : ctx->seg_events) (void)hipEventDestroy(e);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
@@ -388,7 +391,16 @@ size_t wf_column_bytes(const wf_params *p) {
 size_t wf_lde_bytes(const wf_params *p) {
     return ((size_t)1 << (p->log2_trace_len + p->log2_blowup)) * wf_row_width(p) * wf_elem_bytes(p->field);
 }
-size_t wf_digests_bytes(const wf_params *p) { return ((size_t)1 << (p->log2_trace_len + p->log2_blowup)) * 32; }
+size_t wf_digests_bytes(const wf_params *p) { return ((size_t)1 << (p->log2_trace_len + p->log2_blowup)) * p->digest_bytes; }
+
+int wf_ctx_set_digest_bytes(wf_ctx *ctx, uint32_t digest_bytes) {
+    if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
+    if (digest_bytes != 32 && digest_bytes != 24)
+        return fail(WF_ERR_DIGEST, "digest_bytes must be 32 (Blake3_256) or 24 (Blake3_192), got %u", digest_bytes);
+    WF_ENTER(ctx, nullptr);
+    ctx->digest_bytes = digest_bytes;
+    return 0;
+}
 
 
 }  // extern "C"

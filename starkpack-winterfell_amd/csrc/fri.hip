@@ -33,10 +33,10 @@ static int fri_layer_commit_dev(wf_ctx *ctx, hipStream_t st, uint32_t ext, const
                        (T *)d_transposed, rows, folding, ext);
     HIP_TRY(hipGetLastError());
     prof_mark(ctx, st, "fri.hash_values");
-    int rc = path_hash_rows(ctx, st, F::FIELD_ID == 1 ? WF_FIELD_F64 : WF_FIELD_F128, d_transposed, 0, rows, folding * ext, folding * ext, 1, d_leaves);
+    int rc = path_hash_rows(ctx, st, F::FIELD_ID == 1 ? WF_FIELD_F64 : WF_FIELD_F128, d_transposed, 0, rows, folding * ext, folding * ext, 1, d_leaves, ctx->digest_bytes);
     if (rc) return rc;
     prof_mark(ctx, st, "fri.merkle");
-    rc = path_merkle(ctx, st, d_leaves, rows, d_nodes);
+    rc = path_merkle(ctx, st, d_leaves, rows, d_nodes, ctx->digest_bytes);
     prof_mark(ctx, st, "between_calls");
     return rc;
 }
@@ -138,8 +138,11 @@ int wf_fri_layer_commit(wf_ctx *ctx, uint32_t field, uint32_t ext, const void *e
     rc = wf_fri_layer_commit_dev(ctx, field, ext, ctx->io[0].p, n, folding, ctx->io[2].p, ctx->io[3].p, ctx->io[4].p, st);
     if (rc) return rc;
     if (transposed_out) HIP_TRY(hipMemcpyAsync(transposed_out, ctx->io[2].p, bytes, hipMemcpyDeviceToHost, st));
-    if (leaves_out) HIP_TRY(hipMemcpyAsync(leaves_out, ctx->io[3].p, rows * 32, hipMemcpyDeviceToHost, st));
-    if (nodes_out) HIP_TRY(hipMemcpyAsync(nodes_out, ctx->io[4].p, rows * 32, hipMemcpyDeviceToHost, st));
+    if (leaves_out) {
+        if ((rc = path_digests_to_host(ctx, st, ctx->io[3].p, leaves_out, rows, ctx->digest_bytes))) return rc;
+        if (ctx->digest_bytes != 32) HIP_TRY(hipStreamSynchronize(st));  // (one packing buffer for both arrays)
+    }
+    if (nodes_out && (rc = path_digests_to_host(ctx, st, ctx->io[4].p, nodes_out, rows, ctx->digest_bytes))) return rc;
     if (root_out) HIP_TRY(hipMemcpyAsync(root_out, (char *)ctx->io[4].p + 32, 32, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return 0;
@@ -400,7 +403,7 @@ int wf_fri_prover_commit_layer(wf_fri_prover *pr, uint8_t root_out[32]) {
     c->p.ext_degree = pr->ext;
     c->p.n_cols = pr->folding;
     c->p.n_traces = 1;
-    c->p.digest_bytes = 32;
+    c->p.digest_bytes = ctx->digest_bytes;  // the context's hasher (wf_ctx_set_digest_bytes)
     memcpy(c->p.domain_offset, pr->offset, 16);
     c->n_rows = rows;
     c->row_width = c->epr = c->row_elems = (uint64_t)pr->folding * pr->ext;

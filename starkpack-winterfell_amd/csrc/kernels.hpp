@@ -278,8 +278,14 @@ struct HashArgs {
     uint32_t row_width;         // elements per stored row
     uint32_t epr;               // elements of a row that are hashed (elements_per_row)
     uint32_t n_traces;
-    uint32_t *leaves;           // n_rows * 8 words
+    uint32_t *leaves;           // n_rows * 8 words (32-byte slots)
+    uint32_t digest_words;      // 8 (Blake3_256) or 6 (Blake3_192: words 6, 7 of a leaf's slot are written as zeros)
 };
+
+// the second half of a digest slot: words 4..7, the last two zero for a 24-byte digest
+__device__ __forceinline__ uint4 digest_hi(uint32_t w4, uint32_t w5, uint32_t w6, uint32_t w7, uint32_t digest_words) {
+    return digest_words == 6 ? make_uint4(w4, w5, 0u, 0u) : make_uint4(w4, w5, w6, w7);
+}
 
 template <class F>
 __device__ __forceinline__ void elem_words(typename F::T v, uint32_t *w);
@@ -378,7 +384,7 @@ __global__ void __launch_bounds__(256) k_hash_rows(HashArgs<F> a) {
     }
     uint4 *dst = reinterpret_cast<uint4 *>(a.leaves + j * 8);
     dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
-    dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+    dst[1] = digest_hi(out[4], out[5], out[6], out[7], a.digest_words);
 }
 
 // Rows longer than one BLAKE3 chunk (1024 bytes: packed traces, wide traces): one lane per (row, chunk) computes the
@@ -421,14 +427,14 @@ __global__ void __launch_bounds__(256) k_hash_chunks(HashArgs<F> a, uint32_t chu
 }
 
 static __global__ void __launch_bounds__(256) k_hash_merge_chunks(const uint32_t *__restrict__ cvs, uint32_t chunks_per_row,
-                                                           uint64_t n_rows, uint32_t *__restrict__ leaves) {
+                                                           uint64_t n_rows, uint32_t *__restrict__ leaves, uint32_t digest_words) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_rows) return;
     uint32_t out[8];
     b3::merge_chunk_cvs(cvs + j * chunks_per_row * 8, chunks_per_row, out);
     uint4 *dst = reinterpret_cast<uint4 *>(leaves + j * 8);
     dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
-    dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+    dst[1] = digest_hi(out[4], out[5], out[6], out[7], digest_words);
 }
 
 // The same fold with 16 lanes per row (16 rows per work-group): a row's chaining values sit in LDS and are merged level
@@ -436,7 +442,7 @@ static __global__ void __launch_bounds__(256) k_hash_merge_chunks(const uint32_t
 // (above) leaves the chip idle when there are few long rows: 8192 rows of 80 chunks are 79 dependent compressions on 128
 // waves.  Dynamic LDS: 16 * n * 32 bytes (the launcher uses this kernel for n <= 128).
 static __global__ void __launch_bounds__(256) k_hash_merge_chunks_par(const uint32_t *__restrict__ cvs, uint32_t n, uint64_t n_rows,
-                                                               uint32_t *__restrict__ leaves) {
+                                                               uint32_t *__restrict__ leaves, uint32_t digest_words) {
     extern __shared__ __attribute__((aligned(16))) unsigned char merge_smem[];
     const uint32_t lane = threadIdx.x & 15, r = threadIdx.x >> 4;
     const uint64_t row = (uint64_t)blockIdx.x * 16 + r;
@@ -479,7 +485,7 @@ static __global__ void __launch_bounds__(256) k_hash_merge_chunks_par(const uint
     if (live && lane == 0) {
         uint4 *dst = reinterpret_cast<uint4 *>(leaves + row * 8);
         dst[0] = my[0];
-        dst[1] = my[1];
+        dst[1] = digest_hi(my[1].x, my[1].y, my[1].z, my[1].w, digest_words);
     }
 }
 
@@ -488,7 +494,8 @@ static __global__ void __launch_bounds__(256) k_hash_merge_chunks_par(const uint
 // through up to `levels` levels, keeping the intermediate digests in LDS and writing every level to `nodes`.
 // children: digests of the level below (n_children of them); the parents level has n_children/2 nodes stored at
 // nodes[n_children/2 .. n_children).
-static __global__ void __launch_bounds__(256) k_merkle_subtree(const uint32_t *__restrict__ children,
+template <int DW>
+__global__ void __launch_bounds__(256) k_merkle_subtree(const uint32_t *__restrict__ children,
                                                         uint32_t *__restrict__ nodes, uint64_t n_children,
                                                         uint32_t levels) {
     __shared__ uint32_t sh[256 * 8];
@@ -504,7 +511,7 @@ static __global__ void __launch_bounds__(256) k_merkle_subtree(const uint32_t *_
         m[4] = q1.x; m[5] = q1.y; m[6] = q1.z; m[7] = q1.w;
         m[8] = q2.x; m[9] = q2.y; m[10] = q2.z; m[11] = q2.w;
         m[12] = q3.x; m[13] = q3.y; m[14] = q3.z; m[15] = q3.w;
-        b3::merge(m, cv);
+        b3::merge_slots<DW>(m, cv);
         uint4 *dst = reinterpret_cast<uint4 *>(nodes + (n_par + first + tid) * 8);
         dst[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
         dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
@@ -522,7 +529,7 @@ static __global__ void __launch_bounds__(256) k_merkle_subtree(const uint32_t *_
             const uint32_t node = tid >> 2, q = tid & 3;
             const bool act = node < width;  // whole quads
             uint32_t lo = 0, hi = 0;
-            if (act) b3::merge_quad(sh + node * 16, q, lo, hi);
+            if (act) b3::merge_quad<DW>(sh + node * 16, q, lo, hi);
             __syncthreads();
             if (act) {
                 uint32_t *dst = nodes + (n_par + first + node) * 8;
@@ -537,7 +544,7 @@ static __global__ void __launch_bounds__(256) k_merkle_subtree(const uint32_t *_
         if (act) {
 #pragma unroll
             for (int i = 0; i < 16; i++) m[i] = sh[tid * 16 + i];
-            b3::merge(m, cv);
+            b3::merge_slots<DW>(m, cv);
         }
         __syncthreads();
         if (act) {
@@ -558,7 +565,8 @@ static __global__ void __launch_bounds__(256) k_merkle_subtree(const uint32_t *_
 }
 
 // One Merkle level per launch (used while a level still fills the chip): parents[i] = merge(children[2i], children[2i+1]).
-static __global__ void __launch_bounds__(256) k_merkle_level(const uint32_t *__restrict__ children,
+template <int DW>
+__global__ void __launch_bounds__(256) k_merkle_level(const uint32_t *__restrict__ children,
                                                       uint32_t *__restrict__ parents, uint64_t n_parents) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_parents) return;
@@ -569,10 +577,25 @@ static __global__ void __launch_bounds__(256) k_merkle_level(const uint32_t *__r
     m[4] = q1.x; m[5] = q1.y; m[6] = q1.z; m[7] = q1.w;
     m[8] = q2.x; m[9] = q2.y; m[10] = q2.z; m[11] = q2.w;
     m[12] = q3.x; m[13] = q3.y; m[14] = q3.z; m[15] = q3.w;
-    b3::merge(m, cv);
+    b3::merge_slots<DW>(m, cv);
     uint4 *dst = reinterpret_cast<uint4 *>(parents + i * 8);
     dst[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
     dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+}
+
+// 24-byte digests travel between host arrays (ByteDigest<24>, 24 bytes apart: the reference's Vec<Digest>) and the device's
+// 32-byte slots: one 8-byte word per thread.  pack: slots -> 24-byte entries; unpack: the reverse, words 6, 7 zeroed.
+static __global__ void __launch_bounds__(256) k_digests_pack24(const uint2 *__restrict__ slots, uint2 *__restrict__ packed, uint64_t n) {
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= 3 * n) return;
+    const uint64_t i = g / 3, w = g - 3 * i;
+    packed[g] = slots[4 * i + w];
+}
+static __global__ void __launch_bounds__(256) k_digests_unpack24(const uint2 *__restrict__ packed, uint2 *__restrict__ slots, uint64_t n) {
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= 4 * n) return;
+    const uint64_t i = g >> 2, w = g & 3;
+    slots[g] = w < 3 ? packed[3 * i + w] : make_uint2(0u, 0u);
 }
 
 // Query service: gather rows of all traces at the queried positions.  grid = (n positions, n traces)
@@ -604,8 +627,9 @@ static __global__ void __launch_bounds__(256) k_gather_digests(const uint4 *__re
 #ifndef WF_EXP_MERKLE_WAVES
 #define WF_EXP_MERKLE_WAVES 6
 #endif
+template <int DW>
 __attribute__((amdgpu_waves_per_eu(WF_EXP_MERKLE_WAVES, WF_EXP_MERKLE_WAVES)))
-static __global__ void __launch_bounds__(256) k_merkle_level2(const uint32_t *__restrict__ children,
+__global__ void __launch_bounds__(256) k_merkle_level2(const uint32_t *__restrict__ children,
                                                        uint32_t *__restrict__ parents,
                                                        uint32_t *__restrict__ grandparents, uint64_t n_grand) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_grand; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -618,14 +642,14 @@ static __global__ void __launch_bounds__(256) k_merkle_level2(const uint32_t *__
         m[4] = q1.x; m[5] = q1.y; m[6] = q1.z; m[7] = q1.w;
         m[8] = q2.x; m[9] = q2.y; m[10] = q2.z; m[11] = q2.w;
         m[12] = q3.x; m[13] = q3.y; m[14] = q3.z; m[15] = q3.w;
-        b3::merge(m, cv);
+        b3::merge_slots<DW>(m, cv);
         uint4 *dst = reinterpret_cast<uint4 *>(parents + (2 * i + h) * 8);
         dst[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
         dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
 #pragma unroll
         for (int k = 0; k < 8; k++) g[8 * h + k] = cv[k];
     }
-    b3::merge(g, cv);
+    b3::merge_slots<DW>(g, cv);
     uint4 *dst = reinterpret_cast<uint4 *>(grandparents + i * 8);
     dst[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
     dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);

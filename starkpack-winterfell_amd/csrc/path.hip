@@ -52,11 +52,11 @@ static Plan make_plan(uint32_t L, uint32_t max_digit, bool avoid_full = false, b
 
 // the plan of the segment kernels (run_seg_transform and the sizing of its work buffer must agree on it)
 template <class F>
-static Plan seg_plan(uint32_t logN, uint32_t n_seg, uint32_t digit_cap = 0) {
+static Plan seg_plan(uint32_t logN, uint32_t n_seg, uint32_t digit_cap = 0, bool full_tiles = false) {
     uint32_t max_digit = F::BYTES == 8 ? 11 : 10;
     // wf_tuning::max_digit (tests / tuning): force more, smaller passes
     if (digit_cap >= 4 && digit_cap < max_digit && (logN + digit_cap - 1) / digit_cap <= 4) max_digit = digit_cap;  // Plan holds 4 digits
-    return make_plan(logN, max_digit, true, n_seg <= 8);
+    return make_plan(logN, max_digit, !full_tiles, n_seg <= 8);
 }
 
 template <class F>
@@ -186,7 +186,7 @@ static int seg_launch_dims(uint32_t logD, uint32_t &threads, size_t &lds, bool l
     return 0;
 }
 
-static void launch_merge_chunks(hipStream_t st, const void *cvs, uint32_t n_chunks, uint64_t n_rows, void *leaves);
+static void launch_merge_chunks(hipStream_t st, const void *cvs, uint32_t n_chunks, uint64_t n_rows, void *leaves, uint32_t dw);
 
 // per-XCD ticket / exit counters of the persistent kernels + their error word; zeroed once (the kernels leave them at zero)
 static int ensure_tickets(wf_ctx *ctx, hipStream_t st) {
@@ -231,6 +231,7 @@ struct SegDesc {
     bool rows_out;
     void *leaves = nullptr;     // rows_out: hash the leaves in the last pass when the shape allows (sets *fused)
     uint32_t hash_epr = 0;
+    uint32_t digest_words = 8;  // 6: Blake3_192 leaves
     bool *fused = nullptr;
     const TableSet *pre;
     bool pad_traces = false;     // rows_out, unpacked: the lane with a trace's last column zeroes the rest of that row
@@ -250,7 +251,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
     TableSet *tw;
     int rc = root_tables<F>(ctx, d.logN, inverse, &tw);
     if (rc) return rc;
-    const Plan plan = seg_plan<F>(d.logN, d.n_seg, ctx->tune.max_digit);
+    const Plan plan = seg_plan<F>(d.logN, d.n_seg, ctx->tune.max_digit, ctx->tune.full_tiles);
     const uint64_t N = (uint64_t)1 << d.logN;
 
     SegArgs<F> a;
@@ -271,6 +272,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
     a.pad_traces = d.pad_traces ? 1 : 0;
     a.tail_pad = d.pad_in_kernel ? (uint32_t)d.row_width - d.n_seg * SegCfg<F>::S : 0;
     a.coset0 = d.coset0;
+    a.digest_words = d.digest_words ? d.digest_words : 8;  // (descriptors are memset to zero by their users)
     a.rows_per_k = d.n_cosets;
     a.row_width = d.row_width;
     a.trace_lde_elems = d.trace_lde_elems;
@@ -436,7 +438,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             void *kargs[] = {&a};
             HIP_TRY(hipLaunchKernel(kern, dim3((uint32_t)std::min<uint64_t>((uint64_t)d.n_cosets * d.n_seg, resident_single)), dim3(threads), kargs, lds, st));
-            launch_merge_chunks(st, ctx->hash_tmp.p, n_chunks, launch_rows, d.leaves);
+            launch_merge_chunks(st, ctx->hash_tmp.p, n_chunks, launch_rows, d.leaves, a.digest_words);
             HIP_TRY(hipGetLastError());
             return 0;
         }
@@ -469,7 +471,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             HIP_TRY(hipLaunchKernel(kern, dim3((uint32_t)std::min<uint64_t>(tickets, resident)), dim3(threads), kargs, lds_p, st));
             if (chunked) {
                 HIP_TRY(hipGetLastError());
-                launch_merge_chunks(st, ctx->hash_tmp.p, n_chunks, launch_rows, d.leaves);
+                launch_merge_chunks(st, ctx->hash_tmp.p, n_chunks, launch_rows, d.leaves, a.digest_words);
             }
         } else if (d.rows_out && packed)
             hipLaunchKernelGGL((k_seg_last<F, SEG_OUT_ROWS, true>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
@@ -507,20 +509,20 @@ static int run_xpose(wf_ctx *ctx, hipStream_t st, bool to_seg, const void *src, 
 
 // ------------------------------------------------------------------------------------------------- hashing + tree
 // leaves from per-row chunk chaining values ([row][n_chunks][8 words])
-static void launch_merge_chunks(hipStream_t st, const void *cvs, uint32_t n_chunks, uint64_t n_rows, void *leaves) {
+static void launch_merge_chunks(hipStream_t st, const void *cvs, uint32_t n_chunks, uint64_t n_rows, void *leaves, uint32_t dw) {
     // few, long rows: 16 lanes per row; otherwise one lane per row (measured: 8192 rows x 80 chunks 0.48 -> 0.37 ms for
     // chunks + merge, but 32768 x 20 and shorter rows are faster with a lane per row)
     if (n_chunks >= 32 && n_chunks <= 128 && n_rows <= 65536)
         hipLaunchKernelGGL(k_hash_merge_chunks_par, dim3((uint32_t)((n_rows + 15) / 16)), dim3(256), (size_t)16 * n_chunks * 32, st,
-                           (const uint32_t *)cvs, n_chunks, n_rows, (uint32_t *)leaves);
+                           (const uint32_t *)cvs, n_chunks, n_rows, (uint32_t *)leaves, dw);
     else
         hipLaunchKernelGGL(k_hash_merge_chunks, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, (const uint32_t *)cvs,
-                           n_chunks, n_rows, (uint32_t *)leaves);
+                           n_chunks, n_rows, (uint32_t *)leaves, dw);
 }
 
 template <class F>
 static int run_hash_rows(wf_ctx *ctx, hipStream_t st, const void *lde, uint64_t trace_elems, uint64_t n_rows, uint32_t row_width,
-                         uint32_t epr, uint32_t n_traces, void *leaves) {
+                         uint32_t epr, uint32_t n_traces, void *leaves, uint32_t dw = 8) {
     HashArgs<F> h;
     h.lde = (const typename F::T *)lde;
     h.trace_elems = trace_elems;
@@ -529,6 +531,7 @@ static int run_hash_rows(wf_ctx *ctx, hipStream_t st, const void *lde, uint64_t 
     h.epr = epr;
     h.n_traces = n_traces;
     h.leaves = (uint32_t *)leaves;
+    h.digest_words = dw;
     const uint32_t threads = 256;
     const uint64_t grid = (n_rows + threads - 1) / threads;
     const uint64_t row_bytes = (uint64_t)n_traces * epr * F::BYTES;
@@ -544,13 +547,14 @@ static int run_hash_rows(wf_ctx *ctx, hipStream_t st, const void *lde, uint64_t 
         hipLaunchKernelGGL(k_hash_chunks<F>, dim3((uint32_t)g2), dim3(threads), 0, st, h, (uint32_t)chunks,
                            (uint32_t *)ctx->hash_tmp.p);
         HIP_TRY(hipGetLastError());
-        launch_merge_chunks(st, ctx->hash_tmp.p, (uint32_t)chunks, n_rows, leaves);
+        launch_merge_chunks(st, ctx->hash_tmp.p, (uint32_t)chunks, n_rows, leaves, dw);
     }
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-static int run_merkle(wf_ctx *ctx, hipStream_t st, const void *leaves, uint64_t n_leaves, void *nodes) {
+template <int DW>
+static int run_merkle_dw(wf_ctx *ctx, hipStream_t st, const void *leaves, uint64_t n_leaves, void *nodes) {
     // (nodes[0] = Digest::default(), merkle/mod.rs:355, is written by the launch that produces the root)
     const uint32_t *children = (const uint32_t *)leaves;
     uint64_t n_children = n_leaves;
@@ -567,12 +571,12 @@ static int run_merkle(wf_ctx *ctx, hipStream_t st, const void *leaves, uint64_t 
 #define WF_EXP_MERKLE_GRID_WAVES 8
 #endif
             const uint64_t blocks2 = std::min<uint64_t>((n_grand + threads - 1) / threads, (uint64_t)ctx->num_cus * WF_EXP_MERKLE_GRID_WAVES);  // grid-stride
-            hipLaunchKernelGGL(k_merkle_level2, dim3((uint32_t)blocks2), dim3(threads), 0, st,
+            hipLaunchKernelGGL(k_merkle_level2<DW>, dim3((uint32_t)blocks2), dim3(threads), 0, st,
                                children, (uint32_t *)nodes + n_par * 8, (uint32_t *)nodes + n_grand * 8, n_grand);
             HIP_TRY(hipGetLastError());
             n_children = n_grand;
         } else if (n_par >= (1u << 15) && l2_min == 16) {  // a level that still fills the chip: one lane per node
-            hipLaunchKernelGGL(k_merkle_level, dim3((uint32_t)grid), dim3(threads), 0, st, children,
+            hipLaunchKernelGGL(k_merkle_level<DW>, dim3((uint32_t)grid), dim3(threads), 0, st, children,
                                (uint32_t *)nodes + n_par * 8, n_par);
             HIP_TRY(hipGetLastError());
             n_children = n_par;
@@ -580,7 +584,7 @@ static int run_merkle(wf_ctx *ctx, hipStream_t st, const void *leaves, uint64_t 
             uint32_t total_levels = 0;
             for (uint64_t t = n_children; t > 1; t >>= 1) total_levels++;
             const uint32_t levels = std::min<uint32_t>(9, total_levels);
-            hipLaunchKernelGGL(k_merkle_subtree, dim3((uint32_t)grid), dim3(threads), 0, st, children,
+            hipLaunchKernelGGL(k_merkle_subtree<DW>, dim3((uint32_t)grid), dim3(threads), 0, st, children,
                                (uint32_t *)nodes, n_children, levels);
             HIP_TRY(hipGetLastError());
             n_children >>= levels;
@@ -588,6 +592,11 @@ static int run_merkle(wf_ctx *ctx, hipStream_t st, const void *leaves, uint64_t 
         children = (const uint32_t *)nodes + n_children * 8;  // that level lives at nodes[n .. 2n)
     }
     return 0;
+}
+
+// dw: digest words -- 8 = Blake3_256, 6 = Blake3_192 (48-byte merge inputs; the slots' last two words are zeros)
+static int run_merkle(wf_ctx *ctx, hipStream_t st, const void *leaves, uint64_t n_leaves, void *nodes, uint32_t dw = 8) {
+    return dw == 6 ? run_merkle_dw<6>(ctx, st, leaves, n_leaves, nodes) : run_merkle_dw<8>(ctx, st, leaves, n_leaves, nodes);
 }
 
 // ------------------------------------------------------------------------------------------------- the path (device)
@@ -610,7 +619,7 @@ static int path_buffers(wf_ctx *ctx, const wf_params *p, PathBufs<F> &b, uint32_
     b.n_seg = (b.total_base_cols + S - 1) / S;
     const size_t seg_vals = (size_t)b.n_seg * S << p->log2_trace_len;
     if (n_cosets == 0) n_cosets = 1u << p->log2_blowup;
-    const size_t work_vals = seg_plan<F>(p->log2_trace_len, b.n_seg, ctx->tune.max_digit).n_pass > 1 ? seg_vals * n_cosets : 0;
+    const size_t work_vals = seg_plan<F>(p->log2_trace_len, b.n_seg, ctx->tune.max_digit, ctx->tune.full_tiles).n_pass > 1 ? seg_vals * n_cosets : 0;
     int rc = ensure(ctx, ctx->scratch, (2 * seg_vals + work_vals) * sizeof(T));
     if (rc) return rc;
     b.segA = (T *)ctx->scratch.p;
@@ -677,6 +686,7 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
     bool hashed = false;  // leaves produced by the last evaluation pass itself (one segment, one trace)
     d.leaves = d_leaves;
     d.hash_epr = b.total_base_cols;  // the combined row of all traces (= base_cols for one trace)
+    d.digest_words = p->digest_bytes / 4;
     d.fused = &hashed;
     d.phase = phase;
     d.seg0 = seg0;
@@ -688,12 +698,12 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
     if (d_leaves) {
         if (!hashed) {
             prof_mark(ctx, st, "hash_rows");
-            rc = run_hash_rows<F>(ctx, st, d_lde, Nrows * row_width, Nrows, (uint32_t)row_width, base_cols, p->n_traces, d_leaves);
+            rc = run_hash_rows<F>(ctx, st, d_lde, Nrows * row_width, Nrows, (uint32_t)row_width, base_cols, p->n_traces, d_leaves, p->digest_bytes / 4);
             if (rc) return rc;
         }
         if (d_nodes) {
             prof_mark(ctx, st, "merkle");
-            rc = run_merkle(ctx, st, d_leaves, Nrows, d_nodes);
+            rc = run_merkle(ctx, st, d_leaves, Nrows, d_nodes, p->digest_bytes / 4);
             if (rc) return rc;
         }
     }
@@ -808,8 +818,8 @@ static bool pipelined_upload_ok(const wf_ctx *ctx, const wf_params *p, size_t co
     const uint32_t S = p->field == WF_FIELD_F64 ? SegCfg<F64>::S : SegCfg<F128>::S;
     const uint32_t n_seg = (p->n_cols * p->n_traces + S - 1) / S;
     if (n_seg < 2) return false;
-    const int n_pass = p->field == WF_FIELD_F64 ? seg_plan<F64>(p->log2_trace_len, n_seg, ctx->tune.max_digit).n_pass
-                                                : seg_plan<F128>(p->log2_trace_len, n_seg, ctx->tune.max_digit).n_pass;
+    const int n_pass = p->field == WF_FIELD_F64 ? seg_plan<F64>(p->log2_trace_len, n_seg, ctx->tune.max_digit, ctx->tune.full_tiles).n_pass
+                                                : seg_plan<F128>(p->log2_trace_len, n_seg, ctx->tune.max_digit, ctx->tune.full_tiles).n_pass;
     if (n_pass < 2) return false;
     return colb >= ctx->tune.pipeline_min_bytes;  // (below ~1 MiB per column the events cost more than they hide; tests lower it)
 }
@@ -942,7 +952,7 @@ int wf_merkle_build_dev(wf_ctx *ctx, const void *d_leaves, size_t n_leaves, void
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     WF_ENTER(ctx, st);
     prof_mark(ctx, st, "merkle");
-    int rc = run_merkle(ctx, st, d_leaves, n_leaves, d_nodes);
+    int rc = run_merkle(ctx, st, d_leaves, n_leaves, d_nodes, ctx->digest_bytes / 4);
     prof_mark(ctx, st, "between_calls");
     return rc;
 }
@@ -957,7 +967,8 @@ static int commit_host(wf_ctx *ctx, const wf_params *p, bool constraint, const v
     if (!cols_in) return fail(WF_ERR_ARG, "column pointer array is null");
     HIP_TRY(hipSetDevice(ctx->device));
     WF_ENTER(ctx, ctx->stream);
-    const size_t colb = wf_column_bytes(p), ldeb = wf_lde_bytes(p), digb = wf_digests_bytes(p);
+    const size_t colb = wf_column_bytes(p), ldeb = wf_lde_bytes(p);
+    const size_t n_dig = (size_t)1 << (p->log2_trace_len + p->log2_blowup), digb = n_dig * 32;  // device side: 32-byte slots
     const size_t TC = (size_t)p->n_cols * p->n_traces;
     for (size_t i = 0; i < TC; i++)
         if (!cols_in[i]) return fail(WF_ERR_ARG, "column %zu is null", i);
@@ -979,9 +990,14 @@ static int commit_host(wf_ctx *ctx, const wf_params *p, bool constraint, const v
         for (size_t t = 0; t < p->n_traces; t++)
             if (lde_out[t])
                 HIP_TRY(hipMemcpyAsync(lde_out[t], (char *)ctx->io[2].p + t * ldeb, ldeb, hipMemcpyDeviceToHost, st));
-    if (leaves_out) HIP_TRY(hipMemcpyAsync(leaves_out, ctx->io[3].p, digb, hipMemcpyDeviceToHost, st));
-    if (nodes_out) HIP_TRY(hipMemcpyAsync(nodes_out, ctx->io[4].p, digb, hipMemcpyDeviceToHost, st));
-    if (root_out) HIP_TRY(hipMemcpyAsync(root_out, (char *)ctx->io[4].p + 32, 32, hipMemcpyDeviceToHost, st));
+    // host arrays of digests are Vec<ByteDigest<N>>: digest_bytes apart (24-byte digests are packed on the device, one
+    // array after the other through the same staging buffer)
+    if (leaves_out) {
+        if ((rc = path_digests_to_host(ctx, st, ctx->io[3].p, leaves_out, n_dig, p->digest_bytes))) return rc;
+        if (p->digest_bytes != 32) HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (nodes_out && (rc = path_digests_to_host(ctx, st, ctx->io[4].p, nodes_out, n_dig, p->digest_bytes))) return rc;
+    if (root_out) HIP_TRY(hipMemcpyAsync(root_out, (char *)ctx->io[4].p + 32, 32, hipMemcpyDeviceToHost, st));  // (zero-padded: Digest::as_bytes)
     HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
@@ -1155,11 +1171,11 @@ int wf_hash_rows(wf_ctx *ctx, uint32_t field, const void *rows, size_t n_rows, s
     hipStream_t st = ctx->stream;
     if (bytes) HIP_TRY(hipMemcpyAsync(ctx->io[2].p, rows, bytes, hipMemcpyHostToDevice, st));
     if (field == WF_FIELD_F64)
-        rc = run_hash_rows<F64>(ctx, st, ctx->io[2].p, 0, n_rows, (uint32_t)row_elems, (uint32_t)row_elems, 1, ctx->io[3].p);
+        rc = run_hash_rows<F64>(ctx, st, ctx->io[2].p, 0, n_rows, (uint32_t)row_elems, (uint32_t)row_elems, 1, ctx->io[3].p, ctx->digest_bytes / 4);
     else
-        rc = run_hash_rows<F128>(ctx, st, ctx->io[2].p, 0, n_rows, (uint32_t)row_elems, (uint32_t)row_elems, 1, ctx->io[3].p);
+        rc = run_hash_rows<F128>(ctx, st, ctx->io[2].p, 0, n_rows, (uint32_t)row_elems, (uint32_t)row_elems, 1, ctx->io[3].p, ctx->digest_bytes / 4);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(digests_out, ctx->io[3].p, n_rows * 32, hipMemcpyDeviceToHost, st));
+    if ((rc = path_digests_to_host(ctx, st, ctx->io[3].p, digests_out, n_rows, ctx->digest_bytes))) return rc;
     HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
@@ -1175,10 +1191,10 @@ int wf_merkle_build(wf_ctx *ctx, const uint8_t *leaves, size_t n_leaves, uint8_t
     if ((rc = ensure(ctx, ctx->io[3], n_leaves * 32))) return rc;
     if ((rc = ensure(ctx, ctx->io[4], n_leaves * 32))) return rc;
     hipStream_t st = ctx->stream;
-    HIP_TRY(hipMemcpyAsync(ctx->io[3].p, leaves, n_leaves * 32, hipMemcpyHostToDevice, st));
-    rc = run_merkle(ctx, st, ctx->io[3].p, n_leaves, ctx->io[4].p);
+    if ((rc = path_digests_from_host(ctx, st, leaves, ctx->io[3].p, n_leaves, ctx->digest_bytes))) return rc;
+    rc = run_merkle(ctx, st, ctx->io[3].p, n_leaves, ctx->io[4].p, ctx->digest_bytes / 4);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(nodes_out, ctx->io[4].p, n_leaves * 32, hipMemcpyDeviceToHost, st));
+    if ((rc = path_digests_to_host(ctx, st, ctx->io[4].p, nodes_out, n_leaves, ctx->digest_bytes))) return rc;
     HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
@@ -1248,7 +1264,7 @@ static int trace_commit_sharded(wf_comm *c, const wf_params *p, const void *d_tr
     if (rc) return rc;
     const uint64_t n_local = N / W;
     if (n_local >= 2) {
-        rc = run_merkle(ctx, st, d_leaves, n_local, d_nodes);  // local layout: d_nodes[1] = this rank's sub-root
+        rc = run_merkle(ctx, st, d_leaves, n_local, d_nodes, p->digest_bytes / 4);  // local layout: d_nodes[1] = this rank's sub-root
         if (rc) return rc;
     }
     // the top log2(W) levels: all-gather of the W sub-roots (32 * W bytes), folded by every rank
@@ -1260,7 +1276,7 @@ static int trace_commit_sharded(wf_comm *c, const wf_params *p, const void *d_tr
     } else {
         rc = comm_all_gather(c, sub_root, top + (size_t)W * 32, 32, st);
         if (rc) return rc;
-        rc = run_merkle(ctx, st, top + (size_t)W * 32, W, top);
+        rc = run_merkle(ctx, st, top + (size_t)W * 32, W, top, p->digest_bytes / 4);
         if (rc) return rc;
     }
     prof_mark(ctx, st, "between_calls");
@@ -1318,13 +1334,39 @@ bool path_dense_column_ok(const wf_params *p) {
 bool path_dense_matrix_ok(const wf_params *p) { return dense_matrix_ok(p); }
 
 int path_hash_rows(wf_ctx *ctx, hipStream_t st, uint32_t field, const void *lde, uint64_t trace_elems, uint64_t n_rows,
-                   uint32_t row_width, uint32_t epr, uint32_t n_traces, void *leaves) {
-    return field == WF_FIELD_F64 ? run_hash_rows<F64>(ctx, st, lde, trace_elems, n_rows, row_width, epr, n_traces, leaves)
-                                 : run_hash_rows<F128>(ctx, st, lde, trace_elems, n_rows, row_width, epr, n_traces, leaves);
+                   uint32_t row_width, uint32_t epr, uint32_t n_traces, void *leaves, uint32_t digest_bytes) {
+    return field == WF_FIELD_F64 ? run_hash_rows<F64>(ctx, st, lde, trace_elems, n_rows, row_width, epr, n_traces, leaves, digest_bytes / 4)
+                                 : run_hash_rows<F128>(ctx, st, lde, trace_elems, n_rows, row_width, epr, n_traces, leaves, digest_bytes / 4);
 }
 
-int path_merkle(wf_ctx *ctx, hipStream_t st, const void *leaves, uint64_t n_leaves, void *nodes) {
-    return run_merkle(ctx, st, leaves, n_leaves, nodes);
+int path_merkle(wf_ctx *ctx, hipStream_t st, const void *leaves, uint64_t n_leaves, void *nodes, uint32_t digest_bytes) {
+    return run_merkle(ctx, st, leaves, n_leaves, nodes, digest_bytes / 4);
+}
+
+int path_digests_to_host(wf_ctx *ctx, hipStream_t st, const void *d_slots, void *host, size_t n, uint32_t digest_bytes) {
+    if (digest_bytes == 32) {
+        HIP_TRY(hipMemcpyAsync(host, d_slots, n * 32, hipMemcpyDeviceToHost, st));
+        return 0;
+    }
+    int rc = ensure(ctx, ctx->pack_tmp, n * 24);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_digests_pack24, dim3((uint32_t)((3 * n + 255) / 256)), dim3(256), 0, st, (const uint2 *)d_slots, (uint2 *)ctx->pack_tmp.p, (uint64_t)n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host, ctx->pack_tmp.p, n * 24, hipMemcpyDeviceToHost, st));
+    return 0;
+}
+
+int path_digests_from_host(wf_ctx *ctx, hipStream_t st, const void *host, void *d_slots, size_t n, uint32_t digest_bytes) {
+    if (digest_bytes == 32) {
+        HIP_TRY(hipMemcpyAsync(d_slots, host, n * 32, hipMemcpyHostToDevice, st));
+        return 0;
+    }
+    int rc = ensure(ctx, ctx->pack_tmp, n * 24);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->pack_tmp.p, host, n * 24, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_digests_unpack24, dim3((uint32_t)((4 * n + 255) / 256)), dim3(256), 0, st, (const uint2 *)ctx->pack_tmp.p, (uint2 *)d_slots, (uint64_t)n);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int path_device_error(wf_ctx *ctx) {

@@ -52,7 +52,8 @@ void free_commitment(wf_commitment *c) {
 
 // A resident commitment's handle with its buffers (LDE, leaves, nodes, polynomials) taken from the context's pool
 int commitment_alloc(wf_ctx *ctx, const wf_params *p, bool constraint, wf_commitment **out, bool *dense_out) {
-    const size_t colb = wf_column_bytes(p), ldeb = wf_lde_bytes(p), digb = wf_digests_bytes(p);
+    const size_t colb = wf_column_bytes(p), ldeb = wf_lde_bytes(p);
+    const size_t digb = ((size_t)1 << (p->log2_trace_len + p->log2_blowup)) * 32;  // 32-byte slots whatever the digest size
     const size_t TC = (size_t)p->n_cols * p->n_traces;
     wf_commitment *c = commitment_new(ctx);
     c->p = *p;
@@ -363,8 +364,11 @@ static int fetch_digests(const wf_commitment *c, const std::vector<uint64_t> &id
     hipLaunchKernelGGL(k_gather_digests, dim3((2 * n + 255) / 256), dim3(256), 0, st, (const uint4 *)c->leaves,
                        (const uint4 *)c->nodes, c->n_rows, (const uint64_t *)ctx->io[3].p, n, (uint4 *)ctx->io[4].p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out, ctx->io[4].p, ids.size() * 32, hipMemcpyDeviceToHost, st));
+    const uint32_t db = c->p.digest_bytes ? c->p.digest_bytes : 32;
+    std::vector<uint8_t> slots(db == 32 ? 0 : ids.size() * 32);
+    HIP_TRY(hipMemcpyAsync(db == 32 ? (void *)out : (void *)slots.data(), ctx->io[4].p, ids.size() * 32, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (db != 32) copy_digests_out(out, slots.data(), ids.size(), db);
     return 0;
 }
 
@@ -508,8 +512,9 @@ static int query_many_impl(wf_query *q, size_t nq) {
     for (size_t i = 0; i < nq; i++) {
         const Part &pt = parts[i];
         if (q[i].rows_out) memcpy(q[i].rows_out, h_out + pt.rows_off, pt.rows_bytes);
-        memcpy(q[i].leaves_out, h_out + pt.dig_off, q[i].n * 32);
-        memcpy(q[i].nodes_out, h_out + pt.dig_off + q[i].n * 32, pt.total * 32);
+        const uint32_t db = q[i].commitment->p.digest_bytes ? q[i].commitment->p.digest_bytes : 32;  // entries of the caller's arrays
+        copy_digests_out(q[i].leaves_out, h_out + pt.dig_off, q[i].n, db);
+        copy_digests_out(q[i].nodes_out, h_out + pt.dig_off + q[i].n * 32, pt.total, db);
         for (size_t v = 0; v < pt.vec_ids.size(); v++) q[i].node_counts[v] = (uint32_t)pt.vec_ids[v].size();
         q[i].n_vectors = pt.vec_ids.size();
         q[i].n_nodes = pt.total;
@@ -942,8 +947,8 @@ int wf_sharded_commitment_query(wf_sharded_commitment *c, const uint64_t *positi
         const uint32_t owner = (uint32_t)(positions[i] % blowup) / c->per;
         memcpy((char *)rows_out + i * row_bytes, &all[(size_t)owner * msg + ids.size() * 32 + i * row_bytes], row_bytes);
     }
-    memcpy(leaves_out, dig.data(), n * 32);
-    memcpy(nodes_out, dig.data() + n * 32, total * 32);
+    copy_digests_out(leaves_out, dig.data(), n, c->p.digest_bytes);
+    copy_digests_out(nodes_out, dig.data() + n * 32, total, c->p.digest_bytes);
     for (size_t i = 0; i < vec_ids.size(); i++) node_counts[i] = (uint32_t)vec_ids[i].size();
     *n_vectors = vec_ids.size();
     *n_nodes = total;

@@ -160,6 +160,7 @@ struct SegArgs {
     // is not read back by k_hash_rows (RowMatrix::commit_to_rows, row_matrix.rs:183-203)
     uint32_t *leaves;          // nullptr: no fused hashing
     uint32_t hash_epr;         // elements of a row that are hashed (elements_per_row)
+    uint32_t digest_words;     // 8 (Blake3_256) or 6 (Blake3_192: the last two words of a leaf's 32-byte slot are zeros)
     uint32_t *chunk_cvs;       // k_seg_last_hash<.., CHUNKED>: [LDE row][n_chunks][8] chunk chaining values (rows > 1024 bytes)
     uint32_t n_chunks;         //   ceil(n_seg / 16): a BLAKE3 chunk is 16 blocks = 16 segments of a row
     uint32_t *tile_counters;   // k_seg_last_hash: 8 ticket + 8 exit counters, one per XCD, zero between launches (self-resetting)
@@ -1113,7 +1114,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
                 b3::compress(out, m, 0, 0, a.hash_epr * F::BYTES, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT);
                 uint4 *dl = reinterpret_cast<uint4 *>(leaf + j * 8);
                 dl[0] = make_uint4(out[0], out[1], out[2], out[3]);
-                dl[1] = make_uint4(out[4], out[5], out[6], out[7]);
+                dl[1] = digest_hi(out[4], out[5], out[6], out[7], a.digest_words);
             }
         }
     }
@@ -1133,7 +1134,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
             const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << (a.logN - a.logD));
             uint4 *dl = reinterpret_cast<uint4 *>(a.leaves + ((uint64_t)(uint32_t)k * a.rows_per_k + c) * 8);
             dl[0] = make_uint4(out[0], out[1], out[2], out[3]);
-            dl[1] = make_uint4(out[4], out[5], out[6], out[7]);
+            dl[1] = digest_hi(out[4], out[5], out[6], out[7], a.digest_words);
         }
     }
 }
@@ -1420,7 +1421,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512))
 #endif
                     uint4 *dl = reinterpret_cast<uint4 *>(CHUNKED ? a.chunk_cvs + (row * n_chunks + ch) * 8 : a.leaves + row * 8);
                     dl[0] = lo;
-                    dl[1] = hi;
+                    dl[1] = CHUNKED ? hi : digest_hi(hi.x, hi.y, hi.z, hi.w, a.digest_words);  // (chunk chaining values stay whole)
                 } else if (r == 0) {
                     cva0 = lo;
                     cva1 = hi;

@@ -55,6 +55,7 @@ struct TableSet {  // device-resident Pow2L tables
 // later changes which kernel a customer's call runs.  All off by default; tests/test_gpu_plans.py forces each one.
 struct wf_tuning {
     uint32_t max_digit = 0;           // WF_EXP_MAX_DIGIT: cap the digit size (more, smaller passes); 0 = planner's own
+    bool full_tiles = false;          // WF_EXP_FULL_TILES: allow plans of two maximal digits (one work-group per CU in both passes)
     bool no_specialized = false;      // WF_EXP_NO_SPECIALIZED: generic strided pass instead of the 2^10-row instantiation
     bool no_fused_hash = false;       // WF_EXP_NO_FUSED_HASH: leaves always from k_hash_rows
     bool no_chunked = false;          // WF_EXP_NO_CHUNKED: long rows hashed by the separate chunk kernels
@@ -72,6 +73,10 @@ struct wf_ctx {
     int device = 0;
     int num_cus = 256;  // compute units of the device: sizes the persistent grid of k_seg_last_hash
     wf_tuning tune;
+    // the hasher of the entry points that take no wf_params (wf_hash_rows, wf_merkle_build*, wf_fri_*): 32 = Blake3_256
+    // (default), 24 = Blake3_192; wf_ctx_set_digest_bytes.  Commitments carry theirs in wf_params::digest_bytes.
+    uint32_t digest_bytes = 32;
+    DevBuf pack_tmp;  // 24-byte digests on their way between host arrays and the device's 32-byte slots
     hipStream_t stream = nullptr;
     // key: (field, logN, kind, aux, offset lo, offset hi); kind 0 = forward root, 1 = inverse root,
     // 2 = coset bases (aux = log blowup), 3 = output series for interpolate_with_offset
@@ -220,9 +225,22 @@ int path_constraint_commit(wf_ctx *ctx, const wf_params *p, const void *d_polys,
                            hipStream_t st, bool dense_rows = false);
 bool path_dense_column_ok(const wf_params *p);
 bool path_dense_matrix_ok(const wf_params *p);
+// (digest_bytes: 32 or 24; device leaves / nodes are 32-byte slots either way, a 24-byte digest in the first 24 bytes)
 int path_hash_rows(wf_ctx *ctx, hipStream_t st, uint32_t field, const void *lde, uint64_t trace_elems, uint64_t n_rows,
-                   uint32_t row_width, uint32_t epr, uint32_t n_traces, void *leaves);
-int path_merkle(wf_ctx *ctx, hipStream_t st, const void *leaves, uint64_t n_leaves, void *nodes);
+                   uint32_t row_width, uint32_t epr, uint32_t n_traces, void *leaves, uint32_t digest_bytes);
+int path_merkle(wf_ctx *ctx, hipStream_t st, const void *leaves, uint64_t n_leaves, void *nodes, uint32_t digest_bytes);
+// n digests from device slots to a HOST array of digest_bytes-sized entries (asynchronous on st; 24-byte digests are packed
+// on the device first) and the way back (host entries -> device slots)
+int path_digests_to_host(wf_ctx *ctx, hipStream_t st, const void *d_slots, void *host, size_t n, uint32_t digest_bytes);
+int path_digests_from_host(wf_ctx *ctx, hipStream_t st, const void *host, void *d_slots, size_t n, uint32_t digest_bytes);
+// host-side copy of n digests out of a buffer of 32-byte slots
+static inline void copy_digests_out(void *dst, const void *slots, size_t n, uint32_t digest_bytes) {
+    if (digest_bytes == 32) {
+        memcpy(dst, slots, n * 32);
+        return;
+    }
+    for (size_t i = 0; i < n; i++) memcpy((char *)dst + i * digest_bytes, (const char *)slots + i * 32, digest_bytes);
+}
 // after a synchronisation: WF_ERR_HIP if a persistent kernel of this context flagged a chaining time-out (cannot happen
 // while the whole grid is resident; the flag exists so that a wrong assumption shows up as an error, not as wrong leaves)
 int path_device_error(wf_ctx *ctx);

@@ -196,7 +196,7 @@ class ShardedCommitment:
     def root(self) -> bytes:
         out = (C.c_uint8 * 32)()
         capi._check(capi.load().wf_sharded_commitment_root(self._h, out))
-        return bytes(out)
+        return bytes(out)[:self.params.digest_bytes]
 
     def query(self, positions):
         """Collective: (rows, (leaves, nodes, depth)) -- the answer of Commitment.query on the unsharded commitment."""
@@ -206,8 +206,8 @@ class ShardedCommitment:
         w = capi.ELEM_WORDS[self.params.field]
         rows = np.empty((n, self.row_elems, w) if w > 1 else (n, self.row_elems), dtype=np.uint64)
         cap = max(1, n) * (self.depth + 1)
-        leaves = np.empty((max(1, n), 32), dtype=np.uint8)
-        nodes = np.empty((cap, 32), dtype=np.uint8)
+        leaves = np.empty((max(1, n), self.params.digest_bytes), dtype=np.uint8)
+        nodes = np.empty((cap, self.params.digest_bytes), dtype=np.uint8)
         counts = np.zeros(max(1, n), dtype=np.uint32)
         n_vec, n_nodes, depth = C.c_size_t(), C.c_size_t(), C.c_uint32()
         capi._check(capi.load().wf_sharded_commitment_query(self._h, capi._p(pos), n, capi._p(rows), capi._p(leaves),
@@ -223,7 +223,7 @@ class ShardedCommitment:
         """The polynomials as a capi.Commitment (evaluate_polys_at); owned by this object."""
         h = C.c_void_p()
         capi._check(capi.load().wf_sharded_commitment_polys(self._h, C.byref(h)))
-        return capi.Commitment(h, self.params.field, owned=False, keep_alive=self)
+        return capi.Commitment(h, self.params.field, owned=False, keep_alive=self, digest_bytes=self.params.digest_bytes)
 
 
 def process_group_collectives(group=None):
