@@ -66,7 +66,7 @@ print(f"kernels: {len(kern)} dispatches, busy {ksum / 1e6:.2f} ms; large H2D cop
 print(f"span of the trace: {(max(k[1] for k in kern) - t0) / 1e6:.2f} ms")
 streams = sorted({k[4] for k in kern} | {c[3] for c in cop})
 print("streams:", streams, " queues:", sorted({k[3] for k in kern}))
-print("\nfirst 60 events of the steady state (ms from start; K = kernel, C = copy):")
+print("\n60 events from the middle of the trace (ms from start; K = kernel, C = copy):")
 ev = [(k[0], k[1], "K", f"q{k[3]} s{k[4]} " + k[2][:60]) for k in kern] + [(c[0], c[1], "C", f"s{c[3]} {c[2]} {(c[1] - c[0]) / 1e3:.0f} us") for c in cop if c[1] - c[0] > 20_000]
 ev.sort()
 mid = len(ev) // 2

@@ -80,12 +80,14 @@ def batch(columns):
     return ms, roots
 
 
+only = sys.argv[3] if len(sys.argv) > 3 else None   # trace mode: one | two | batch -- a timeline of that variant alone
 for name, columns in (("pageable", cols), ("pinned", pinned)):
     if mode == "trace" and len(sys.argv) > 2 and sys.argv[2] != name:
         continue
-    a, root = one(columns)
-    b, roots2 = two(columns)
-    c, roots3 = batch(columns)
+    a, root = one(columns) if only in (None, "one") else (float("nan"), None)
+    b, roots2 = two(columns) if only in (None, "two") else (float("nan"), [])
+    c, roots3 = batch(columns) if only in (None, "batch") else (float("nan"), [])
+    root = root or (roots2 + roots3 + [None])[0]
     ok = all(r == root for r in roots2) and all(r == root for r in roots3)
     print(f"{name:9s}: one context {a:.3f} ms / commitment | two contexts, two threads {b:.3f} | "
-          f"one context, batched upload-under-compute {('%.3f' % c) if c is not None else 'n/a'} | roots agree: {ok}", flush=True)
+          f"one context, wf_trace_commit_resident_async (upload under compute) {('%.3f' % c) if c is not None else 'n/a'} | roots agree: {ok}", flush=True)
