@@ -499,6 +499,7 @@ def verify_multi_rank(torch, capi, shard, ctx, comm, args, packed, params, rank,
             for r in range(world):
                 pid = shard.proofs_of_rank(world, r, world)[0]
                 t = trace if r == 0 else rand_f64_dev(torch, N_COLS * R, shard.seed_of_proof(0x57415446, pid), device)
+                torch.cuda.synchronize()  # (the generator ran on torch's default stream, the commitment runs on `stream`)
                 with torch.cuda.stream(stream):
                     ctx.trace_commit_dev(params, t.data_ptr(), polys.data_ptr(), lde.data_ptr(), leaves.data_ptr(),
                                          nodes.data_ptr(), stream.cuda_stream)
