@@ -251,6 +251,28 @@ where
         (me, polys.into_iter().map(ColMatrix::new).collect())
     }
 
+    /// The same for a STREAM of proofs (STARKPack proves batch after batch): returns as soon as the columns are on their way
+    /// and the kernels are queued -- the next call's upload runs on the context's copy stream under this call's kernels.
+    /// `wait` (or `root`) completes the handle.  The traces' columns are ordinary (pageable) `Vec`s here: the library has
+    /// staged them when this returns, so `traces` may be dropped at once.
+    pub fn commit_traces_async(ctx: &'a WfContext, traces: &[&ColMatrix<E>], domain: &StarkDomain<B>) -> Self {
+        let (r, c, n) = (traces[0].num_rows(), traces[0].num_cols(), traces.len());
+        let p = params::<B, E>(r, c, n, domain);
+        let col_ptrs: Vec<*const c_void> = traces
+            .iter()
+            .flat_map(|t| (0..c).map(move |i| t.get_column(i).as_ptr() as *const c_void))
+            .collect();
+        let mut raw = core::ptr::null_mut();
+        check(unsafe { wf_trace_commit_resident_async(ctx.raw, &p, col_ptrs.as_ptr(), &mut raw) })
+            .expect("failed to queue trace commitment");
+        Self { raw, n_traces: n, n_cols: c, _ctx: PhantomData, _types: PhantomData }
+    }
+
+    /// Blocks until the kernels of an asynchronous commitment have finished (no-op otherwise).
+    pub fn wait(&self) {
+        check(unsafe { wf_commitment_wait(self.raw) }).expect("trace commitment failed on the device");
+    }
+
     /// build_constraint_commitment, outputs resident.
     pub fn commit_composition_poly(ctx: &'a WfContext, poly: &CompositionPoly<E>, domain: &StarkDomain<B>) -> Self {
         let data = poly.data();

@@ -124,6 +124,26 @@ int main(void) {
         free(piece); free(deep); free(deep2);
     }
     wf_commitment_destroy(com);
+    {   /* a stream of proofs (asynchronous form) and the second hasher, from plain C */
+        wf_commitment *a[3] = {NULL, NULL, NULL};
+        uint8_t r3[32], leaves24[2 * 24], nodes24[2 * 24];
+        int i;
+        for (i = 0; i < 3; i++) CHECK(wf_trace_commit_resident_async(ctx, &p, col_ptrs, &a[i]) == WF_OK);
+        for (i = 0; i < 3; i++) {
+            CHECK(wf_commitment_wait(a[i]) == WF_OK);
+            CHECK(wf_commitment_root(a[i], r3) == WF_OK && memcmp(root, r3, 32) == 0);
+            wf_commitment_destroy(a[i]);
+        }
+        CHECK(wf_commitment_wait(NULL) == WF_ERR_ARG);
+        CHECK(wf_ctx_set_digest_bytes(ctx, 20) == WF_ERR_DIGEST && wf_ctx_set_digest_bytes(ctx, 24) == WF_OK);
+        memset(leaves24, 7, sizeof(leaves24));
+        CHECK(wf_merkle_build(ctx, leaves24, 2, nodes24) == WF_OK);   /* Blake3_192: 24-byte entries in and out */
+        for (i = 0; i < 24; i++) CHECK(nodes24[i] == 0);               /* nodes[0] = Digest::default() */
+        CHECK(wf_ctx_set_digest_bytes(ctx, 32) == WF_OK);
+        p.digest_bytes = 24;
+        CHECK(wf_params_check(&p, 0) == WF_OK && wf_digests_bytes(&p) == (size_t)N * 24);
+        p.digest_bytes = 32;
+    }
 
     p.n_cols = 0;
     CHECK(wf_trace_commit(ctx, &p, col_ptrs, NULL, NULL, NULL, NULL, root) == WF_ERR_WIDTH);
