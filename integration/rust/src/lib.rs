@@ -39,7 +39,7 @@ use air::DeepCompositionCoefficients;
 use crypto::{BatchMerkleProof, ElementHasher, Hasher, MerkleTree};
 use math::{fields::f128, fields::f64, FieldElement, StarkField};
 use prover::{ColMatrix, CompositionPoly, ConstraintCommitment, RowMatrix, StarkDomain};
-use utils::{collections::Vec, uninit_vector, Serializable};
+use utils::{collections::Vec, uninit_vector, Deserializable, Serializable};
 
 use ffi::*;
 
@@ -57,10 +57,18 @@ impl WfField for f128::BaseElement {
     const WF_FIELD: u32 = WF_FIELD_F128;
 }
 
-/// Hashers whose digest is the 32-byte array the library writes (`ByteDigest<32>`, `crypto/src/hash/mod.rs:84-85`):
-/// `Blake3_256`.
-pub trait WfHasher: ElementHasher + Hasher<Digest = crypto::hash::ByteDigest<32>> {}
-impl<B: StarkField> WfHasher for crypto::hashers::Blake3_256<B> {}
+/// Hashers the library implements: the digest is a byte array of `DIGEST_BYTES` bytes, written by the library as such
+/// (`ByteDigest<N>`, `crypto/src/hash/mod.rs:84-85`): `Blake3_256` (32) and `Blake3_192` (24: the BLAKE3 output truncated,
+/// 48-byte merges, `crypto/src/hash/blake/mod.rs:68-114`).  Host arrays of digests hold `DIGEST_BYTES` per entry.
+pub trait WfHasher: ElementHasher + Hasher {
+    const DIGEST_BYTES: u32;
+}
+impl<B: StarkField> WfHasher for crypto::hashers::Blake3_256<B> {
+    const DIGEST_BYTES: u32 = 32;
+}
+impl<B: StarkField> WfHasher for crypto::hashers::Blake3_192<B> {
+    const DIGEST_BYTES: u32 = 24;
+}
 
 // CONTEXT
 // ================================================================================================
@@ -97,7 +105,7 @@ fn check(rc: i32) -> Result<(), String> {
 }
 
 fn params<B: WfField, E: FieldElement<BaseField = B>>(
-    trace_len: usize, n_cols: usize, n_traces: usize, domain: &StarkDomain<B>,
+    trace_len: usize, n_cols: usize, n_traces: usize, domain: &StarkDomain<B>, digest_bytes: u32,
 ) -> WfParams {
     let mut p = WfParams {
         field: B::WF_FIELD,
@@ -106,7 +114,7 @@ fn params<B: WfField, E: FieldElement<BaseField = B>>(
         log2_blowup: domain.trace_to_lde_blowup().ilog2(),
         n_cols: n_cols as u32,
         n_traces: n_traces as u32,
-        digest_bytes: 32,
+        digest_bytes,
         reserved: 0,
         domain_offset: [0; 16],
     };
@@ -132,7 +140,7 @@ where
     assert!(!traces.is_empty(), "at least one trace is required");
     let (r, c, n) = (traces[0].num_rows(), traces[0].num_cols(), traces.len());
     assert!(traces.iter().all(|t| t.num_rows() == r && t.num_cols() == c), "packed traces must have one shape");
-    let p = params::<B, E>(r, c, n, domain);
+    let p = params::<B, E>(r, c, n, domain, H::DIGEST_BYTES);
     let row_width = unsafe { wf_row_width(&p) };
     let lde_rows = r * domain.trace_to_lde_blowup();
 
@@ -181,7 +189,7 @@ where
 {
     let data = composition_poly.data(); // ColMatrix<E>: num_cols columns of trace_length coefficients
     let (r, c) = (data.num_rows(), data.num_cols());
-    let p = params::<B, E>(r, c, 1, domain);
+    let p = params::<B, E>(r, c, 1, domain, H::DIGEST_BYTES);
     let row_width = unsafe { wf_row_width(&p) };
     let lde_rows = r * domain.trace_to_lde_blowup();
 
@@ -228,7 +236,7 @@ where
         ctx: &'a WfContext, traces: &[&ColMatrix<E>], domain: &StarkDomain<B>, want_polys: bool,
     ) -> (Self, Vec<ColMatrix<E>>) {
         let (r, c, n) = (traces[0].num_rows(), traces[0].num_cols(), traces.len());
-        let p = params::<B, E>(r, c, n, domain);
+        let p = params::<B, E>(r, c, n, domain, H::DIGEST_BYTES);
         let col_ptrs: Vec<*const c_void> = traces
             .iter()
             .flat_map(|t| (0..c).map(move |i| t.get_column(i).as_ptr() as *const c_void))
@@ -257,7 +265,7 @@ where
     /// staged them when this returns, so `traces` may be dropped at once.
     pub fn commit_traces_async(ctx: &'a WfContext, traces: &[&ColMatrix<E>], domain: &StarkDomain<B>) -> Self {
         let (r, c, n) = (traces[0].num_rows(), traces[0].num_cols(), traces.len());
-        let p = params::<B, E>(r, c, n, domain);
+        let p = params::<B, E>(r, c, n, domain, H::DIGEST_BYTES);
         let col_ptrs: Vec<*const c_void> = traces
             .iter()
             .flat_map(|t| (0..c).map(move |i| t.get_column(i).as_ptr() as *const c_void))
@@ -277,7 +285,7 @@ where
     pub fn commit_composition_poly(ctx: &'a WfContext, poly: &CompositionPoly<E>, domain: &StarkDomain<B>) -> Self {
         let data = poly.data();
         let (r, c) = (data.num_rows(), data.num_cols());
-        let p = params::<B, E>(r, c, 1, domain);
+        let p = params::<B, E>(r, c, 1, domain, H::DIGEST_BYTES);
         let col_ptrs: Vec<*const c_void> = (0..c).map(|i| data.get_column(i).as_ptr() as *const c_void).collect();
         let mut raw = core::ptr::null_mut();
         check(unsafe { wf_constraint_commit_resident(ctx.raw, &p, col_ptrs.as_ptr(), &mut raw) })
@@ -287,9 +295,11 @@ where
 
     /// `MerkleTree::root` (crypto/src/merkle/mod.rs:167) -> `channel.commit_trace` / `commit_constraints`.
     pub fn root(&self) -> H::Digest {
+        // root_out[32] is the digest zero-padded (Digest::as_bytes); H::Digest is ByteDigest<32> or ByteDigest<24>: read the
+        // first DIGEST_BYTES through the type's own Deserializable impl (crypto/src/hash/mod.rs:127-131)
         let mut out = [0u8; 32];
         check(unsafe { wf_commitment_root(self.raw, out.as_mut_ptr()) }).expect("root");
-        crypto::hash::ByteDigest::new(out)
+        H::Digest::read_from_bytes(&out[..H::DIGEST_BYTES as usize]).expect("digest")
     }
 
     /// `TraceCommitment::query` / `ConstraintCommitment::query` (prover/src/trace/commitment.rs:87-111,
@@ -354,7 +364,7 @@ where
         domain: &StarkDomain<B>,
     ) -> Self {
         let ce = tables[0][0].0.len();
-        let p = params::<B, E>(trace_length, num_cols, 1, domain);
+        let p = params::<B, E>(trace_length, num_cols, 1, domain, H::DIGEST_BYTES);
         let mut col_ptrs: Vec<Vec<*const c_void>> = Vec::new();
         let mut divisors: Vec<Vec<WfDivisor>> = Vec::new();
         for t in tables {
