@@ -126,6 +126,41 @@ struct F64 {
         const uint64_t m = (uint64_t)((uint32_t)x << (32 - K));
         return sub(q, (m << 32) - m);
     }
+    // The negated forms whose sign is free: the positive forms above end in one canonical subtraction of two values < p
+    // (K > 32: A - B, division: q - m (2^32 - 1)), so swapping its operands negates the result.
+    template <int K>
+    static WF_HD T neg_mul_pow2(T x) {
+        static_assert(K > 32 && K < 64, "shift out of range");
+        constexpr int M = K - 32;
+        const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32);
+        const uint32_t y0 = x0 << M, y1 = (x1 << M) | (x0 >> (32 - M)), y2 = x1 >> (32 - M);
+        uint32_t ah, bl;
+        const uint32_t k = __builtin_add_overflow(y0, y1, &ah);
+        const uint32_t kb = __builtin_add_overflow(y1, y2, &bl);
+        return sub(((uint64_t)kb << 32) | bl, ((uint64_t)ah << 32) | (0u - k));
+    }
+    template <int K>
+    static WF_HD T neg_div_pow2(T x) {
+        static_assert(K > 0 && K <= 32, "shift out of range");
+        const uint64_t q = x >> K;
+        const uint64_t m = (uint64_t)((uint32_t)x << (32 - K));
+        return sub((m << 32) - m, q);
+    }
+    // x * 2^E for any exponent of the group generated by 2 (order 192: 2^96 = -1).  [0, 64): the shift; [64, 96): 2^E =
+    // -2^-(96 - E); (128, 160): -2^(E - 96) with E - 96 > 32; [160, 192): 2^-(192 - E) -- all at the price of the positive
+    // form.  Only [96, 128] (-2^K with K <= 32, whose positive form ends in an addition) pays a separate negation here:
+    // callers that can hand in -x instead (a preceding subtraction with swapped operands) use mul_pow2<E - 96> themselves.
+    template <int E>
+    static WF_HD T mul_pow2_192(T x) {
+        static_assert(E >= 0 && E < 192, "exponent out of range");
+        if constexpr (E == 0) return x;
+        else if constexpr (E < 64) return mul_pow2<E>(x);
+        else if constexpr (E < 96) return neg_div_pow2<96 - E>(x);
+        else if constexpr (E == 96) return sub(0, x);
+        else if constexpr (E <= 128) return sub(0, mul_pow2<E - 96>(x));
+        else if constexpr (E < 160) return neg_mul_pow2<E - 96>(x);
+        else return div_pow2<192 - E>(x);
+    }
     static WF_HD T from_canonical(uint64_t v) { return mul(v % P, R2); }
     static WF_HD uint64_t to_canonical(T x) { return mont_reduce(x, 0); }
     static WF_HD T from_u128_canonical(u128 v) { return from_canonical((uint64_t)(v % (u128)P)); }

@@ -240,21 +240,22 @@ __device__ __forceinline__ typename F::T radix16_twiddle(typename F::T u, typena
     return F::zero();
 }
 
-template <class F, int DIR, int S, int Q, int I>
+// NEG: the difference comes out negated (t - u): how the last stage hands -X_k to a shift twiddle whose sign is not free
+template <class F, int DIR, int S, int Q, int I, bool NEG = false>
 __device__ __forceinline__ void radix16_bfly(typename F::T (&v)[16], const typename F::T (&w)[8]) {
     constexpr int half = 8 >> S;
     const typename F::T u = v[Q + I], t = v[Q + I + half];
     v[Q + I] = F::add(u, t);
     if constexpr (I == 0)
-        v[Q + I + half] = F::sub(u, t);
+        v[Q + I + half] = NEG ? F::sub(t, u) : F::sub(u, t);
     else
         v[Q + I + half] = radix16_twiddle<F, DIR, (I << S)>(u, t, w);
 }
 
-template <class F, int DIR, int S, int Q>
+template <class F, int DIR, int S, int Q, uint32_t NEGPOS = 0>
 __device__ __forceinline__ void radix16_group(typename F::T (&v)[16], const typename F::T (&w)[8]) {
     constexpr int half = 8 >> S;
-    radix16_bfly<F, DIR, S, Q, 0>(v, w);
+    radix16_bfly<F, DIR, S, Q, 0, S == 3 && ((NEGPOS >> (Q + 1)) & 1u)>(v, w);
     if constexpr (half > 1) radix16_bfly<F, DIR, S, Q, 1>(v, w);
     if constexpr (half > 2) {
         radix16_bfly<F, DIR, S, Q, 2>(v, w);
@@ -268,8 +269,10 @@ __device__ __forceinline__ void radix16_group(typename F::T (&v)[16], const type
     }
 }
 
-template <class F, int DIR>
+// NEGPOS: bit q set = the value at v[q] (q odd: the differences of the last stage) comes out negated
+template <class F, int DIR, uint32_t NEGPOS = 0>
 __device__ __forceinline__ void radix16(typename F::T (&v)[16], const typename F::T (&w)[8]) {
+    static_assert((NEGPOS & 0x5555u) == 0, "only the last stage's differences can be negated for free");
     radix16_group<F, DIR, 0, 0>(v, w);
     radix16_group<F, DIR, 1, 0>(v, w);
     radix16_group<F, DIR, 1, 8>(v, w);
@@ -277,14 +280,59 @@ __device__ __forceinline__ void radix16(typename F::T (&v)[16], const typename F
     radix16_group<F, DIR, 2, 4>(v, w);
     radix16_group<F, DIR, 2, 8>(v, w);
     radix16_group<F, DIR, 2, 12>(v, w);
-    radix16_group<F, DIR, 3, 0>(v, w);
-    radix16_group<F, DIR, 3, 2>(v, w);
-    radix16_group<F, DIR, 3, 4>(v, w);
-    radix16_group<F, DIR, 3, 6>(v, w);
-    radix16_group<F, DIR, 3, 8>(v, w);
-    radix16_group<F, DIR, 3, 10>(v, w);
-    radix16_group<F, DIR, 3, 12>(v, w);
-    radix16_group<F, DIR, 3, 14>(v, w);
+    radix16_group<F, DIR, 3, 0, NEGPOS>(v, w);
+    radix16_group<F, DIR, 3, 2, NEGPOS>(v, w);
+    radix16_group<F, DIR, 3, 4, NEGPOS>(v, w);
+    radix16_group<F, DIR, 3, 6, NEGPOS>(v, w);
+    radix16_group<F, DIR, 3, 8, NEGPOS>(v, w);
+    radix16_group<F, DIR, 3, 10, NEGPOS>(v, w);
+    radix16_group<F, DIR, 3, 12, NEGPOS>(v, w);
+    radix16_group<F, DIR, 3, 14, NEGPOS>(v, w);
+}
+
+// ---- twiddles that are powers of two (Goldilocks, transform of known direction) ------------------------------------
+// After a radix-16 round with 2^6 (2^5) bits left, output k of the item at inner position jp is multiplied by
+// w_64^(jp k) = 2^(3 jp k) (w_32^(jp k) = 2^(6 jp k)): w_64 = 8 (f64/mod.rs:248-264).  With jp uniform in a wave -- the
+// rounds below deal their work items out that way for these tile sizes -- the exponents are compile-time constants of
+// one of four (two) code paths chosen by a scalar branch: 15 shifts of 9-12 VALU instead of 15 general products of 17
+// plus their table reads, and nothing at all for jp = 0.  STEP = 3 jp (6 jp); the inverse transform multiplies by
+// 2^(192 - STEP k).  Exponents in (96, 128] are -2^K with K <= 32, whose shift ends in an addition: for those (all at
+// k >= 8, the differences of the block's last stage: checked by radix16's static_assert) the block delivers -X_k.
+template <int DIR, int STEP, int K>
+__host__ __device__ constexpr int shift_tw_exp() {
+    return DIR > 0 ? (STEP * K) % 192 : (192 - (STEP * K) % 192) % 192;
+}
+template <int DIR, int STEP, int K = 1>
+__host__ __device__ constexpr uint32_t shift_tw_negpos() {
+    if constexpr (K == 16) {
+        return 0;
+    } else {
+        constexpr int E = shift_tw_exp<DIR, STEP, K>();
+        return ((E > 96 && E <= 128) ? (1u << bitrev4(K)) : 0u) | shift_tw_negpos<DIR, STEP, K + 1>();
+    }
+}
+template <class F, int DIR, int STEP, int K = 1>
+__device__ __forceinline__ void shift_tw_apply(typename F::T (&v)[16]) {
+    if constexpr (K < 16) {
+        constexpr int E = shift_tw_exp<DIR, STEP, K>();
+        constexpr int q = bitrev4(K);
+#ifndef WF_EXP_NO_SHIFT_FENCE
+        asm volatile("" : "+v"(v[q]));
+#endif
+        if constexpr (E > 96 && E <= 128)
+            v[q] = F::template mul_pow2<E - 96>(v[q]);  // v[q] = -X_k already
+        else
+            v[q] = F::template mul_pow2_192<E>(v[q]);
+#ifndef WF_EXP_NO_SHIFT_FENCE
+        asm volatile("" : "+v"(v[q]));
+#endif
+        shift_tw_apply<F, DIR, STEP, K + 1>(v);
+    }
+}
+template <class F, int DIR, int STEP>
+__device__ __forceinline__ void radix16_shift_tw(typename F::T (&v)[16], const typename F::T (&w)[8]) {
+    radix16<F, DIR, shift_tw_negpos<DIR, STEP>()>(v, w);
+    shift_tw_apply<F, DIR, STEP>(v);
 }
 
 // In-place transform of x[D][S] in LDS; twd[e] = w_D^e.  Rounds: radix-16 (one lane per work item, 16 values in
@@ -296,10 +344,10 @@ __device__ __forceinline__ void radix16(typename F::T (&v)[16], const typename F
 // `nthr` = blockDim.x, passed in so that the tile-size-specialised kernels (LOGD != 0, below) make it a constant.
 // One radix-16 round of seg_lds_ntt at `cur` remaining bits (no trailing barrier): work item wk = lane wk % S of the
 // 16 rows base + a * 2^(cur-4), a = 0..15.  w16[j] = w_16^j.
-template <class F, int DIR, bool SWZ = false>
+template <class F, int DIR, bool SWZ = false, bool UNI = false>
 __device__ __forceinline__ void seg_round16(typename F::T *x, const typename F::T *twd, const typename F::T (&w16)[8],
                                             uint32_t logD, uint32_t cur, uint32_t nthr, const typename F::T *first,
-                                            uint32_t tid) {  // tid: threadIdx.x (persistent kernels pass opaque_tid())
+                                            uint32_t tid, bool use_first) {  // tid: threadIdx.x; first: read only if use_first
     typedef typename F::T T;
     constexpr uint32_t S = SegCfg<F>::S;
     constexpr uint32_t s_shift = S == 8 ? 3 : 2;
@@ -308,9 +356,23 @@ __device__ __forceinline__ void seg_round16(typename F::T *x, const typename F::
     const uint32_t nwork = (D >> 4) * S;
     const uint32_t tshift = logD - cur;
     const uint32_t st = m * S;
+    // Shift-twiddle rounds (radix16_shift_tw above): 2^10-row tiles at cur = 6 and 2^9-row tiles at cur = 5 -- the
+    // sizes with at least 64 work items per inner position jp.  A wave (8 lanes x 8 items; nthr is a multiple of 64)
+    // takes eight blocks p of ONE jp instead of two blocks of all four: its LDS accesses then sit 4 KiB apart (4-way
+    // on the reads, 2-way on the writes -- under the VALU issue that bounds these kernels), its twiddle exponents are
+    // compile-time constants.
+    // UNI: only from seg_lds_fixed (logD and cur compile-time constants there; as a run-time branch of the generic round
+    // loop the extra paths cost every kernel registers).
+    constexpr bool SHIFT_TW = UNI && F::FIELD_ID == 1 && DIR != 0 && !SWZ && SegCfg<F>::S == 8;
+    const bool uni = SHIFT_TW && ((logD == 10 && cur == 6) || (logD == 9 && cur == 5));
     for (uint32_t wk = tid; wk < nwork; wk += nthr) {
         const uint32_t l = wk & (S - 1), u = wk >> s_shift;
-        const uint32_t jp = u & (m - 1), p = u >> mlog;
+        uint32_t jp = u & (m - 1), p = u >> mlog;
+        if (uni) {
+            const uint32_t wv = u >> 3;
+            jp = wv & (m - 1);
+            p = ((wv >> mlog) << 3) | (u & 7u);
+        }
         const uint32_t row0 = (p << cur) + jp;
         // element offsets of the item's 16 rows row0 + a * m.  Swizzled: with m >= 16 the swizzle term is the same for all of
         // them (one XOR on the base); with m == 4 it depends on a mod 4 only (four bases, compile-time offsets); else per row
@@ -331,18 +393,35 @@ __device__ __forceinline__ void seg_round16(typename F::T *x, const typename F::
             for (int a = 0; a < 16; a++) off[a] = swz_row<SWZ>(row0 + a * m) * S + l;
         }
         T v[16];
-        if (first) {  // uniform
+        if (use_first) {  // uniform
 #pragma unroll
             for (int a = 0; a < 16; a++) v[a] = first[a];
         } else {
 #pragma unroll
             for (int a = 0; a < 16; a++) v[a] = x[off[a]];
         }
-        radix16<F, DIR>(v, w16);
-        if (jp != 0) {
-            const uint32_t e = jp << tshift;
+        bool done = false;
+        if constexpr (SHIFT_TW) {
+            if (uni) {  // uniform
+                const uint32_t ju = __builtin_amdgcn_readfirstlane(jp) * (cur == 6 ? 1u : 2u);  // STEP / 3
+                if (ju == 0)
+                    radix16<F, DIR>(v, w16);
+                else if (ju == 1)
+                    radix16_shift_tw<F, DIR, 3>(v, w16);
+                else if (ju == 2)
+                    radix16_shift_tw<F, DIR, 6>(v, w16);
+                else
+                    radix16_shift_tw<F, DIR, 9>(v, w16);
+                done = true;
+            }
+        }
+        if (!done) {
+            radix16<F, DIR>(v, w16);
+            if (jp != 0) {
+                const uint32_t e = jp << tshift;
 #pragma unroll
-            for (int k = 1; k < 16; k++) v[bitrev4(k)] = F::mul(v[bitrev4(k)], twd[e * k]);
+                for (int k = 1; k < 16; k++) v[bitrev4(k)] = F::mul(v[bitrev4(k)], twd[e * k]);
+            }
         }
 #pragma unroll
         for (int k = 0; k < 16; k++) x[off[k]] = v[bitrev4(k)];
@@ -361,7 +440,7 @@ __device__ __forceinline__ typename F::T mul_w4(typename F::T u, typename F::T t
 }
 
 // One radix-4 round (two lanes per work item, 16-byte LDS accesses for f64); w4 = w_4.
-template <class F, int DIR = 0, bool SWZ = false>
+template <class F, int DIR = 0, bool SWZ = false, bool UNI = false>
 __device__ __forceinline__ void seg_round4(typename F::T *x, const typename F::T *twd, typename F::T w4, uint32_t logD,
                                            uint32_t cur, uint32_t nthr, uint32_t tid) {
     typedef typename F::T T;
@@ -373,9 +452,18 @@ __device__ __forceinline__ void seg_round4(typename F::T *x, const typename F::T
     const uint32_t nwork = (D >> 2) * HP;
     const uint32_t tshift = logD - cur;
     const uint32_t st = m * S;
+    // cur == 3 (tiles of 2^7 and 2^11 rows): the twiddles are w_8^(jp k) = 2^(24 jp k), jp = 0, 1.  As in seg_round16 a wave
+    // (4 lane pairs x 16 items) takes sixteen blocks of one jp, and the products become shifts (or nothing).
+    constexpr bool SHIFT_TW = UNI && F::FIELD_ID == 1 && DIR != 0 && !SWZ && HP == 4;
+    const bool uni = SHIFT_TW && cur == 3 && logD >= 7;
     for (uint32_t wk = tid; wk < nwork; wk += nthr) {
         const uint32_t lp = wk & (HP - 1), u = wk >> hp_shift;
-        const uint32_t jp = u & (m - 1), p = u >> mlog;
+        uint32_t jp = u & (m - 1), p = u >> mlog;
+        if (uni) {
+            const uint32_t wv = u >> 4;
+            jp = wv & 1u;
+            p = ((wv >> 1) << 4) | (u & 15u);
+        }
         const uint32_t row0 = (p << cur) + jp;
         uint32_t o0, o1, o2, o3;  // element offsets of rows row0 + k * m
         if (!SWZ || mlog >= 4) {
@@ -416,7 +504,22 @@ __device__ __forceinline__ void seg_round4(typename F::T *x, const typename F::T
             y1.b = F::add(b, d);
             y3.b = F::sub(b, d);
         }
-        if (jp != 0) {
+        bool done = false;
+        if constexpr (SHIFT_TW) {
+            if (uni) {  // uniform
+                if (__builtin_amdgcn_readfirstlane(jp) != 0) {
+                    constexpr int E1 = shift_tw_exp<DIR, 24, 1>(), E2 = shift_tw_exp<DIR, 24, 2>(), E3 = shift_tw_exp<DIR, 24, 3>();
+                    y1.a = F::template mul_pow2_192<E1>(y1.a);
+                    y1.b = F::template mul_pow2_192<E1>(y1.b);
+                    y2.a = F::template mul_pow2_192<E2>(y2.a);
+                    y2.b = F::template mul_pow2_192<E2>(y2.b);
+                    y3.a = F::template mul_pow2_192<E3>(y3.a);
+                    y3.b = F::template mul_pow2_192<E3>(y3.b);
+                }
+                done = true;
+            }
+        }
+        if (!done && jp != 0) {
             const uint32_t e = jp << tshift;
             const T t1 = twd[e], t2 = twd[2 * e], t3 = twd[3 * e];
             y1.a = F::mul(y1.a, t1);
@@ -455,18 +558,72 @@ __device__ __forceinline__ void seg_round2(typename F::T *x, uint32_t logD, uint
     }
 }
 
-template <class F, int DIR = 0, bool SWZ = false>
+__device__ __forceinline__ uint32_t opaque_tid() {
+    // everything derived from the thread index is recomputed inside every iteration of the tile loop from this opaque
+    // copy: otherwise the compiler hoists dozens of loop-invariant addresses out of the loop and holds them in VGPRs
+    uint32_t t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
+// The rounds of a tile of 2^LOGD rows with every size a compile-time constant: what the Goldilocks tiles with power-of-two
+// inter-round twiddles run (2^10 and 2^9 rows: after the second radix-16 round; 2^7 and 2^11: in the radix-4 round).
+template <class F, int DIR, bool SWZ, int LOGD, int CUR>
+__device__ __forceinline__ void seg_lds_fixed(typename F::T *x, const typename F::T *twd, const typename F::T (&w16)[8],
+                                              typename F::T w4, uint32_t nthr, const typename F::T *first, bool use_first,
+                                              bool opaque) {
+    // opaque (persistent kernels): the thread index is re-read per round, so that what a round derives from it is not hoisted
+    // out of the kernel's tile loop and held in registers across it
+    const uint32_t tid = opaque ? opaque_tid() : threadIdx.x;
+    if constexpr (SegCfg<F>::RADIX16 && CUR >= 4) {
+        seg_round16<F, DIR, SWZ, true>(x, twd, w16, LOGD, CUR, nthr, first, tid, use_first && CUR == LOGD);
+        __syncthreads();
+        seg_lds_fixed<F, DIR, SWZ, LOGD, CUR - 4>(x, twd, w16, w4, nthr, first, false, opaque);
+    } else if constexpr (CUR >= 2) {
+        seg_round4<F, DIR, SWZ, true>(x, twd, w4, LOGD, CUR, nthr, tid);
+        __syncthreads();
+        seg_lds_fixed<F, DIR, SWZ, LOGD, CUR - 2>(x, twd, w16, w4, nthr, first, false, opaque);
+    } else if constexpr (CUR == 1) {
+        seg_round2<F, SWZ>(x, LOGD, nthr, tid);
+        __syncthreads();
+    }
+}
+
+// FIXED = false: never the fixed-size round sequences (kernels without the registers for them).  `use_first`: whether `first`
+// is to be used (a flag beside an always-valid pointer keeps the caller's register array out of scratch memory).
+template <class F, int DIR = 0, bool SWZ = false, bool FIXED = true>
 __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::T *twd, uint32_t logD, uint32_t nthr,
-                                            const typename F::T *first = nullptr) {
+                                            const typename F::T *first = nullptr, bool use_first = false,
+                                            bool opaque = false) {
     typedef typename F::T T;
     const uint32_t D = 1u << logD;
+#ifdef WF_EXP_NO_FIXED  // tuning: the generic round loop everywhere (the code of before the shift-twiddle rounds)
+    constexpr bool fixed_ok = false;
+#else
+    constexpr bool fixed_ok = FIXED;
+#endif
+    if constexpr (fixed_ok && F::FIELD_ID == 1 && DIR != 0 && !SWZ) {  // a transform of known direction reads no radix-16 / w_4 constants
+        T w16[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) w16[j] = F::zero();
+        if (logD == 10) {  // uniform
+            seg_lds_fixed<F, DIR, SWZ, 10, 10>(x, twd, w16, F::zero(), nthr, first, use_first, opaque);
+            return;
+        }
+#ifdef WF_EXP_FIXED7
+        if (logD == 7) {
+            seg_lds_fixed<F, DIR, SWZ, 7, 7>(x, twd, w16, F::zero(), nthr, first, use_first, opaque);
+            return;
+        }
+#endif
+    }
     uint32_t cur = logD;
     if (SegCfg<F>::RADIX16 && logD >= 4) {
         T w16[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) w16[j] = twd[j * (D >> 4)];
         while (cur >= 4) {
-            seg_round16<F, DIR, SWZ>(x, twd, w16, logD, cur, nthr, cur == logD ? first : nullptr, threadIdx.x);
+            seg_round16<F, DIR, SWZ>(x, twd, w16, logD, cur, nthr, first, threadIdx.x, use_first && cur == logD);
             cur -= 4;
             __syncthreads();
         }
@@ -483,14 +640,6 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
         }
         __syncthreads();
     }
-}
-
-__device__ __forceinline__ uint32_t opaque_tid() {
-    // everything derived from the thread index is recomputed inside every iteration of the tile loop from this opaque
-    // copy: otherwise the compiler hoists dozens of loop-invariant addresses out of the loop and holds them in VGPRs
-    uint32_t t = threadIdx.x;
-    asm volatile("" : "+v"(t));
-    return t;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -704,7 +853,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_strided(SegArgs<F> a) {
         if (k < D) aux[k] = fo[q];
     }
 #ifndef WF_EXP_SKIP_NTT  // tuning experiment: memory phases only (scripts/exp_variants.sh)
-    seg_lds_ntt<F, EVAL ? 1 : -1, SWZ>(x, twd, a.logD, NT, direct ? vr : nullptr);
+    seg_lds_ntt<F, EVAL ? 1 : -1, SWZ>(x, twd, a.logD, NT, vr, direct);
 #else
     if (direct && has16) {
 #pragma unroll
@@ -1298,10 +1447,18 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512))
             WF_TILE_PUT(6, q6);
             WF_TILE_PUT(7, q7);
 #undef WF_TILE_PUT
+            // the rows are in LDS: end the registers' live ranges here.  They are refilled only `if (more)` below, so left alone
+            // their old contents count as live through the transform and the hashing of the last tile's iteration -- 32 VGPRs
+            // that the transform needs (a constant costs nothing until the iteration that leaves the loop)
+            q0 = q1 = q2 = q3 = q4 = q5 = q6 = q7 = make_uint4(0, 0, 0, 0);
         }
         __syncthreads();
         WF_STAMP(0);  // tile in LDS (waits for the prefetched rows)
-        seg_lds_ntt<F, 1, SWZ>(x, twd, a.logD, NT);
+#ifdef WF_EXP_NO_FIXED_LAST
+        seg_lds_ntt<F, 1, SWZ, false>(x, twd, a.logD, NT);
+#else
+        seg_lds_ntt<F, 1, SWZ>(x, twd, a.logD, NT, nullptr, false, true);
+#endif
         WF_STAMP(1);  // transform
 
         // row stores: lane pair (2l, 2l+1) of row position pos -> its place in LDE row k * rows_per_k + c of its trace

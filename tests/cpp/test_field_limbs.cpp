@@ -45,6 +45,29 @@ static u128 pattern(long mode) {
 static U128 n(u128 v) { return U128{(uint64_t)v, (uint64_t)(v >> 64)}; }
 static u128 w(U128 v) { return ((u128)v.hi << 64) | v.lo; }
 
+// x * 2^E mod p by repeated doubling on 128-bit integers (2^192 = 1: any E in [0, 192))
+static uint64_t shl_mod(uint64_t x, int e) {
+    u128 v = x;
+    const u128 P64 = wf::F64::P;
+    for (int i = 0; i < e; i++) v = (v << 1) % P64;
+    return (uint64_t)v;
+}
+template <int E>
+static long chk_pow2_192(uint64_t x) {
+    long bad = 0;
+    if constexpr (E < 192) {
+        const uint64_t want = shl_mod(x, E);
+        if (wf::F64::mul_pow2_192<E>(x) != want) bad++;
+        // the form the transform rounds use for (96, 128]: the caller hands in -x, the shift is E - 96
+        if constexpr (E > 96 && E <= 128) {
+            const uint64_t nx = x ? wf::F64::P - x : 0;
+            if (wf::F64::mul_pow2<E - 96>(nx) != want) bad++;
+        }
+        bad += chk_pow2_192<E + 1>(x);
+    }
+    return bad;
+}
+
 int main(int argc, char **argv) {
     const long iters = argc > 1 ? atol(argv[1]) : 400000;
     P = F128::P();
@@ -85,6 +108,10 @@ int main(int argc, char **argv) {
                                  0x0FFFFFFFFFFFFFFFull, 0xFFFFFFFFull << 4, 0xFFFFFFFFull << 16, 0xFFFFFFFFull << 28};
         for (uint64_t e : edge) chk(e % F64::P);
         for (long it = 0; it < iters; it++) chk(rnd() % F64::P);
+        // every exponent of the order-192 group (the wave-uniform twiddles w_64^(j k) = 2^(3 j k), w_32^k = 2^(6 k), w_8^k = 2^(24 k)
+        // and their inverses are among them)
+        for (uint64_t e : edge) bad += chk_pow2_192<0>(e % F64::P);
+        for (long it = 0; it < iters / 100 + 1000; it++) bad += chk_pow2_192<0>(rnd() % F64::P);
     }
     printf("checked %ld triples, bad=%ld\n", iters, bad);
     if (bad == 0) printf("ALL OK\n");
