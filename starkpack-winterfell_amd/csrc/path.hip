@@ -452,6 +452,11 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
                 : multi ? (a.pad_traces ? (small ? (const void *)k_seg_last_hash<F, true, true, false, true> : (const void *)k_seg_last_hash<F, true, true>)
                                         : (small ? (const void *)k_seg_last_hash<F, true, false, false, true> : (const void *)k_seg_last_hash<F, true, false>))
                         : (a.pad_traces ? (const void *)k_seg_last_hash<F, false, true> : (const void *)k_seg_last_hash<F, false, false>);
+#ifndef WF_EXP_NO_SPEC_LAST
+            // one segment of one trace in 2^10-row f64 tiles (the bench workload): the tile-size-specialised instantiation
+            if (F::BYTES == 8 && !chunked && !multi && !a.pad_traces && a.logD == 10 && !ctx->tune.no_specialized)
+                kern = (const void *)k_seg_last_hash<F, false, false, false, false, F::BYTES == 8 ? 10 : 0>;
+#endif
             if (chunked) {
                 int rcc = ensure(ctx, ctx->hash_tmp, (size_t)launch_rows * n_chunks * 32);
                 if (rcc) return rcc;

@@ -1309,14 +1309,14 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
 template <class F, bool MULTI, bool PADT = false, bool CHUNKED = false, bool SMALL = false, int LOGD = 0>  // PADT: SegArgs::pad_traces (kept out of the other instantiations' registers)
 __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512)) k_seg_last_hash(SegArgs<F> a) {  // f128 tiles: D <= 2^10
     typedef typename F::T T;
-    if (LOGD) a.logD = LOGD;
+    const uint32_t logD_ = LOGD ? (uint32_t)LOGD : a.logD;  // (a local, not a.logD = LOGD: a modified copy of the arguments would live in scratch, where decode() indexes prev_log[])
     const uint32_t NT = tile_threads<LOGD>();
     typedef Pair<T> P2;
     constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;
     constexpr uint32_t hp_shift = HP == 4 ? 2 : 1;
     constexpr uint32_t WPE = F::BYTES / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const uint32_t D = 1u << a.logD;
+    const uint32_t D = 1u << logD_;
     T *x = reinterpret_cast<T *>(smem_raw);
     T *twd = x + (size_t)D * S;
 #ifdef WF_EXP_SWIZZLE
@@ -1328,7 +1328,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512))
     const uint64_t total = (uint64_t)a.n_cosets * a.O * n_chunks;  // tickets: (coset, row block[, chunk])
     const uint64_t seg_elems = ((uint64_t)1 << a.logN) * S;
     const uint32_t step = NT;
-    const uint32_t out_shift = a.logN - a.logD;
+    const uint32_t out_shift = a.logN - logD_;
     const uint32_t k_stride = a.rows_per_k * (uint32_t)a.row_width;  // < 2^19
     const uint32_t hash_bytes = a.hash_epr * F::BYTES;             // <= 1024 (one chunk) unless CHUNKED
 
@@ -1359,7 +1359,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512))
         }
     };
     auto tile_src = [&](uint32_t c, uint64_t o, uint32_t g) -> const T * {
-        return a.src + ((uint64_t)c * a.n_seg + g) * seg_elems + (o << a.logD) * S;
+        return a.src + ((uint64_t)c * a.n_seg + g) * seg_elems + (o << logD_) * S;
     };
 
     // Tickets are handed out dynamically, per XCD (work-groups are dispatched to XCD blockIdx % 8): ticket index =
@@ -1455,9 +1455,9 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512))
         __syncthreads();
         WF_STAMP(0);  // tile in LDS (waits for the prefetched rows)
 #ifdef WF_EXP_NO_FIXED_LAST
-        seg_lds_ntt<F, 1, SWZ, false>(x, twd, a.logD, NT);
+        seg_lds_ntt<F, 1, SWZ, false>(x, twd, logD_, NT);
 #else
-        seg_lds_ntt<F, 1, SWZ>(x, twd, a.logD, NT, nullptr, false, true);
+        seg_lds_ntt<F, 1, SWZ>(x, twd, logD_, NT, nullptr, false, true);
 #endif
         WF_STAMP(1);  // transform
 
@@ -1490,19 +1490,19 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512))
                 }
             }
             if (pa) {
-                const uint32_t k0 = seg_digit_reverse<F>(pos0, a.logD);
+                const uint32_t k0 = seg_digit_reverse<F>(pos0, logD_);
                 const bool tail = F::BYTES == 16 && a.tail_pad && g + 1 == a.n_seg;  // (single trace: every lane has its pa)
                 for (uint32_t pj = 0; pj < D; pj += pstride) {
 #if defined(WF_EXP_LOCAL_STORE) && WF_EXP_LOCAL_STORE == 1  // diagnostic (wrong output): rows of a tile next to each other, cosets interleaved
-                    const uint64_t k = (o << a.logD) + pos0 + pj;
+                    const uint64_t k = (o << logD_) + pos0 + pj;
 #elif defined(WF_EXP_LOCAL_STORE)  // diagnostic (wrong output): the tile written as one contiguous 64 KiB run
                     const uint64_t k = 0;
 #else
-                    const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, a.logD)) << out_shift);
+                    const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, logD_)) << out_shift);
 #endif
                     const P2 v = *reinterpret_cast<P2 *>(x + swz_row<SWZ>(pos0 + pj) * S + lane_a);
 #if defined(WF_EXP_LOCAL_STORE) && WF_EXP_LOCAL_STORE == 2
-                    const uint64_t off = (((uint64_t)c * a.O + o) << a.logD) * S + (uint64_t)(pos0 + pj) * S - (uint64_t)c * a.row_width;
+                    const uint64_t off = (((uint64_t)c * a.O + o) << logD_) * S + (uint64_t)(pos0 + pj) * S - (uint64_t)c * a.row_width;
 #else
                     const uint64_t off = (uint64_t)(uint32_t)k * k_stride;
 #endif
@@ -1568,12 +1568,12 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512))
                 const uint4 lo = make_uint4(cv[0], cv[1], cv[2], cv[3]), hi = make_uint4(cv[4], cv[5], cv[6], cv[7]);
                 if (last) {
 #if defined(WF_EXP_LOCAL_STORE) && WF_EXP_LOCAL_STORE == 1
-                    const uint64_t k = (o << a.logD) + pos;
+                    const uint64_t k = (o << logD_) + pos;
                     const uint64_t row = (uint64_t)(uint32_t)k * a.rows_per_k + c;
 #elif defined(WF_EXP_LOCAL_STORE)
-                    const uint64_t row = (((uint64_t)c * a.O + o) << a.logD) + pos;
+                    const uint64_t row = (((uint64_t)c * a.O + o) << logD_) + pos;
 #else
-                    const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << out_shift);
+                    const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, logD_) << out_shift);
                     const uint64_t row = (uint64_t)(uint32_t)k * a.rows_per_k + c;
 #endif
                     uint4 *dl = reinterpret_cast<uint4 *>(CHUNKED ? a.chunk_cvs + (row * n_chunks + ch) * 8 : a.leaves + row * 8);
