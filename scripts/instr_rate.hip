@@ -30,6 +30,22 @@ KERNEL(k_cmp64, asm volatile("v_cmp_lt_u64 vcc, %0, %1" : : "v"(p), "v"(q) : "vc
 KERNEL(k_fma32, asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(d)); asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(c) : "v"(d), "v"(b));)
 KERNEL(k_mad24, asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(d)); asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(c) : "v"(d), "v"(b));)
 KERNEL(k_pkfma, asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p) : "v"(q)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(q) : "v"(p));)
+// round 3: candidates for cheaper BLAKE3 rotations / field shifts
+KERNEL(k_xor_sdwa, asm volatile("v_xor_b32_sdwa %0, %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(a) : "v"(b)); asm volatile("v_xor_b32_sdwa %0, %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(c) : "v"(d));)
+KERNEL(k_xor_sdwa_keep, asm volatile("v_xor_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(a) : "v"(b), "v"(d)); asm volatile("v_xor_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(c) : "v"(d), "v"(b));)
+KERNEL(k_perm, asm volatile("v_perm_b32 %0, %0, %0, %1" : "+v"(a) : "v"(b)); asm volatile("v_perm_b32 %0, %0, %0, %1" : "+v"(c) : "v"(d));)
+KERNEL(k_xad, asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(d)); asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(c) : "v"(d), "v"(b));)
+KERNEL(k_lshl, asm volatile("v_lshlrev_b32 %0, 7, %0" : "+v"(a)); asm volatile("v_lshlrev_b32 %0, 9, %0" : "+v"(c));)
+KERNEL(k_lshl_or, asm volatile("v_lshl_or_b32 %0, %0, 7, %1" : "+v"(a) : "v"(b)); asm volatile("v_lshl_or_b32 %0, %0, 9, %1" : "+v"(c) : "v"(d));)
+KERNEL(k_lshl64, asm volatile("v_lshlrev_b64 %0, 7, %0" : "+v"(p)); asm volatile("v_lshlrev_b64 %0, 9, %0" : "+v"(q));)
+KERNEL(k_mov, asm volatile("v_mov_b32 %0, %1" : "=v"(a) : "v"(b)); asm volatile("v_mov_b32 %0, %1" : "=v"(c) : "v"(d));)
+KERNEL(k_mov_dpp, asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(b)); asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf" : "+v"(c) : "v"(d));)
+KERNEL(k_add_dpp, asm volatile("v_add_u32_dpp %0, %0, %1 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(b)); asm volatile("v_add_u32_dpp %0, %0, %1 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf" : "+v"(c) : "v"(d));)
+KERNEL(k_mul24, asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a) : "v"(b)); asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(c) : "v"(d));)
+KERNEL(k_addco_only, asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(a) : "v"(b) : "vcc"); asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(c) : "v"(d) : "vcc");)
+KERNEL(k_pk_add16, asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a) : "v"(b)); asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(c) : "v"(d));)
+KERNEL(k_bfi, asm volatile("v_bfi_b32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(d)); asm volatile("v_bfi_b32 %0, %0, %1, %2" : "+v"(c) : "v"(d), "v"(b));)
+KERNEL(k_mad64_const0, asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p) : "v"(b), "v"(d) : "vcc"); asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(q) : "v"(d), "v"(b) : "vcc");)
 
 template <class K>
 static void run(const char *name, K kern, uint32_t *out) {
@@ -68,5 +84,20 @@ int main() {
     run("v_fma_f32", k_fma32, out);
     run("v_mad_u32_u24", k_mad24, out);
     run("v_pk_fma_f32", k_pkfma, out);
+    run("xor_sdwa_pad", k_xor_sdwa, out);
+    run("xor_sdwa_keep", k_xor_sdwa_keep, out);
+    run("v_perm_b32", k_perm, out);
+    run("v_xad_u32", k_xad, out);
+    run("v_lshlrev_b32", k_lshl, out);
+    run("v_lshl_or_b32", k_lshl_or, out);
+    run("v_lshlrev_b64", k_lshl64, out);
+    run("v_mov_b32", k_mov, out);
+    run("v_mov_dpp", k_mov_dpp, out);
+    run("v_add_dpp", k_add_dpp, out);
+    run("v_mul_u32_u24", k_mul24, out);
+    run("v_add_co only", k_addco_only, out);
+    run("v_pk_add_u16", k_pk_add16, out);
+    run("v_bfi_b32", k_bfi, out);
+    run("mad64 (+0)", k_mad64_const0, out);
     return 0;
 }

@@ -589,33 +589,40 @@ __device__ __forceinline__ void seg_lds_fixed(typename F::T *x, const typename F
     }
 }
 
-// FIXED = false: never the fixed-size round sequences (kernels without the registers for them).  `use_first`: whether `first`
-// is to be used (a flag beside an always-valid pointer keeps the caller's register array out of scratch memory).
-template <class F, int DIR = 0, bool SWZ = false, bool FIXED = true>
+// FIXMASK: bit L set = tiles of 2^L rows run the fixed-size round sequence (L = 7, 9, 10, 11: the sizes with shift twiddles
+// between rounds); each kernel names the sizes it has the registers for.  `use_first`: whether `first` is to be used (a
+// flag beside an always-valid pointer keeps the caller's register array out of scratch memory).
+constexpr uint32_t FIX10 = 1u << 10, FIX7 = 1u << 7, FIX9 = 1u << 9, FIX11 = 1u << 11;
+#ifndef WF_FIX_BIG
+#define WF_FIX_BIG (FIX10 | FIX11)  // the fused last pass on tiles of 2^10 / 2^11 rows
+#endif
+template <class F, int DIR = 0, bool SWZ = false, uint32_t FIXMASK = FIX10>
 __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::T *twd, uint32_t logD, uint32_t nthr,
                                             const typename F::T *first = nullptr, bool use_first = false,
                                             bool opaque = false) {
     typedef typename F::T T;
     const uint32_t D = 1u << logD;
 #ifdef WF_EXP_NO_FIXED  // tuning: the generic round loop everywhere (the code of before the shift-twiddle rounds)
-    constexpr bool fixed_ok = false;
+    constexpr uint32_t fixmask = 0;
 #else
-    constexpr bool fixed_ok = FIXED;
+    constexpr uint32_t fixmask = FIXMASK;
 #endif
-    if constexpr (fixed_ok && F::FIELD_ID == 1 && DIR != 0 && !SWZ) {  // a transform of known direction reads no radix-16 / w_4 constants
+    if constexpr (fixmask != 0 && F::FIELD_ID == 1 && DIR != 0 && !SWZ) {  // a transform of known direction reads no radix-16 / w_4 constants
         T w16[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) w16[j] = F::zero();
-        if (logD == 10) {  // uniform
-            seg_lds_fixed<F, DIR, SWZ, 10, 10>(x, twd, w16, F::zero(), nthr, first, use_first, opaque);
-            return;
-        }
-#ifdef WF_EXP_FIXED7
-        if (logD == 7) {
-            seg_lds_fixed<F, DIR, SWZ, 7, 7>(x, twd, w16, F::zero(), nthr, first, use_first, opaque);
-            return;
-        }
-#endif
+#define WF_FIXED_SIZE(L)                                                                                        \
+    if constexpr ((fixmask & (1u << (L))) != 0) {                                                               \
+        if (logD == (L)) { /* uniform */                                                                        \
+            seg_lds_fixed<F, DIR, SWZ, (L), (L)>(x, twd, w16, F::zero(), nthr, first, use_first, opaque);       \
+            return;                                                                                             \
+        }                                                                                                       \
+    }
+        WF_FIXED_SIZE(10)
+        WF_FIXED_SIZE(7)
+        WF_FIXED_SIZE(9)
+        WF_FIXED_SIZE(11)
+#undef WF_FIXED_SIZE
     }
     uint32_t cur = logD;
     if (SegCfg<F>::RADIX16 && logD >= 4) {
@@ -853,7 +860,8 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_strided(SegArgs<F> a) {
         if (k < D) aux[k] = fo[q];
     }
 #ifndef WF_EXP_SKIP_NTT  // tuning experiment: memory phases only (scripts/exp_variants.sh)
-    seg_lds_ntt<F, EVAL ? 1 : -1, SWZ>(x, twd, a.logD, NT, vr, direct);
+    // (the generic kernel runs the generic round loop: with the 16 direct values in registers it has no room for more)
+    seg_lds_ntt<F, EVAL ? 1 : -1, SWZ, (LOGD ? (1u << LOGD) : 0u)>(x, twd, a.logD, NT, direct ? vr : nullptr, direct);
 #else
     if (direct && has16) {
 #pragma unroll
@@ -1125,7 +1133,10 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
     }
     __syncthreads();
 #ifndef WF_EXP_SKIP_NTT
-    seg_lds_ntt<F, OUT == SEG_OUT_ROWS ? 1 : -1>(x, twd, a.logD, NT);
+#ifndef WF_FIX_LAST
+#define WF_FIX_LAST (FIX10 | FIX9)
+#endif
+    seg_lds_ntt<F, OUT == SEG_OUT_ROWS ? 1 : -1, false, WF_FIX_LAST>(x, twd, a.logD, NT);
 #endif
 
     // Store.  Work item = (row position pos, lane pair); this thread's positions are pos0 + j * pstride, j = 0, 1, ..
@@ -1454,11 +1465,8 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512))
         }
         __syncthreads();
         WF_STAMP(0);  // tile in LDS (waits for the prefetched rows)
-#ifdef WF_EXP_NO_FIXED_LAST
-        seg_lds_ntt<F, 1, SWZ, false>(x, twd, logD_, NT);
-#else
-        seg_lds_ntt<F, 1, SWZ>(x, twd, logD_, NT, nullptr, false, true);
-#endif
+        // (SMALL instantiations -- tiles of at most 2^9 rows -- have no 128-register cap: the 2^7- and 2^9-row sequences too)
+        seg_lds_ntt<F, 1, SWZ, (LOGD ? (1u << LOGD) : SMALL ? (FIX7 | FIX9) : WF_FIX_BIG)>(x, twd, logD_, NT, nullptr, false, true);
         WF_STAMP(1);  // transform
 
         // row stores: lane pair (2l, 2l+1) of row position pos -> its place in LDE row k * rows_per_k + c of its trace
