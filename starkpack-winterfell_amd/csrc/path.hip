@@ -338,6 +338,9 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             constexpr bool F8 = F::BYTES == 8;  // (the specialised instantiations exist for f64 only)
             switch (a.logD) {
                 case 10: kern = d.rows_out ? (const void *)k_seg_strided<F, 1, false, F8 ? 10 : 0> : (const void *)k_seg_strided<F, 0, false, F8 ? 10 : 0>; break;
+#ifndef WF_EXP_NO_SPEC9
+                case 9: kern = d.rows_out ? (const void *)k_seg_strided<F, 1, false, F8 ? 9 : 0> : (const void *)k_seg_strided<F, 0, false, F8 ? 9 : 0>; break;
+#endif
 #ifdef WF_EXP_SPEC7
                 // 2^7-row tiles (the middle digit of the 2^22 plan): the radix-4 round's twiddles w_8^(j k) are shifts there
                 case 7: kern = d.rows_out ? (const void *)k_seg_strided<F, 1, false, F8 ? 7 : 0> : (const void *)k_seg_strided<F, 0, false, F8 ? 7 : 0>; break;
