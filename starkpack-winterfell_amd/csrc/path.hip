@@ -341,6 +341,9 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
 #ifndef WF_EXP_NO_SPEC9
                 case 9: kern = d.rows_out ? (const void *)k_seg_strided<F, 1, false, F8 ? 9 : 0> : (const void *)k_seg_strided<F, 0, false, F8 ? 9 : 0>; break;
 #endif
+#ifdef WF_EXP_SPEC8
+                case 8: kern = d.rows_out ? (const void *)k_seg_strided<F, 1, false, F8 ? 8 : 0> : (const void *)k_seg_strided<F, 0, false, F8 ? 8 : 0>; break;
+#endif
 #ifdef WF_EXP_SPEC7
                 // 2^7-row tiles (the middle digit of the 2^22 plan): the radix-4 round's twiddles w_8^(j k) are shifts there
                 case 7: kern = d.rows_out ? (const void *)k_seg_strided<F, 1, false, F8 ? 7 : 0> : (const void *)k_seg_strided<F, 0, false, F8 ? 7 : 0>; break;
@@ -487,10 +490,22 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             }
         } else if (d.rows_out && packed)
             hipLaunchKernelGGL((k_seg_last<F, SEG_OUT_ROWS, true>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
-        else if (d.rows_out)
-            hipLaunchKernelGGL((k_seg_last<F, SEG_OUT_ROWS>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
-        else
-            hipLaunchKernelGGL((k_seg_last<F, SEG_OUT_SEG>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
+        else {
+            // one work-group per tile: 2^10- and 2^9-row f64 tiles run the tile-size-specialised instantiations
+            const void *kern = d.rows_out ? (const void *)k_seg_last<F, SEG_OUT_ROWS> : (const void *)k_seg_last<F, SEG_OUT_SEG>;
+#ifndef WF_EXP_NO_SPEC_LAST1
+            constexpr bool F8 = F::BYTES == 8;
+            if (F8 && threads * 2 == (1u << a.logD) && !ctx->tune.no_specialized) {
+                if (a.logD == 10)
+                    kern = d.rows_out ? (const void *)k_seg_last<F, SEG_OUT_ROWS, false, F8 ? 10 : 0> : (const void *)k_seg_last<F, SEG_OUT_SEG, false, F8 ? 10 : 0>;
+                else if (a.logD == 9)
+                    kern = d.rows_out ? (const void *)k_seg_last<F, SEG_OUT_ROWS, false, F8 ? 9 : 0> : (const void *)k_seg_last<F, SEG_OUT_SEG, false, F8 ? 9 : 0>;
+            }
+#endif
+            if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            void *kargs[] = {&a};
+            HIP_TRY(hipLaunchKernel(kern, dim3((uint32_t)grid), dim3(threads), kargs, lds, st));
+        }
         HIP_TRY(hipGetLastError());
     }
     return 0;

@@ -622,6 +622,7 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
         WF_FIXED_SIZE(7)
         WF_FIXED_SIZE(9)
         WF_FIXED_SIZE(11)
+        WF_FIXED_SIZE(8)
 #undef WF_FIXED_SIZE
     }
     uint32_t cur = logD;
@@ -969,13 +970,13 @@ __device__ __forceinline__ void store_rows_narrow(const typename F::T *x, const 
 template <class F, int OUT, bool PACKED = false, int LOGD = 0>
 __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
     typedef typename F::T T;
-    if (LOGD) a.logD = LOGD;
+    const uint32_t logD_ = LOGD ? (uint32_t)LOGD : a.logD;  // (a local: see k_seg_last_hash)
     const uint32_t NT = tile_threads<LOGD>();
     typedef Pair<T> P2;
     constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;
     constexpr uint32_t hp_shift = HP == 4 ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const uint32_t D = 1u << a.logD;
+    const uint32_t D = 1u << logD_;
     T *x = reinterpret_cast<T *>(smem_raw);
     T *twd = x + (size_t)D * S;
     T *aux = twd;  // input factors of a single-pass evaluation: same LDS as the twiddles, which are written after the fill
@@ -988,7 +989,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
     const uint64_t o = q32 & (uint32_t)(a.O - 1);
     const uint32_t g = q32 >> logO;
     const uint64_t seg_elems = ((uint64_t)1 << a.logN) * S;
-    const T *src = a.src + (a.src_shared ? (uint64_t)g : (uint64_t)c * a.n_seg + g) * seg_elems + (o << a.logD) * S;
+    const T *src = a.src + (a.src_shared ? (uint64_t)g : (uint64_t)c * a.n_seg + g) * seg_elems + (o << logD_) * S;
 
     // natural-order contribution of the earlier digits: o = (k1, k2, ..), k1 most significant -> k1 + N1*k2 + ..
     uint64_t rev_o = 0;
@@ -1136,22 +1137,22 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
 #ifndef WF_FIX_LAST
 #define WF_FIX_LAST (FIX10 | FIX9)
 #endif
-    seg_lds_ntt<F, OUT == SEG_OUT_ROWS ? 1 : -1, false, WF_FIX_LAST>(x, twd, a.logD, NT);
+    seg_lds_ntt<F, OUT == SEG_OUT_ROWS ? 1 : -1, false, (LOGD ? (1u << LOGD) : WF_FIX_LAST)>(x, twd, logD_, NT);
 #endif
 
     // Store.  Work item = (row position pos, lane pair); this thread's positions are pos0 + j * pstride, j = 0, 1, ..
     // (pstride is a power of two > pos0), so its output indices are rev(pos0) | rev(j * pstride): the per-thread
     // part is computed once, the per-iteration part is wave-uniform (scalar ALU), and everything that depends only on
     // the lane (column, trace, destination base) is hoisted out of the loop.
-    const uint32_t out_shift = a.logN - a.logD;
+    const uint32_t out_shift = a.logN - logD_;
     const uint32_t pstride = NT >> hp_shift, pos0 = threadIdx.x >> hp_shift;
-    const uint32_t k0 = seg_digit_reverse<F>(pos0 < D ? pos0 : 0, a.logD);
+    const uint32_t k0 = seg_digit_reverse<F>(pos0 < D ? pos0 : 0, logD_);
     const bool has_rows = pos0 < D;  // more threads than work items in tiny transforms
     if (OUT == SEG_OUT_SEG) {
         if (!has_rows) return;
         T *dst = a.dst + ((uint64_t)c * a.n_seg + g) * seg_elems + lane_a;
         for (uint32_t pj = 0; pj < D; pj += pstride) {
-            const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, a.logD)) << out_shift);
+            const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, logD_)) << out_shift);
             P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
             if (a.scale_on) {
                 v.a = F::mul(v.a, a.scale);
@@ -1213,7 +1214,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
             const uint32_t n_items = (D << cpr) * upr;
             for (uint32_t idx = threadIdx.x; idx < n_items; idx += NT) {
                 const uint32_t u = idx & (upr - 1), rj = idx / upr, j = rj & ((1u << cpr) - 1), pos = rj >> cpr;
-                const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << out_shift);
+                const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, logD_) << out_shift);
                 T *row = a.dst + (uint64_t)(uint32_t)k * k_stride + (((uint64_t)c << cpr) + j) * a.row_width + EPU * u;
                 const T *xs = x + pos * S + (j << lg) + EPU * u;
                 if (EPU == 2) {
@@ -1229,7 +1230,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
         }
         const bool tail = !PACKED && F::BYTES == 16 && a.tail_pad && g + 1 == a.n_seg;  // (single trace: every lane has its pa)
         for (uint32_t pj = 0; (pa || pb) && pj < D; pj += pstride) {
-            const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, a.logD)) << out_shift);
+            const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, logD_)) << out_shift);
             const P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
             const uint64_t off = (uint64_t)(uint32_t)k * k_stride;  // k < 2^32 rows: one 32 x 32 -> 64 multiply
             if (tail) store_pair(pa + off + S, P2{F::zero(), F::zero()});
@@ -1256,7 +1257,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
         constexpr uint32_t WPE = F::BYTES / 4;
         const uint32_t lg = a.lg_log, ncos = 1u << a.cpr_log;
         for (uint32_t pos = threadIdx.x; pos < D; pos += NT) {
-            const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << (a.logN - a.logD));
+            const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, logD_) << (a.logN - logD_));
             uint32_t *leaf = a.leaves + ((uint64_t)(uint32_t)k * a.rows_per_k + ((uint64_t)c << a.cpr_log)) * 8;
 #pragma unroll 1
             for (uint32_t j = 0; j < ncos; j++) {
@@ -1291,7 +1292,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
             for (uint32_t e = 0; e < S; e++) elem_words<F>(ev[e], &m[e * WPE]);
             b3::set_iv(out);
             b3::compress(out, m, 0, 0, a.hash_epr * F::BYTES, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT);
-            const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, a.logD) << (a.logN - a.logD));
+            const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, logD_) << (a.logN - logD_));
             uint4 *dl = reinterpret_cast<uint4 *>(a.leaves + ((uint64_t)(uint32_t)k * a.rows_per_k + c) * 8);
             dl[0] = make_uint4(out[0], out[1], out[2], out[3]);
             dl[1] = digest_hi(out[4], out[5], out[6], out[7], a.digest_words);
