@@ -33,8 +33,10 @@ struct Plan {
 
 // digits of at most `max_digit` bits (what one work-group can hold in LDS: 11 for f64, 10 for f128), balanced.
 // `avoid_full`: a plan of two maximal digits would run both passes with a single work-group per CU (the tile fills
-// the LDS), which measures ~10 % slower than three passes over smaller tiles (2^22 f64, 2^20 f128).
-static Plan make_plan(uint32_t L, uint32_t max_digit, bool avoid_full = false, bool few_tiles = false) {
+// the LDS), which measures ~10 % slower than three passes over smaller tiles (2^22 f64; f128 tiles of 2^10 rows are
+// half a CU's LDS in both passes since the strided pass time-shares one table region: 2^20 f128 runs [10, 10],
+// 12-15 % faster than [7, 7, 6]).  `max_last`: a maximal digit goes to the last pass.
+static Plan make_plan(uint32_t L, uint32_t max_digit, bool avoid_full = false, bool few_tiles = false, bool max_last = false) {
     Plan p;
     p.n_pass = L <= 10 ? 1 : (int)((L + max_digit - 1) / max_digit);
     if (avoid_full && p.n_pass == 2 && L == 2 * max_digit) p.n_pass = 3;
@@ -45,7 +47,7 @@ static Plan make_plan(uint32_t L, uint32_t max_digit, bool avoid_full = false, b
     for (int i = 0; i < p.n_pass; i++) p.dig[i] = base + (i < (int)rem ? 1 : 0);
     // a maximal digit goes last: the last pass keeps one table less in LDS (an f128 2^10-row tile leaves room for two
     // work-groups per CU there, not in a strided pass) -- f128 2^19 x 10: 2.99 -> 2.81 ms, f64 2^21 x 64: 20.9 -> 19.8 ms
-    if (avoid_full && p.n_pass >= 2 && p.dig[0] == max_digit && p.dig[p.n_pass - 1] < max_digit)
+    if (max_last && p.n_pass >= 2 && p.dig[0] == max_digit && p.dig[p.n_pass - 1] < max_digit)
         std::swap(p.dig[0], p.dig[p.n_pass - 1]);
     return p;
 }
@@ -56,7 +58,7 @@ static Plan seg_plan(uint32_t logN, uint32_t n_seg, uint32_t digit_cap = 0, bool
     uint32_t max_digit = F::BYTES == 8 ? 11 : 10;
     // wf_tuning::max_digit (tests / tuning): force more, smaller passes
     if (digit_cap >= 4 && digit_cap < max_digit && (logN + digit_cap - 1) / digit_cap <= 4) max_digit = digit_cap;  // Plan holds 4 digits
-    return make_plan(logN, max_digit, !full_tiles, n_seg <= 8);
+    return make_plan(logN, max_digit, !full_tiles && F::BYTES == 8, n_seg <= 8, !full_tiles);
 }
 
 template <class F>
@@ -166,7 +168,12 @@ static int seg_launch_dims(uint32_t logD, uint32_t &threads, size_t &lds, bool l
     const size_t D = (size_t)1 << logD;
     // tile + digit twiddles (+ the factor table of a strided pass; a last pass keeps its input factors where the
     // twiddles go afterwards: a 2^10-row f128 tile is 80 KiB, two work-groups per CU)
-    lds = (D * SegCfg<F>::S + (last_pass ? 1 : 2) * D) * sizeof(typename F::T);
+#ifdef WF_EXP_TWO_TABLES
+    constexpr bool one_table = false;
+#else
+    constexpr bool one_table = F::BYTES == 16;  // k_seg_strided, ONE_TABLE: the f128 strided pass time-shares one table region
+#endif
+    lds = (D * SegCfg<F>::S + (last_pass || one_table ? 1 : 2) * D) * sizeof(typename F::T);
     if (lds > 160 * 1024) return fail(WF_ERR_ARG, "internal: pass needs %zu bytes of LDS", lds);
     // one work item of the widest round per thread (radix-16 on 8 lanes for f64, radix-4 on lane pairs for f128: D/2
     // items either way), so that no wave idles through the transform rounds; a 2^11-row f64 tile fills the LDS of a CU

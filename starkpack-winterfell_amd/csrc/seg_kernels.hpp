@@ -86,6 +86,23 @@ __device__ __forceinline__ Pair<U128> pair_from<F128>(const uint4 &qa, const uin
     return v;
 }
 
+// One element parked in a native vector register (the same lesson: arrays of U128 that wait through a kernel phase end up
+// in scratch memory) and back.
+__device__ __forceinline__ uint4 park(uint64_t v) { return make_uint4((uint32_t)v, (uint32_t)(v >> 32), 0u, 0u); }
+__device__ __forceinline__ uint4 park(const U128 &v) {
+    return make_uint4((uint32_t)v.lo, (uint32_t)(v.lo >> 32), (uint32_t)v.hi, (uint32_t)(v.hi >> 32));
+}
+template <class F>
+__device__ __forceinline__ typename F::T unpark(const uint4 &q);
+template <>
+__device__ __forceinline__ uint64_t unpark<F64>(const uint4 &q) {
+    return ((uint64_t)q.y << 32) | q.x;
+}
+template <>
+__device__ __forceinline__ U128 unpark<F128>(const uint4 &q) {
+    return U128{((uint64_t)q.y << 32) | q.x, ((uint64_t)q.w << 32) | q.z};
+}
+
 enum : int { SEG_OUT_SEG = 0, SEG_OUT_ROWS = 1 };
 
 // Tile-size specialisation of the pass kernels: LOGD != 0 instantiates a kernel for tiles of exactly 2^LOGD rows run by
@@ -666,7 +683,16 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_strided(SegArgs<F> a) {
     const uint32_t D = 1u << a.logD;
     T *x = reinterpret_cast<T *>(smem_raw);
     T *twd = x + (size_t)D * S;
-    T *aux = twd + D;  // coset factors of the input rows, later the inter-pass twiddles of the output rows
+    // f128 (ONE_TABLE): the three tables of the pass -- input factors while the tile is filled, digit twiddles during the
+    // transform, output factors for the stores -- take turns in ONE region of D entries (two more barriers per tile; the
+    // twiddles and the output factors wait in registers): a 2^10-row tile is 80 KiB instead of 96, two work-groups per CU,
+    // a 2^9-row tile 40 KiB instead of 48, four instead of three.
+#ifdef WF_EXP_TWO_TABLES
+    constexpr bool ONE_TABLE = false;
+#else
+    constexpr bool ONE_TABLE = F::BYTES == 16;
+#endif
+    T *aux = ONE_TABLE ? twd : twd + D;  // coset factors of the input rows, later the inter-pass twiddles of the output rows
 #ifdef WF_EXP_SWIZZLE
     constexpr bool SWZ = LOGD == 10 && F::BYTES == 8 && !PACKED;  // (the direct first round: every access below goes through the rounds or the read-out)
 #else
@@ -796,11 +822,13 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_strided(SegArgs<F> a) {
             if (!trivial) f = F::mul(f, start);
             fo[q] = f;
             if (threadIdx.x + q * NT < D) {
-                twd[kq[q]] = tw_q[q];
+                if (!ONE_TABLE) twd[kq[q]] = tw_q[q];
                 if (scale_in) aux[kq[q]] = F::mul(fi_a[q], fi_b[q]);  // h_c^(d*I); h_c^i goes into the output factors
             }
         }
     }
+    // (ONE_TABLE: twiddles and output factors wait in vector registers for their turn in the table region)
+    const uint4 twk0 = park(tw_q[0]), twk1 = park(tw_q[1]), fok0 = park(fo[0]), fok1 = park(fo[1]);
     __syncthreads();
 
     if (direct) {
@@ -854,11 +882,16 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_strided(SegArgs<F> a) {
 #undef WF_FILL_ITEM
     }
     if (!direct || scale_in) __syncthreads();  // LDS tile written / input factors consumed (uniform condition)
-    // `aux` now takes the output factors (visible after the transform's barriers)
+    if (ONE_TABLE) {  // the region now takes the digit twiddles
+        if (threadIdx.x < D) twd[kq[0]] = unpark<F>(twk0);
+        if (threadIdx.x + NT < D) twd[kq[1]] = unpark<F>(twk1);
+        __syncthreads();
+    } else {  // `aux` now takes the output factors (visible after the transform's barriers)
 #pragma unroll
-    for (uint32_t q = 0; q < 2; q++) {
-        const uint32_t k = threadIdx.x + q * NT;
-        if (k < D) aux[k] = fo[q];
+        for (uint32_t q = 0; q < 2; q++) {
+            const uint32_t k = threadIdx.x + q * NT;
+            if (k < D) aux[k] = fo[q];
+        }
     }
 #ifndef WF_EXP_SKIP_NTT  // tuning experiment: memory phases only (scripts/exp_variants.sh)
     // (the generic kernel runs the generic round loop: with the 16 direct values in registers it has no room for more)
@@ -870,6 +903,11 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_strided(SegArgs<F> a) {
     }
     __syncthreads();
 #endif
+    if (ONE_TABLE) {  // (the transform ended with a barrier: the twiddles are done with) the region takes the output factors
+        if (threadIdx.x < D) aux[threadIdx.x] = unpark<F>(fok0);
+        if (threadIdx.x + NT < D) aux[threadIdx.x + NT] = unpark<F>(fok1);
+        __syncthreads();
+    }
 
     T start_a = F::one(), start_b = F::one();
     if (PACKED && a.pre_on) {  // h_c^i of each lane's coset (the table above carries only the twiddle)
@@ -1035,6 +1073,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
         tw_q[q] = a.digit_tw[kq[q]];
         pin.fetch(kq[q], fi_a[q], fi_b[q]);  // single-pass evaluation: row index = coefficient index
     }
+    const uint4 twk0 = park(tw_q[0]), twk1 = park(tw_q[1]);  // (wait in vector registers: as an array they sit in scratch for f128)
     // (no direct first round here, unlike k_seg_strided: the tile is one contiguous 64 KiB run, which 16-byte-per-lane
     // loads staged through LDS stream faster than sixteen 8-byte loads per thread -- measured 0.61 -> 0.69 ms with it)
     // blockDim >= D/2: a tile is at most LOAD_BATCH lane pairs per thread, eight 16-byte registers either way
@@ -1079,7 +1118,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
             if (scale_in)
                 aux[kq[q]] = F::mul(fi_a[q], fi_b[q]);  // (in the twiddles' place until the tile is filled)
             else
-                twd[kq[q]] = tw_q[q];
+                twd[kq[q]] = unpark<F>(q == 0 ? twk0 : twk1);
         }
     }
     __syncthreads();
@@ -1128,9 +1167,8 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
     }
     if (scale_in) {  // the input factors have been consumed: the digit twiddles take their place
         __syncthreads();
-#pragma unroll
-        for (uint32_t q = 0; q < 2; q++)
-            if (threadIdx.x + q * NT < D) twd[kq[q]] = tw_q[q];
+        if (threadIdx.x < D) twd[kq[0]] = unpark<F>(twk0);
+        if (threadIdx.x + NT < D) twd[kq[1]] = unpark<F>(twk1);
     }
     __syncthreads();
 #ifndef WF_EXP_SKIP_NTT

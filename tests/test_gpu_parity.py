@@ -209,7 +209,7 @@ def test_error_codes(ctx, capi):
     (F64, 23, 1, 1),    # three passes [8, 8, 7]
     (F64, 21, 1, 8),    # full rows, one segment: leaves hashed by the persistent last pass (2^11-row strided tiles)
     (F64, 22, 1, 5),    # the same under a three-pass plan, 5 of 8 lanes used (40-byte leaves, padded rows)
-    (F128, 20, 1, 1),   # f128 digits are capped at 10 bits; [10, 10] is replaced by three passes [7, 7, 6]
+    (F128, 20, 1, 1),   # f128 digits are capped at 10 bits: two full passes [10, 10] (80 KiB tiles, two work-groups per CU)
     (F128, 21, 1, 1),   # three passes [7, 7, 7]
 ])
 def test_large_transform_plans(ctx, orc, capi, field, logR, logB, n_cols):
