@@ -55,7 +55,10 @@ static Plan make_plan(uint32_t L, uint32_t max_digit, bool avoid_full = false, b
 // the plan of the segment kernels (run_seg_transform and the sizing of its work buffer must agree on it)
 template <class F>
 static Plan seg_plan(uint32_t logN, uint32_t n_seg, uint32_t digit_cap = 0, bool full_tiles = false) {
-    uint32_t max_digit = F::BYTES == 8 ? 11 : 10;
+    // f128: a tile of 2^11 rows (128 KiB) and ONE table region of 2^11 entries are exactly the 160 KiB of a CU.  Used where
+    // it makes a transform of 2^11 rows a single pass over many segments (64 packed do_work traces of 2^11 steps: 0.725 ->
+    // 0.513 ms); as a digit of a longer transform it loses to smaller tiles (2^21 x 10: [10, 11] 11.1 ms, [7, 7, 7] 10.0 ms).
+    uint32_t max_digit = F::BYTES == 8 || (logN == 11 && n_seg > 8) ? 11 : 10;
     // wf_tuning::max_digit (tests / tuning): force more, smaller passes
     if (digit_cap >= 4 && digit_cap < max_digit && (logN + digit_cap - 1) / digit_cap <= 4) max_digit = digit_cap;  // Plan holds 4 digits
     return make_plan(logN, max_digit, !full_tiles && F::BYTES == 8, n_seg <= 8, !full_tiles);

@@ -1357,7 +1357,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
 // SMALL: tiles of at most 2^9 rows (<= 256 threads): compiled without the 128-VGPR cap that 1024-thread work-groups impose
 // (the multi-segment variants spill a few registers under it)
 template <class F, bool MULTI, bool PADT = false, bool CHUNKED = false, bool SMALL = false, int LOGD = 0>  // PADT: SegArgs::pad_traces (kept out of the other instantiations' registers)
-__global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : (F::BYTES == 8 ? 1024 : 512)) k_seg_last_hash(SegArgs<F> a) {  // f128 tiles: D <= 2^10
+__global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : 1024) k_seg_last_hash(SegArgs<F> a) {
     typedef typename F::T T;
     const uint32_t logD_ = LOGD ? (uint32_t)LOGD : a.logD;  // (a local, not a.logD = LOGD: a modified copy of the arguments would live in scratch, where decode() indexes prev_log[])
     const uint32_t NT = tile_threads<LOGD>();

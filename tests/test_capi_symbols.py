@@ -73,8 +73,11 @@ def test_transform_plans(capi):
     assert plan(F64, 20) == [10, 10] and plan(F64, 16) == [8, 8] and plan(F64, 19) == [10, 9]
     assert plan(F64, 21) == [10, 11]                                        # the maximal digit goes last
     assert plan(F64, 22) == [8, 7, 7] and plan(F64, 23) == [8, 8, 7]        # never two full tiles
+    # f128 tiles: 2^10 rows are half a CU's LDS in both passes (so 2^20 runs two full passes); 2^11 rows (128 KiB + one
+    # 32 KiB table region: all of a CU) only as the single pass of a 2^11-row transform over many segments
     assert plan(F128, 18) == [9, 9] and plan(F128, 19) == [9, 10]
-    assert plan(F128, 20) == [10, 10] and plan(F128, 21) == [7, 7, 7]     # f128 2^10-row tiles are half a CU in both passes
+    assert plan(F128, 20) == [10, 10] and plan(F128, 21) == [7, 7, 7] and plan(F128, 22) == [8, 7, 7]
+    assert plan(F128, 11, 1) == [6, 5] and plan(F128, 11, 32) == [11]
     assert plan(F64, 32) == [10, 11, 11] and plan(F128, 40) == [10, 10, 10, 10]
     for bad in ((3, 10, 1), (1, 0, 1), (1, 41, 1)):
         with pytest.raises(capi.WfError):

@@ -211,6 +211,8 @@ def test_error_codes(ctx, capi):
     (F64, 22, 1, 5),    # the same under a three-pass plan, 5 of 8 lanes used (40-byte leaves, padded rows)
     (F128, 20, 1, 1),   # f128 digits are capped at 10 bits: two full passes [10, 10] (80 KiB tiles, two work-groups per CU)
     (F128, 21, 1, 1),   # three passes [7, 7, 7]
+    (F128, 20, 1, 6),   # [10, 10] with two segments (rows of 8 elements, 6 used): fused hashing over the segments
+    (F128, 22, 1, 1),   # three passes [8, 7, 7]
 ])
 def test_large_transform_plans(ctx, orc, capi, field, logR, logB, n_cols):
     rng = np.random.default_rng(logR)
