@@ -358,6 +358,13 @@ void orc_ext_mul(int field, size_t ext, const void *a, const void *b, void *out)
     else
         f128_ext_mul(ext, (const f128e *)a, (const f128e *)b, (f128e *)out);
 }
+/* polynom::syn_div_in_place(p, 1, b) in place on n coefficients of `ext` coordinates */
+void orc_syn_div(int field, size_t ext, void *p, size_t n, const void *b) {
+    if (field == ORC_FIELD_F64)
+        orc_f64_syn_div((uint64_t *)p, ext, n, (const uint64_t *)b);
+    else
+        orc_f128_syn_div((f128e *)p, ext, n, (const f128e *)b);
+}
 void orc_transpose_slice(int field, const void *src, size_t n, size_t ext, size_t N, void *out) {
     if (field == ORC_FIELD_F64)
         orc_f64_transpose_slice((const uint64_t *)src, n, ext, N, (uint64_t *)out);

@@ -87,6 +87,7 @@ int orc_build_constraint_commitment(int field, size_t ext, unsigned log2_R, unsi
 
 /* --- extension fields and FRI layer pieces (fri/src/prover/mod.rs:191-226, fri/src/folding/mod.rs:85-117) */
 void orc_ext_mul(int field, size_t ext, const void *a, const void *b, void *out);
+void orc_syn_div(int field, size_t ext, void *p, size_t n, const void *b);
 void orc_transpose_slice(int field, const void *src, size_t n, size_t ext, size_t N, void *out);
 void orc_apply_drp(int field, const void *values, size_t rows, size_t ext, size_t N, const uint8_t offset_le[16],
                    const void *alpha, void *out, int threads);
@@ -110,6 +111,8 @@ void orc_deep_compose(int field, size_t ext, size_t n, size_t n_tables, const si
                       const size_t *col_ext, const void *ood_z, const void *ood_zg, const void *cc_traces,
                       size_t n_constraint_cols, const void *const *constraint_cols, const void *ood_constraints,
                       const void *cc_constraints, const void *z, void *out);
+void orc_f64_syn_div(uint64_t *p, size_t ext, size_t n, const uint64_t *b);
+void orc_f128_syn_div(unsigned __int128 *p, size_t ext, size_t n, const unsigned __int128 *b);
 void orc_f64_deep_compose(size_t ext, size_t n, size_t n_tables, const size_t *cols_per_table, const uint64_t *const *cols,
                           const size_t *col_ext, const uint64_t *ood_z, const uint64_t *ood_zg, const uint64_t *cc_traces,
                           size_t n_constraint_cols, const uint64_t *const *constraint_cols, const uint64_t *ood_constraints,

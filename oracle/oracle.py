@@ -77,6 +77,8 @@ def lib():
         L.orc_blake3_hash.argtypes = [vp, sz, vp]
         L.orc_eval_column_at.argtypes = [i32, vp, sz, sz, vp, sz, vp]
         L.orc_ext_mul.argtypes = [i32, sz, vp, vp, vp]
+        L.orc_syn_div.argtypes = [i32, sz, vp, sz, vp]
+        L.orc_syn_div.restype = None
         L.orc_acc_column.argtypes = [i32, vp, sz, sz, sz, vp, vp, sz, vp, vp]
         L.orc_scale_acc.argtypes = [i32, vp, vp, sz, sz, vp, sz]
         L.orc_deep_compose.argtypes = [i32, sz, sz, sz, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]
@@ -430,6 +432,16 @@ def merkle_prove_batch(nodes: np.ndarray, leaves: np.ndarray, indexes):
 
 
 # ----------------------------------------------------------------------------------------------- FRI layer pieces
+
+def syn_div(field: int, ext: int, poly: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """polynom::syn_div_in_place(poly, 1, b) (math/src/polynom/mod.rs:535-542): poly / (x - b), the remainder dropped; the
+    quotient's n - 1 coefficients followed by a zero, as the reference leaves the slice."""
+    out = np.ascontiguousarray(poly, dtype=np.uint64).copy()
+    bb = np.ascontiguousarray(b, dtype=np.uint64)
+    n = out.size // (ELEM_WORDS[field] * ext)
+    lib().orc_syn_div(field, ext, _p(out), n, _p(bb))
+    return out
+
 
 def ext_mul(field: int, ext: int, a: np.ndarray, b: np.ndarray) -> np.ndarray:
     a = np.ascontiguousarray(a, dtype=np.uint64)

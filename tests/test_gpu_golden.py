@@ -6,6 +6,7 @@ import pytest
 import golden_util as G
 
 pytestmark = pytest.mark.gpu
+F64, F128 = 1, 2
 
 
 @pytest.mark.parametrize("case", G.load("lde_commit_small.json"), ids=lambda c: c["name"])
@@ -75,3 +76,22 @@ def test_reference_literal_inputs_golden(ctx, capi):
     pr.begin(ev)
     assert pr.commit_layer().hex() == f["root"]
     pr.close()
+
+
+def test_reference_held_known_answers(ctx, orc):
+    """The vectors the reference's own tests hold (tests/golden/reference_kat.json), through the C ABI: the device's extension
+    product as P(z) of the polynomial a * x at z = b (wf_evaluate_columns_at: Horner in E multiplies coefficient and point with the
+    kernels' one ext_mul, csrc/fri_kernels.hpp, which FRI folding, DEEP and the constraint combination share), and the leaf hash
+    of the f128 row 1, 2, 3, 4 (wf_hash_rows: canonical bytes as f128/tests.rs:165-181 lists them, then BLAKE3)."""
+    g = G.load("reference_kat.json")
+    ints = lambda v: [int(x) for x in v]  # noqa: E731
+    for ext, key in ((2, "f64_quad_mul"), (3, "f64_cube_mul")):
+        for c in g[key]:
+            col = np.zeros(8 * ext, dtype=np.uint64)          # eight coefficients of `ext` coordinates: 0, a, 0, ...
+            col[ext:2 * ext] = orc.f64_new(ints(c["a"]))
+            got = ctx.evaluate_columns_at(F64, ext, [col], orc.f64_new(ints(c["b"])), ext)
+            assert [int(x) for x in orc.f64_as_int(got[0])] == ints(c["expected"]), c["where"]
+    c = g["f128_elements_as_bytes"]
+    row = orc.f128_from_ints(ints(c["source"]))
+    assert ctx.hash_rows(F128, row, 1, 4)[0].tobytes().hex() == c["blake3_256_of_expected_bytes"]
+

@@ -477,3 +477,24 @@ def test_phase_clock_of_the_commitment(orc):
     orc.build_trace_commitment(1, [cols], 1, 10, 3, 7)
     ph = orc.last_phase_ms()
     assert len(ph) == 4 and all(x >= 0 for x in ph) and sum(ph) > 0
+
+
+def test_reference_held_known_answers(orc):
+    """The known-answer vectors the reference's OWN tests hold (tests/golden/reference_kat.json; inputs and expected outputs
+    are the literals of math/src/field/f64/tests.rs:251-280 / :321-378, math/src/field/f128/tests.rs:165-181 and
+    math/src/polynom/tests.rs:178-207) against the oracle's extension products, canonical bytes + leaf hash, and syn_div."""
+    g = G.load("reference_kat.json")
+    ints = lambda v: [int(x) for x in v]  # noqa: E731
+    for ext, key in ((2, "f64_quad_mul"), (3, "f64_cube_mul")):
+        for c in g[key]:
+            got = orc.f64_as_int(orc.ext_mul(F64, ext, orc.f64_new(ints(c["a"])), orc.f64_new(ints(c["b"]))))
+            assert [int(x) for x in got] == ints(c["expected"]), c["where"]
+    c = g["f128_elements_as_bytes"]
+    elems = orc.f128_from_ints(ints(c["source"]))
+    assert elems.tobytes() == bytes(c["expected_bytes"])            # the canonical u128s, little-endian: elements_as_bytes
+    assert orc.hash_elements(F128, elems).hex() == c["blake3_256_of_expected_bytes"]
+    for c in g["f128_syn_div"]:
+        q = orc.f128_to_ints(orc.syn_div(F128, 1, orc.f128_from_ints(ints(c["poly"])), orc.f128_from_ints([int(c["b"])])))
+        want = ints(c["expected"])
+        assert q[:len(want)] == want and not any(q[len(want):]), c["where"]
+
