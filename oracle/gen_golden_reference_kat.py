@@ -12,6 +12,11 @@ evaluation, a root equals nested merges -- see tests/golden/README.md.)
   * polynom::syn_div by (x - b) (math/src/polynom/tests.rs:178-207, f128): the division of the DEEP composition
     (composer/mod.rs:62-193 divides by x - z and x - z g with syn_div_in_place).
 
+  * the composition polynomial's column split (prover/src/constraints/composition_poly.rs:109-123 `segment`, f128): the
+    coefficients 0..15 in four columns of four.
+  * transpose_slice (utils/core/src/lib.rs:198-205, the function's doc test): 0..7 in rows of two -- how FriProver lays out
+    a layer's evaluations before hashing them (fri/src/prover/mod.rs:207-214).
+
 Every literal is cross-checked below against Python integers (a typing error fails the run); the EXPECTED values written
 to the fixture are the reference's literals, not the recomputation.
 
@@ -57,6 +62,15 @@ SYN_DIV = [
 ]
 
 
+# composition_poly.rs:109-123 -- segment((0..16), 4, 4)
+SEGMENT = {"values": list(range(16)), "trace_len": 4, "num_cols": 4,
+           "expected": [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11], [12, 13, 14, 15]]}
+
+
+# utils/core/src/lib.rs:198-205 -- transpose_slice::<u32, 2>(&[0, 1, .., 7])
+TRANSPOSE = {"values": list(range(8)), "N": 2, "expected": [[0, 4], [1, 5], [2, 6], [3, 7]]}
+
+
 def quad_mul(a, b):  # x^2 = x - 2 (f64/mod.rs:401-430)
     c0, c1, c2 = a[0] * b[0], a[0] * b[1] + a[1] * b[0], a[1] * b[1]
     return [(c0 - 2 * c2) % M64, (c1 + c2) % M64]
@@ -88,6 +102,9 @@ def main():
     assert list(want) == F128_BYTES_EXPECTED
     for c in SYN_DIV:
         assert syn_div(c["poly"], c["b"], M128) == c["expected"], c
+    assert [SEGMENT["values"][c * 4:(c + 1) * 4] for c in range(4)] == SEGMENT["expected"]
+    rows = len(TRANSPOSE["values"]) // TRANSPOSE["N"]
+    assert [[TRANSPOSE["values"][i + j * rows] for j in range(TRANSPOSE["N"])] for i in range(rows)] == TRANSPOSE["expected"]
     s = lambda v: [str(x) for x in v]  # noqa: E731  (decimal strings: JSON numbers stop at 2^53)
     out = {
         "_note": "known-answer vectors held by the reference's own tests; see oracle/gen_golden_reference_kat.py for the lines",
@@ -96,6 +113,8 @@ def main():
         "f128_elements_as_bytes": {"source": s(F128_BYTES_SOURCE), "expected_bytes": F128_BYTES_EXPECTED,
                                    "blake3_256_of_expected_bytes": blake3(bytes(F128_BYTES_EXPECTED)).hex(),
                                    "where": "f128/tests.rs:165-181; digest: official BLAKE3 of those bytes"},
+        "f128_composition_segment": dict(SEGMENT, where="prover/src/constraints/composition_poly.rs:109-123"),
+        "transpose_slice": dict(TRANSPOSE, where="utils/core/src/lib.rs:198-205 (doc test)"),
         "f128_syn_div": [{"poly": s(c["poly"]), "b": str(c["b"]), "expected": s(c["expected"]), "where": c["where"]} for c in SYN_DIV],
     }
     with open(os.path.join(OUT, "reference_kat.json"), "w") as f:

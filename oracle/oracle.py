@@ -560,7 +560,15 @@ def composition_poly_from_evaluations(field: int, ext: int, tables, log2_R: int,
         else:
             fc = np.ascontiguousarray(final_coeff, dtype=np.uint64)
             lib().orc_scale_acc(field, _p(final), _p(v), ext, ce, _p(fc), i)
-    flat = final.reshape(-1, ext * w)
+    return segment(field, ext, final, R, n_cols)
+
+
+def segment(field: int, ext: int, coefficients: np.ndarray, R: int, n_cols: int):
+    """constraints/composition_poly.rs:86-98 `segment`: the composition polynomial's coefficients in n_cols contiguous runs of
+    R elements of E -- column c holds coefficients c R .. (c + 1) R - 1 (the reference's own test: 0..15 -> four columns of
+    four, composition_poly.rs:109-123; tests/golden/reference_kat.json)."""
+    w = ELEM_WORDS[field]
+    flat = np.ascontiguousarray(coefficients, dtype=np.uint64).reshape(-1, ext * w)
     return [np.ascontiguousarray(flat[c * R:(c + 1) * R]).reshape((R * ext, w) if w > 1 else (R * ext,)) for c in range(n_cols)]
 
 

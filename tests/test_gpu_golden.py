@@ -94,4 +94,8 @@ def test_reference_held_known_answers(ctx, orc):
     c = g["f128_elements_as_bytes"]
     row = orc.f128_from_ints(ints(c["source"]))
     assert ctx.hash_rows(F128, row, 1, 4)[0].tobytes().hex() == c["blake3_256_of_expected_bytes"]
+    # transpose_slice's doc test through the FRI layer commitment (the layer's rows are the transposed evaluations)
+    c = g["transpose_slice"]
+    layer = ctx.fri_layer_commit(F64, 1, np.array(c["values"], dtype=np.uint64), c["N"])
+    assert np.asarray(layer["transposed"]).reshape(-1, c["N"]).tolist() == c["expected"], c["where"]
 

@@ -497,4 +497,10 @@ def test_reference_held_known_answers(orc):
         q = orc.f128_to_ints(orc.syn_div(F128, 1, orc.f128_from_ints(ints(c["poly"])), orc.f128_from_ints([int(c["b"])])))
         want = ints(c["expected"])
         assert q[:len(want)] == want and not any(q[len(want):]), c["where"]
+    c = g["f128_composition_segment"]
+    cols = orc.segment(F128, 1, orc.f128_from_ints(c["values"]), c["trace_len"], c["num_cols"])
+    assert [orc.f128_to_ints(col) for col in cols] == c["expected"], c["where"]
+    c = g["transpose_slice"]
+    tr = orc.transpose_slice(F64, np.array(c["values"], dtype=np.uint64), len(c["values"]), 1, c["N"])
+    assert tr.reshape(-1, c["N"]).tolist() == c["expected"], c["where"]
 
