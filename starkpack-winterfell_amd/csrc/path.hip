@@ -477,6 +477,21 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             if (F::BYTES == 8 && !chunked && !multi && !a.pad_traces && a.logD == 10 && !ctx->tune.no_specialized)
                 kern = (const void *)k_seg_last_hash<F, false, false, false, false, F::BYTES == 8 ? 10 : 0>;
 #endif
+#ifndef WF_EXP_NO_SPEC_LAST7
+            // several segments in 2^7-row tiles (the last digit of the 2^22 plan: cfg 3's last pass 11.44 -> 11.12 ms)
+            if (F::BYTES == 8 && !chunked && multi && !a.pad_traces && a.logD == 7 && small && !ctx->tune.no_specialized)
+                kern = (const void *)k_seg_last_hash<F, true, false, false, true, F::BYTES == 8 ? 7 : 0>;
+#endif
+#ifndef WF_EXP_NO_SPEC_LAST9
+            // ... and in 2^9-row tiles (2^18 x 32: last pass 0.547 -> 0.521 ms)
+            if (F::BYTES == 8 && !chunked && multi && !a.pad_traces && a.logD == 9 && small && !ctx->tune.no_specialized)
+                kern = (const void *)k_seg_last_hash<F, true, false, false, true, F::BYTES == 8 ? 9 : 0>;
+#endif
+#ifndef WF_EXP_NO_SPEC_LAST8
+            // ... and in 2^8-row tiles (2^17 x 32: last pass 0.278 -> 0.259 ms)
+            if (F::BYTES == 8 && !chunked && multi && !a.pad_traces && a.logD == 8 && small && !ctx->tune.no_specialized)
+                kern = (const void *)k_seg_last_hash<F, true, false, false, true, F::BYTES == 8 ? 8 : 0>;
+#endif
             if (chunked) {
                 int rcc = ensure(ctx, ctx->hash_tmp, (size_t)launch_rows * n_chunks * 32);
                 if (rcc) return rcc;
