@@ -344,6 +344,10 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         // specialised for the tile size need more registers than two work-groups per CU allow (scratch spills).
         const bool spec_ok = F::BYTES == 8 && !packed && threads * 2 == (1u << a.logD) && !ctx->tune.no_specialized;
         const void *kern = nullptr;
+#ifdef WF_EXP_SPEC9_F128
+        if (F::BYTES == 16 && !packed && threads * 2 == (1u << a.logD) && a.logD == 9 && !ctx->tune.no_specialized)
+            kern = d.rows_out ? (const void *)k_seg_strided<F, 1, false, F::BYTES == 16 ? 9 : 0> : (const void *)k_seg_strided<F, 0, false, F::BYTES == 16 ? 9 : 0>;
+#endif
         if (spec_ok) {
             constexpr bool F8 = F::BYTES == 8;  // (the specialised instantiations exist for f64 only)
             switch (a.logD) {
@@ -486,6 +490,11 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             // ... and in 2^9-row tiles (2^18 x 32: last pass 0.547 -> 0.521 ms)
             if (F::BYTES == 8 && !chunked && multi && !a.pad_traces && a.logD == 9 && small && !ctx->tune.no_specialized)
                 kern = (const void *)k_seg_last_hash<F, true, false, false, true, F::BYTES == 8 ? 9 : 0>;
+#endif
+#ifndef WF_EXP_NO_SPEC_LAST9_F128
+            // f128, 2^9-row tiles (cfg 5: last pass 0.513 -> 0.500 ms)
+            if (F::BYTES == 16 && !chunked && multi && !a.pad_traces && a.logD == 9 && small && !ctx->tune.no_specialized)
+                kern = (const void *)k_seg_last_hash<F, true, false, false, true, F::BYTES == 16 ? 9 : 0>;
 #endif
 #ifndef WF_EXP_NO_SPEC_LAST8
             // ... and in 2^8-row tiles (2^17 x 32: last pass 0.278 -> 0.259 ms)
