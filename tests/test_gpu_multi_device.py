@@ -119,6 +119,6 @@ def test_launcher_gives_up_on_ranks_that_hang(capi):
     """The parent of `bench.py --gpus N` ends its ranks' process group at its wall-clock limit and exits non-zero."""
     capi.load()
     out = run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--inject-fault", "hang",
-                    env_extra={"WF_BENCH_BACKEND": "gloo", "WF_BENCH_LAUNCH_TIMEOUT_S": "30"}, timeout=300)
+                    env_extra={"WF_BENCH_BACKEND": "gloo", "WF_BENCH_LAUNCH_TIMEOUT_S": "20"}, timeout=300)
     assert out.returncode == 124, out.stdout[-2000:] + out.stderr[-2000:]
     assert "did not finish within" in out.stderr

@@ -12,43 +12,53 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("switch", ["WF_EXP_MAX_DIGIT=5", "WF_EXP_MAX_DIGIT=7", "WF_EXP_NO_FUSED_HASH=1",
-                                    "WF_EXP_NO_PERSISTENT=1", "WF_EXP_NO_CHUNKED=1", "WF_EXP_PERSISTENT_ALWAYS=1"])
-def test_parity_under_forced_plans(capi, switch):
+PARITY_SWITCHES = ["WF_EXP_MAX_DIGIT=5", "WF_EXP_MAX_DIGIT=7", "WF_EXP_NO_FUSED_HASH=1",
+                   "WF_EXP_NO_PERSISTENT=1", "WF_EXP_NO_CHUNKED=1", "WF_EXP_PERSISTENT_ALWAYS=1"]
+PARITY_FILES = ["test_gpu_coset_shard.py", "test_gpu_parity.py", "test_gpu_golden.py"]
+RESIDENT_SWITCHES = ["WF_EXP_PIPELINE_MIN_BYTES=0", "WF_EXP_PIPELINE_MIN_BYTES=0 WF_EXP_MAX_DIGIT=5", "WF_EXP_NO_PIPELINE=1"]
+RESIDENT_FILES = ["test_gpu_queries.py", "test_gpu_deep.py", "test_gpu_pipeline.py", "test_gpu_wide_resident.py"]
+
+
+def _run_suite(switches, files):
+    env = dict(os.environ)
+    for sw in switches.split():
+        name, value = sw.split("=")
+        env[name] = value
+    return subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"]
+                          + [os.path.join(ROOT, "tests", f) for f in files],
+                          env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+
+
+@pytest.fixture(scope="module")
+def forced_runs(capi):
+    """Every forced-plan run of this module, three child processes at a time (with this process: four on the GPU, within
+    the pool's limit of six) -- most of a child's time is the CPU oracle, so the runs overlap well: the module takes a
+    third of the wall clock of running them one after the other."""
+    from concurrent.futures import ThreadPoolExecutor
+    capi.load()
+    jobs = [(sw, PARITY_FILES) for sw in PARITY_SWITCHES] + [(sw, RESIDENT_FILES) for sw in RESIDENT_SWITCHES]
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        results = list(pool.map(lambda j: _run_suite(*j), jobs))
+    return {sw: r for (sw, _), r in zip(jobs, results)}
+
+
+@pytest.mark.parametrize("switch", PARITY_SWITCHES)
+def test_parity_under_forced_plans(forced_runs, switch):
     """WF_EXP_NO_FUSED_HASH: one-segment, one-trace matrices normally get their leaves from the last evaluation pass;
     with the switch they go through k_hash_rows like every other shape -- both routes must give the same bytes.
     WF_EXP_NO_PERSISTENT: the fused last pass as one work-group per tile instead of the persistent ticket kernel.
     WF_EXP_NO_CHUNKED: rows longer than one BLAKE3 chunk hashed by the separate chunk kernels instead of chunk by chunk
     inside the persistent pass.  WF_EXP_PERSISTENT_ALWAYS: the ticket kernel also on the small shapes that normally take
     one work-group per tile."""
-    capi.load()
-    env = dict(os.environ)
-    name, value = switch.split("=")
-    env[name] = value
-    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                          os.path.join(ROOT, "tests", "test_gpu_coset_shard.py"),
-                          os.path.join(ROOT, "tests", "test_gpu_parity.py"),
-                          os.path.join(ROOT, "tests", "test_gpu_golden.py")],
-                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    out = forced_runs[switch]
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
 
 
-@pytest.mark.parametrize("switches", ["WF_EXP_PIPELINE_MIN_BYTES=0", "WF_EXP_PIPELINE_MIN_BYTES=0 WF_EXP_MAX_DIGIT=5",
-                                      "WF_EXP_NO_PIPELINE=1"])
-def test_resident_suites_with_pipelined_upload(capi, switches):
+@pytest.mark.parametrize("switches", RESIDENT_SWITCHES)
+def test_resident_suites_with_pipelined_upload(forced_runs, switches):
     """Resident trace commitments of several segments upload segment by segment under the kernels of the previous segments
     (trace_commit_pipelined) once a column is a MiB or more; WF_EXP_PIPELINE_MIN_BYTES=0 sends the small multi-segment
     shapes of the resident test suites down that route (with WF_EXP_MAX_DIGIT=5: also those below 2^11 rows, which are
     single-pass otherwise), WF_EXP_NO_PIPELINE switches it off: same roots, rows, proofs and polynomials every way."""
-    capi.load()
-    env = dict(os.environ)
-    for sw in switches.split():
-        name, value = sw.split("=")
-        env[name] = value
-    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                          os.path.join(ROOT, "tests", "test_gpu_queries.py"),
-                          os.path.join(ROOT, "tests", "test_gpu_deep.py"),
-                          os.path.join(ROOT, "tests", "test_gpu_pipeline.py"),
-                          os.path.join(ROOT, "tests", "test_gpu_wide_resident.py")],
-                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    out = forced_runs[switches]
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
