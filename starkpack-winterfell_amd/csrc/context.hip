@@ -36,6 +36,7 @@ wf_tuning tuning_from_env() {
     }
     t.no_pipeline = getenv("WF_EXP_NO_PIPELINE") != nullptr;
     t.single_fused = getenv("WF_EXP_SINGLE_FUSED") != nullptr;
+    t.fold_input = getenv("WF_EXP_FOLD_INPUT") != nullptr;
     if (const char *e = getenv("WF_EXP_PIPELINE_MIN_BYTES")) t.pipeline_min_bytes = (size_t)atoll(e);
     if (const char *e = getenv("WF_EXP_FAIL_AFTER_SEGMENT")) t.fail_after_segment = atoi(e);
     return t;

@@ -237,6 +237,7 @@ struct SegDesc {
     const T *in;
     T *work;
     T *out;
+    const T *in_cols = nullptr;  // interpolation, tuning (wf_tuning::fold_input): the first strided pass reads these COLUMNS
     uint32_t logN, n_seg, n_cosets;
     bool rows_out;
     void *leaves = nullptr;     // rows_out: hash the leaves in the last pass when the shape allows (sets *fused)
@@ -323,6 +324,8 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         } else {
             a.src = first ? d.in : d.work;  // interpolation: first pass in -> work, later passes in place
             a.dst = d.work;
+            a.src_cols = first ? d.in_cols : nullptr;
+            a.src_cols_rows = N;
             a.src_shared = 0;
             a.pre_on = 0;
             a.scale_on = first ? 1 : 0;     // 1/n rides on the first inter-pass twiddle table
@@ -780,22 +783,29 @@ static int trace_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_trace
     int rc = path_buffers<F>(ctx, p, b);
     if (rc) return rc;
     const uint64_t R = (uint64_t)1 << p->log2_trace_len;
-    // columns -> segments
-    rc = run_xpose<F>(ctx, st, true, d_trace, b.segA, R, p->ext_degree, b.total_base_cols, b.n_seg);
-    if (rc) return rc;
-    if (input_read) HIP_TRY(hipEventRecord(input_read, st));  // nothing below reads d_trace: its buffer may be refilled
+    // columns -> segments (tuning, wf_tuning::fold_input: not launched -- the first strided pass of a 2^20-row f64 interpolation
+    // gathers the columns itself; measured slower)
+    const bool fold = ctx->tune.fold_input && F::BYTES == 8 && p->ext_degree == 1 && p->log2_trace_len == 20 && !ctx->tune.no_specialized;
+    if (!fold) {
+        rc = run_xpose<F>(ctx, st, true, d_trace, b.segA, R, p->ext_degree, b.total_base_cols, b.n_seg);
+        if (rc) return rc;
+        if (input_read) HIP_TRY(hipEventRecord(input_read, st));  // nothing below reads d_trace: its buffer may be refilled
+    }
     // ColMatrix::interpolate_columns (col_matrix.rs:196-206)
     SegDesc<F> d;
     memset(&d, 0, sizeof(d));
     d.in = b.segA;
     d.work = b.segA;  // strided passes run in place
     d.out = b.segB;
+    d.in_cols = fold ? (const typename F::T *)d_trace : nullptr;
+    d.total_base_cols = b.total_base_cols;  // (read by the column gather only)
     d.logN = p->log2_trace_len;
     d.n_seg = b.n_seg;
     d.n_cosets = 1;
     d.rows_out = false;
     rc = run_seg_transform<F>(ctx, st, d);
     if (rc) return rc;
+    if (fold && input_read) HIP_TRY(hipEventRecord(input_read, st));
     // the caller's copy of the polynomials, column layout
     rc = run_xpose<F>(ctx, st, false, b.segB, d_polys, R, p->ext_degree, b.total_base_cols, b.n_seg);
     if (rc) return rc;

@@ -140,6 +140,8 @@ struct SegArgs {
     typedef typename F::T T;
     const T *src;
     T *dst;
+    const T *src_cols;      // k_seg_strided, direct first round only (tuning: wf_tuning::fold_input): the rows come from a column-major
+    uint64_t src_cols_rows; //   matrix (column B at src_cols + B * src_cols_rows) instead of segment layout; nullptr: segment layout
     uint32_t logN, logD;
     uint64_t I, O;          // inner / outer row counts of the [O][D][I] view (last pass: I = 1)
     uint32_t n_seg;         // segments per coset
@@ -766,7 +768,14 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_strided(SegArgs<F> a) {
         if (has16) {
             // sixteen rows m16 * I apart: one address, then a running 64-bit add per row
             const T *pr = src + (row0 + ((uint64_t)j16 << logI)) * S + l16;
-            const uint64_t rstep = ((uint64_t)m16 << logI) * S;
+            uint64_t rstep = ((uint64_t)m16 << logI) * S;
+            bool live = true;
+            if (a.src_cols) {  // uniform: column-major source (8-byte gathers, one per lane)
+                const uint32_t B = g * S + l16;
+                live = B < a.total_base_cols;
+                pr = a.src_cols + (uint64_t)(live ? B : 0) * a.src_cols_rows + row0 + ((uint64_t)j16 << logI);
+                rstep = (uint64_t)m16 << logI;
+            }
 #pragma unroll
             for (uint32_t q = 0; q < 16; q++) {
 #ifdef WF_EXP_SKIP_LOAD
@@ -775,6 +784,10 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_strided(SegArgs<F> a) {
                 vr[q] = *pr;
 #endif
                 pr += rstep;
+            }
+            if (!live) {
+#pragma unroll
+                for (uint32_t q = 0; q < 16; q++) vr[q] = F::zero();
             }
         }
     } else if (from_regs) {

@@ -64,6 +64,7 @@ struct wf_tuning {
     uint32_t merkle_l2_min = 18;      // WF_EXP_MERKLE_L2_MIN: log2 of the narrowest level the two-level launches take
     bool no_pipeline = false;         // WF_EXP_NO_PIPELINE: host columns uploaded in front of the kernels, never under them
     size_t pipeline_min_bytes = (size_t)1 << 20;  // WF_EXP_PIPELINE_MIN_BYTES
+    bool fold_input = false;          // WF_EXP_FOLD_INPUT: the interpolation's first pass reads the caller's COLUMNS (no cols->segments launch): measured, off
     bool single_fused = false;        // WF_EXP_SINGLE_FUSED: single-pass long rows hashed inside the pass (k_seg_single_hash: measured slower, off)
     int fail_after_segment = -1;      // WF_EXP_FAIL_AFTER_SEGMENT: the pipelined upload fails after that many segments (error-path test)
 };
