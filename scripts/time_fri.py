@@ -1,7 +1,7 @@
 """Times the resident FRI commit phase (wf_fri_prover_*) at the bench scale: DEEP polynomial of 2^logR coefficients over
 the quadratic extension -> LDE (blowup 8) -> layers (folding 4 or 8) down to the remainder.  Wall clock, host in the loop
 (commit_layer returns each root to the host, as the Fiat-Shamir channel needs it).
-    python scripts/time_fri.py [logR] [folding]"""
+    python scripts/time_fri.py [logR] [folding] [field 1|2]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,13 +10,15 @@ import starkpack_winterfell_amd.capi as capi
 
 logR = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 folding = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+field = int(sys.argv[3]) if len(sys.argv) > 3 else capi.F64
 ext, blowup, max_rem = 2, 8, 127
 ctx = capi.Context(0)
 rng = np.random.default_rng(1)
-poly = rng.integers(0, 2**62, size=((1 << logR), ext), dtype=np.uint64)
-fri = capi.FriProver(ctx, capi.F64, ext, folding, blowup, max_rem, 7)
+shape = ((1 << logR), ext) if field == capi.F64 else ((1 << logR), ext, 2)   # f128: (lo, hi) words, any value below 2^126
+poly = rng.integers(0, 2**62, size=shape, dtype=np.uint64)
+fri = capi.FriProver(ctx, field, ext, folding, blowup, max_rem, 7 if field == capi.F64 else 3)
 n_layers = capi.fri_num_layers(folding, blowup, max_rem, (1 << logR) * blowup)
-alphas = [rng.integers(0, 2**62, size=ext, dtype=np.uint64) for _ in range(n_layers)]
+alphas = [rng.integers(0, 2**62, size=shape[1:], dtype=np.uint64) for _ in range(n_layers)]
 for rep in range(4):
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -102,6 +102,12 @@ struct DrpArgs {
     T alpha[3];
 };
 
+__host__ __device__ constexpr int drp_bitrev(int k, int bits) {
+    int r = 0;
+    for (int b = 0; b < bits; b++) r |= ((k >> b) & 1) << (bits - 1 - b);
+    return r;
+}
+
 // apply_drp: per row, interpolate the N values (inverse DFT, coefficient k scaled by (1/N) * (s^-1 g^-i)^k) and
 // evaluate the resulting polynomial at alpha (Horner in E).
 template <class F, int W, int N>
@@ -110,53 +116,52 @@ __global__ void __launch_bounds__(256) k_fri_drp(DrpArgs<F> a) {
     typedef Ext<F, W> E;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.rows) return;
-    E v[N];
+    // the N values of the row in native vector registers (ElemReg): as an array of E they sit in scratch memory for f128 and
+    // for the cubic extension (400-784 bytes per thread)
+    typedef ElemReg<F> R;
+    typename R::type v[N * W];
 #pragma unroll
     for (int j = 0; j < N; j++)
 #pragma unroll
-        for (int w = 0; w < W; w++) v[j].c[w] = a.values[(i * N + j) * W + w];
-    // radix-2 decimation in frequency with the inverse root: natural in, bit-reversed out
+        for (int w = 0; w < W; w++) v[j * W + w] = R::put(a.values[(i * N + j) * W + w]);
+    // radix-2 decimation in frequency with the inverse root: natural in, bit-reversed out (static_for: every index a constant)
     constexpr int LOGN = N == 2 ? 1 : (N == 4 ? 2 : (N == 8 ? 3 : 4));
-#pragma unroll
-    for (int s = 0; s < LOGN; s++) {
-        const int half = (N / 2) >> s;
-#pragma unroll
-        for (int q = 0; q < N; q += 2 * half) {
-#pragma unroll
-            for (int k = 0; k < half; k++) {
-                const T t = a.tw[(k << s) & (N - 1)];
-#pragma unroll
-                for (int w = 0; w < W; w++) {
-                    const T u = v[q + k].c[w], x = v[q + k + half].c[w];
-                    v[q + k].c[w] = F::add(u, x);
-                    T d = F::sub(u, x);
-                    if (k != 0) d = F::mul(d, t);
-                    v[q + k + half].c[w] = d;
-                }
-            }
-        }
-    }
+    static_for<0, LOGN>([&](auto sc) {
+        constexpr int s = decltype(sc)::value, half = (N / 2) >> s;
+        static_for<0, N / 2>([&](auto bc) {  // butterfly b of the stage: block q, position k
+            constexpr int b = decltype(bc)::value, q = (b / half) * 2 * half, k = b % half;
+            const T t = a.tw[(k << s) & (N - 1)];
+            static_for<0, W>([&](auto wc) {
+                constexpr int w = decltype(wc)::value;
+                const T u = R::get(v[(q + k) * W + w]), x = R::get(v[(q + k + half) * W + w]);
+                v[(q + k) * W + w] = R::put(F::add(u, x));
+                T d = F::sub(u, x);
+                if (k != 0) d = F::mul(d, t);
+                v[(q + k + half) * W + w] = R::put(d);
+            });
+        });
+    });
     // coefficient k sits at bit-reversed position; scale by (1/N) * inv_offset^k and fold with alpha from the top
     const T inv_off = F::mul(a.sinv, a.ginv.get(i));
-    T scale[N];
-    scale[0] = a.ninv;
-#pragma unroll
-    for (int k = 1; k < N; k++) scale[k] = F::mul(scale[k - 1], inv_off);
+    typename R::type scale[N];
+    scale[0] = R::put(a.ninv);
+    static_for<1, N>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        scale[k] = R::put(F::mul(R::get(scale[k - 1]), inv_off));
+    });
     E alpha;
 #pragma unroll
     for (int w = 0; w < W; w++) alpha.c[w] = a.alpha[w];
     E acc;
 #pragma unroll
     for (int w = 0; w < W; w++) acc.c[w] = F::zero();
-#pragma unroll
-    for (int k = N - 1; k >= 0; k--) {
-        int pos = 0;
-#pragma unroll
-        for (int b = 0; b < LOGN; b++) pos |= ((k >> b) & 1) << (LOGN - 1 - b);
+    static_for<0, N>([&](auto rc) {
+        constexpr int k = N - 1 - decltype(rc)::value;
+        constexpr int pos = drp_bitrev(k, LOGN);
         acc = ext_mul<F, W>(acc, alpha);
 #pragma unroll
-        for (int w = 0; w < W; w++) acc.c[w] = F::add(acc.c[w], F::mul(v[pos].c[w], scale[k]));
-    }
+        for (int w = 0; w < W; w++) acc.c[w] = F::add(acc.c[w], F::mul(R::get(v[pos * W + w]), R::get(scale[k])));
+    });
 #pragma unroll
     for (int w = 0; w < W; w++) a.out[i * W + w] = acc.c[w];
 }
@@ -226,24 +231,27 @@ __global__ void __launch_bounds__(256) k_eval_columns_at(EvalAtArgs<F> a) {
     const T *poly = a.polys + (uint64_t)col * a.n * WC;
     const uint64_t base = (uint64_t)blk * EVAL_BLOCK;
     // every coefficient of this lane is requested before the first one is used (the Horner chain below is serial)
+    // (compile-time loops and native register arrays: the f128 instantiations kept `cf` in scratch memory otherwise -- the
+    // optimizer declines to unroll a Horner loop of fifteen extension products)
     constexpr int STEPS = EVAL_BLOCK / 256;
-    T cf[STEPS][WC];
-#pragma unroll
-    for (int j = 0; j < STEPS; j++) {
+    typedef ElemReg<F> R;
+    typename R::type cf[STEPS * WC];
+    static_for<0, STEPS>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
         const uint64_t k = base + t + 256u * (uint32_t)j;
 #pragma unroll
-        for (int w = 0; w < WC; w++) cf[j][w] = k < a.n ? poly[k * WC + w] : F::zero();
-    }
+        for (int w = 0; w < WC; w++) cf[j * WC + w] = R::put(k < a.n ? poly[k * WC + w] : F::zero());
+    });
     const E zp = eval_power<F, WZ>(a, pt, 8);  // z^256
     E acc;
 #pragma unroll
-    for (int w = 0; w < WZ; w++) acc.c[w] = w < WC ? cf[STEPS - 1][w < WC ? w : 0] : F::zero();
-#pragma unroll
-    for (int j = STEPS - 2; j >= 0; j--) {
+    for (int w = 0; w < WZ; w++) acc.c[w] = w < WC ? R::get(cf[(STEPS - 1) * WC + (w < WC ? w : 0)]) : F::zero();
+    static_for<0, STEPS - 1>([&](auto rc) {
+        constexpr int j = STEPS - 2 - decltype(rc)::value;
         acc = ext_mul<F, WZ>(acc, zp);
 #pragma unroll
-        for (int w = 0; w < WC; w++) acc.c[w] = F::add(acc.c[w], cf[j][w]);
-    }
+        for (int w = 0; w < WC; w++) acc.c[w] = F::add(acc.c[w], R::get(cf[j * WC + w]));
+    });
     sh[t] = acc;
     __syncthreads();
     eval_fold<F, WZ>(a, pt, 0, sh, t);

@@ -13,6 +13,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "blake3_dev.hpp"
 #include "field.hpp"
@@ -302,6 +303,48 @@ __device__ __forceinline__ void elem_words<F128>(U128 v, uint32_t *w) {
     w[2] = (uint32_t)v.hi;
     w[3] = (uint32_t)(v.hi >> 32);
 }
+
+// One element parked in a native vector register (the same lesson: arrays of U128 that wait through a kernel phase end up
+// in scratch memory) and back.
+__device__ __forceinline__ uint4 park(uint64_t v) { return make_uint4((uint32_t)v, (uint32_t)(v >> 32), 0u, 0u); }
+__device__ __forceinline__ uint4 park(const U128 &v) {
+    return make_uint4((uint32_t)v.lo, (uint32_t)(v.lo >> 32), (uint32_t)v.hi, (uint32_t)(v.hi >> 32));
+}
+template <class F>
+__device__ __forceinline__ typename F::T unpark(const uint4 &q);
+template <>
+__device__ __forceinline__ uint64_t unpark<F64>(const uint4 &q) {
+    return ((uint64_t)q.y << 32) | q.x;
+}
+template <>
+__device__ __forceinline__ U128 unpark<F128>(const uint4 &q) {
+    return U128{((uint64_t)q.y << 32) | q.x, ((uint64_t)q.w << 32) | q.z};
+}
+
+// Compile-time loop: f(std::integral_constant<int, I>) for I = B .. E - 1.  Where `#pragma unroll` is a request the optimizer may
+// decline (it does for the larger instantiations of k_fri_drp: their register arrays then turn into scratch memory), this
+// cannot fail.
+template <int B, int E, class Fn>
+__device__ __forceinline__ void static_for(Fn &&f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// The smallest native register type that holds one element: arrays of it stay in registers where arrays of U128 (or of
+// structs of them) are left in scratch memory by the compiler.
+template <class F> struct ElemReg;
+template <> struct ElemReg<F64> {
+    typedef uint2 type;
+    static __device__ __forceinline__ uint2 put(uint64_t v) { return make_uint2((uint32_t)v, (uint32_t)(v >> 32)); }
+    static __device__ __forceinline__ uint64_t get(const uint2 &q) { return ((uint64_t)q.y << 32) | q.x; }
+};
+template <> struct ElemReg<F128> {
+    typedef uint4 type;
+    static __device__ __forceinline__ uint4 put(const U128 &v) { return park(v); }
+    static __device__ __forceinline__ U128 get(const uint4 &q) { return unpark<F128>(q); }
+};
 
 // Rows of at most one BLAKE3 chunk (1024 bytes); longer rows use k_hash_chunks + k_hash_merge_chunks.
 template <class F>

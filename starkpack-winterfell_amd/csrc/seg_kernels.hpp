@@ -86,23 +86,6 @@ __device__ __forceinline__ Pair<U128> pair_from<F128>(const uint4 &qa, const uin
     return v;
 }
 
-// One element parked in a native vector register (the same lesson: arrays of U128 that wait through a kernel phase end up
-// in scratch memory) and back.
-__device__ __forceinline__ uint4 park(uint64_t v) { return make_uint4((uint32_t)v, (uint32_t)(v >> 32), 0u, 0u); }
-__device__ __forceinline__ uint4 park(const U128 &v) {
-    return make_uint4((uint32_t)v.lo, (uint32_t)(v.lo >> 32), (uint32_t)v.hi, (uint32_t)(v.hi >> 32));
-}
-template <class F>
-__device__ __forceinline__ typename F::T unpark(const uint4 &q);
-template <>
-__device__ __forceinline__ uint64_t unpark<F64>(const uint4 &q) {
-    return ((uint64_t)q.y << 32) | q.x;
-}
-template <>
-__device__ __forceinline__ U128 unpark<F128>(const uint4 &q) {
-    return U128{((uint64_t)q.y << 32) | q.x, ((uint64_t)q.w << 32) | q.z};
-}
-
 enum : int { SEG_OUT_SEG = 0, SEG_OUT_ROWS = 1 };
 
 // Tile-size specialisation of the pass kernels: LOGD != 0 instantiates a kernel for tiles of exactly 2^LOGD rows run by
