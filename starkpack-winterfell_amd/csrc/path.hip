@@ -484,6 +484,13 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             if (F::BYTES == 8 && !chunked && !multi && !a.pad_traces && a.logD == 10 && !ctx->tune.no_specialized)
                 kern = (const void *)k_seg_last_hash<F, false, false, false, false, F::BYTES == 8 ? 10 : 0>;
 #endif
+#ifndef WF_EXP_NO_SPEC_LAST10_MULTI
+            // several segments in 2^10-row tiles (2^20 x 64: last pass 3.68 -> 3.55 ms; the STARKPack shape of eight packed traces
+            // of eight columns: 3.62 -> 3.52)
+            if (F::BYTES == 8 && !chunked && multi && a.logD == 10 && !small && !ctx->tune.no_specialized)
+                kern = a.pad_traces ? (const void *)k_seg_last_hash<F, true, true, false, false, F::BYTES == 8 ? 10 : 0>
+                                    : (const void *)k_seg_last_hash<F, true, false, false, false, F::BYTES == 8 ? 10 : 0>;
+#endif
 #ifndef WF_EXP_NO_SPEC_LAST7
             // several segments in 2^7-row tiles (the last digit of the 2^22 plan: cfg 3's last pass 11.44 -> 11.12 ms)
             if (F::BYTES == 8 && !chunked && multi && !a.pad_traces && a.logD == 7 && small && !ctx->tune.no_specialized)
