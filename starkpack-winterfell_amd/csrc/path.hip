@@ -491,6 +491,14 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
                 kern = a.pad_traces ? (const void *)k_seg_last_hash<F, true, true, false, false, F::BYTES == 8 ? 10 : 0>
                                     : (const void *)k_seg_last_hash<F, true, false, false, false, F::BYTES == 8 ? 10 : 0>;
 #endif
+#ifndef WF_EXP_NO_SPEC_LAST_CHUNKED
+            // rows longer than a BLAKE3 chunk (chunk by chunk inside the pass): 2^10-row tiles (2^20 x 200: last pass 14.39 -> 14.08 ms),
+            // 2^9-row tiles (2^18 x 255: 3.65 -> 3.55)
+            if (F::BYTES == 8 && chunked && !a.pad_traces && !ctx->tune.no_specialized) {
+                if (a.logD == 10 && !small) kern = (const void *)k_seg_last_hash<F, true, false, true, false, F::BYTES == 8 ? 10 : 0>;
+                if (a.logD == 9 && small) kern = (const void *)k_seg_last_hash<F, true, false, true, true, F::BYTES == 8 ? 9 : 0>;
+            }
+#endif
 #ifndef WF_EXP_NO_SPEC_LAST7
             // several segments in 2^7-row tiles (the last digit of the 2^22 plan: cfg 3's last pass 11.44 -> 11.12 ms)
             if (F::BYTES == 8 && !chunked && multi && !a.pad_traces && a.logD == 7 && small && !ctx->tune.no_specialized)
