@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 PARITY_SWITCHES = ["WF_EXP_MAX_DIGIT=5", "WF_EXP_MAX_DIGIT=7", "WF_EXP_NO_FUSED_HASH=1",
-                   "WF_EXP_NO_PERSISTENT=1", "WF_EXP_NO_CHUNKED=1", "WF_EXP_PERSISTENT_ALWAYS=1"]
+                   "WF_EXP_NO_PERSISTENT=1", "WF_EXP_NO_CHUNKED=1", "WF_EXP_PERSISTENT_ALWAYS=1", "WF_EXP_NO_SPECIALIZED=1"]
 PARITY_FILES = ["test_gpu_coset_shard.py", "test_gpu_parity.py", "test_gpu_golden.py"]
 RESIDENT_SWITCHES = ["WF_EXP_PIPELINE_MIN_BYTES=0", "WF_EXP_PIPELINE_MIN_BYTES=0 WF_EXP_MAX_DIGIT=5", "WF_EXP_NO_PIPELINE=1"]
 RESIDENT_FILES = ["test_gpu_queries.py", "test_gpu_deep.py", "test_gpu_pipeline.py", "test_gpu_wide_resident.py"]
@@ -31,13 +31,13 @@ def _run_suite(switches, files):
 
 @pytest.fixture(scope="module")
 def forced_runs(capi):
-    """Every forced-plan run of this module, three child processes at a time (with this process: four on the GPU, within
+    """Every forced-plan run of this module, four child processes at a time (with this process: five on the GPU, within
     the pool's limit of six) -- most of a child's time is the CPU oracle, so the runs overlap well: the module takes a
     third of the wall clock of running them one after the other."""
     from concurrent.futures import ThreadPoolExecutor
     capi.load()
     jobs = [(sw, PARITY_FILES) for sw in PARITY_SWITCHES] + [(sw, RESIDENT_FILES) for sw in RESIDENT_SWITCHES]
-    with ThreadPoolExecutor(max_workers=3) as pool:
+    with ThreadPoolExecutor(max_workers=4) as pool:
         results = list(pool.map(lambda j: _run_suite(*j), jobs))
     return {sw: r for (sw, _), r in zip(jobs, results)}
 
@@ -49,7 +49,8 @@ def test_parity_under_forced_plans(forced_runs, switch):
     WF_EXP_NO_PERSISTENT: the fused last pass as one work-group per tile instead of the persistent ticket kernel.
     WF_EXP_NO_CHUNKED: rows longer than one BLAKE3 chunk hashed by the separate chunk kernels instead of chunk by chunk
     inside the persistent pass.  WF_EXP_PERSISTENT_ALWAYS: the ticket kernel also on the small shapes that normally take
-    one work-group per tile."""
+    one work-group per tile.  WF_EXP_NO_SPECIALIZED: every tile size on the generic kernels (the tile-size-specialised
+    instantiations are the default for 2^7 .. 2^10-row tiles, so without this run the generic code would see few shapes)."""
     out = forced_runs[switch]
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
 
