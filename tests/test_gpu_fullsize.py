@@ -236,3 +236,26 @@ def test_packed_8_traces_2_20_x8_full(ctx, orc, capi):
         for c in range(C):
             assert np.array_equal(got["polys"][t * C + c], want["polys"][t][c]), ("poly", t, c)
     ctx.release_cached()
+
+
+def test_tuning_switches_of_the_2_20_shape_give_the_same_bytes(ctx, capi, monkeypatch):
+    """The switches that only this shape reaches (read once per context, at wf_ctx_create): WF_EXP_FOLD_INPUT -- the first
+    interpolation pass gathers the caller's columns itself -- and WF_EXP_NO_SPECIALIZED -- every tile on the generic kernels.
+    Same polynomials, LDE, leaves, nodes and root as the default context (which test_cfg2_2_20_x8 checks against the oracle)."""
+    logR, logB, C = 20, 3, 8
+    rng = np.random.default_rng(77)
+    cols = [rand_f64(rng, 1 << logR) for _ in range(C)]
+    params = capi.make_params(F64, 1, logR, logB, C, 1)
+    want = ctx.trace_commit(params, cols)
+    for switch in ("WF_EXP_FOLD_INPUT", "WF_EXP_NO_SPECIALIZED"):
+        monkeypatch.setenv(switch, "1")
+        other = capi.Context(0)
+        monkeypatch.delenv(switch)
+        try:
+            got = other.trace_commit(params, cols)
+        finally:
+            other.close()
+        assert got["root"] == want["root"], switch
+        assert np.array_equal(got["lde"][0], want["lde"][0]) and np.array_equal(got["nodes"], want["nodes"]), switch
+        assert all(np.array_equal(a, b) for a, b in zip(got["polys"], want["polys"])), switch
+
