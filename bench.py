@@ -2,6 +2,7 @@
 """bench.py -- BASELINE.json metric on MI355X: trace-LDE + Merkle-commit of a 2^20 x 8 f64 trace at blowup 8.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode proofs|packed] [--config cfg2|cfg3|cfg5|dowork]
+                    [--ranks processes|threads]
 
 A "step" is one pass of the hot path (Prover::build_trace_commitment, /root/reference/prover/src/lib.rs:615-670)
 over one synthetic trace that is already resident in HBM: interpolate 8 columns -> evaluate over the 8 cosets into
@@ -16,8 +17,12 @@ environment) it is a rank.
       (wf_comm_all_gather_roots: the collective lives inside libwf_lde.so, behind the C ABI).
   --mode packed: ONE STARKPack commitment of 8 packed 2^20 x 8 traces, sharded by coset over the ranks
       (wf_trace_commit_sharded_dev; strong scaling).
-WF_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks: the ranks share
-the device and the bytes of the collectives travel over a torch.distributed gloo group (wf_transport).
+--ranks threads (N > 1 as a plain command): ONE process, one host thread + one wf_ctx + one wf_comm per GPU on real
+RCCL (ncclCommInitRank from N threads with one unique id) -- same steps, same gates, same JSON line; for boxes that
+limit the processes per card.  The parent decides the route before anything touches the GPU and never re-executes.
+WF_BENCH_BACKEND=gloo (processes) / loopback (threads) rehearses the multi-rank control flow on a box with fewer GPUs
+than ranks: the ranks share the device and the bytes of the collectives travel over a torch.distributed gloo group /
+through host memory (wf_transport).
 
 --config (single GPU) prints the same line for the other workloads of the record: cfg3 (2^22 x 64 f64), cfg5 (f128 2^18 x 10),
 dowork (the reference's example at its defaults: 512 packed f128 traces of 2^10); the headline stays cfg2.
@@ -390,11 +395,11 @@ def with_transfers(ctx, capi, params, trace_host, gpu_root):
         a = sorted(wide_commit() for _ in range(3))[1]
         # the same with the upload in front of the kernels: a second context created with WF_EXP_NO_PIPELINE set (the
         # library reads its tuning switches once, when a context is created)
-        os.environ["WF_EXP_NO_PIPELINE"] = "1"
+        os.environ["WF_EXP_NO_PIPELINE"] = os.environ["WF_EXP_ENABLE"] = "1"
         try:
             serial_ctx = capi.Context(ctx.device)
         finally:
-            del os.environ["WF_EXP_NO_PIPELINE"]
+            del os.environ["WF_EXP_NO_PIPELINE"], os.environ["WF_EXP_ENABLE"]
 
         def wide_commit_serial():
             t0 = time.perf_counter()
@@ -547,12 +552,82 @@ def verify_multi_rank(torch, capi, shard, ctx, comm, args, packed, params, rank,
     return (not failed), {"checked": what, "ok": not failed}
 
 
+class ThreadRanks:
+    """What the ranks of --ranks threads share: the RCCL unique id (drawn once, before the threads start) or the in-process
+    rehearsal transport, and a barrier for the few host-side hand-overs."""
+
+    def __init__(self, world, backend):
+        import threading
+        from starkpack_winterfell_amd import shard
+        self.world, self.backend = world, backend
+        self.uid = shard.unique_id() if backend == "rccl" else None
+        self.loopback = shard.Loopback(world, timeout=float(os.environ.get("WF_COMM_TIMEOUT_S", "300"))) if backend == "loopback" else None
+        self.host_barrier = threading.Barrier(world)
+        self.rc = [None] * world
+
+
+def run_threads(args):
+    """`python bench.py --gpus N --ranks threads`: the N ranks as N host threads of THIS process, one GPU each (device r for
+    rank r; `r % device_count` only under the loopback rehearsal).  Returns the exit code: non-zero if any rank failed, 124
+    if the ranks did not finish within WF_BENCH_LAUNCH_TIMEOUT_S (the process then ends without joining them)."""
+    import threading
+    import traceback
+    n = args.gpus
+    backend = os.environ.get("WF_BENCH_BACKEND", "rccl")
+    if backend == "gloo":
+        backend = "loopback"  # (the process-group rehearsal has no meaning inside one process)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch  # noqa: F401  (first import on the main thread)
+    import starkpack_winterfell_amd.capi as capi
+    n_dev = capi.device_count()
+    if n_dev < 1:
+        print("bench.py: no HIP device", file=sys.stderr, flush=True)
+        return 1
+    if backend == "rccl" and n_dev < n:
+        print(f"bench.py: --ranks threads on RCCL needs one device per rank ({n_dev} device(s), {n} ranks); "
+              f"WF_BENCH_BACKEND=loopback rehearses the same control flow on fewer", file=sys.stderr, flush=True)
+        return 1
+    shared = ThreadRanks(n, backend)
+
+    def body(r):
+        try:
+            rank_main(args, r, n, r, "threads", shared)
+            shared.rc[r] = 0
+        except SystemExit as e:
+            if e.code not in (None, 0):
+                print(f"rank {r}: {e.code}", file=sys.stderr, flush=True)
+            shared.rc[r] = 0 if e.code in (None, 0) else 1
+        except BaseException:  # noqa: BLE001 -- a rank's failure is the run's failure
+            traceback.print_exc()
+            shared.rc[r] = 1
+            try:
+                shared.host_barrier.abort()
+            except Exception:  # noqa: BLE001
+                pass
+
+    threads = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(n)]
+    for t in threads:
+        t.start()
+    limit = float(os.environ.get("WF_BENCH_LAUNCH_TIMEOUT_S", "900"))
+    deadline = time.monotonic() + limit
+    for t in threads:
+        t.join(timeout=max(0.0, deadline - time.monotonic()))
+    if any(t.is_alive() for t in threads):
+        print(f"bench.py: the {n} rank threads did not finish within {limit:.0f} s; ending the process", file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(124)  # the stuck threads sit inside the runtime: no orderly shutdown to wait for
+    return 0 if all(rc == 0 for rc in shared.rc) else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=("proofs", "packed"), default="proofs")
+    ap.add_argument("--ranks", choices=("processes", "threads"), default=os.environ.get("WF_BENCH_RANKS", "processes"),
+                    help="N > 1: one process per GPU under torch.distributed.run (default), or one host thread per GPU in this "
+                         "process -- both on RCCL inside libwf_lde.so, same steps, gates and JSON line")
     ap.add_argument("--config", choices=tuple(CONFIGS), default="cfg2",
                     help="workload (single GPU for all but cfg2): cfg2 = the metric; cfg3 = 2^22 x 64 f64; cfg5 = f128 2^18 x 10; "
                          "dowork = the reference's example defaults (512 packed f128 traces of 2^10)")
@@ -566,16 +641,23 @@ def main():
 
     if args.config != "cfg2" and (args.gpus > 1 or args.mode != "proofs"):
         sys.exit("--config other than cfg2 is a single-GPU record of the default mode (the multi-GPU modes run the metric's workload)")
+    # N > 1 as a plain command: the route is chosen HERE, before this process has touched the GPU -- child processes (never
+    # an exec of this one), or threads of this process
     if args.gpus > 1 and "RANK" not in os.environ:
-        sys.exit(launch_ranks(args.gpus))
+        sys.exit(run_threads(args) if args.ranks == "threads" else launch_ranks(args.gpus))
+    rank_main(args, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0")),
+              "processes", None)
 
+
+def rank_main(args, rank, world, local_rank, route, shared):
+    """One rank: a process started by torch.distributed.run (route "processes"; also the single-GPU run) or a thread of
+    run_threads (route "threads")."""
+    import copy
+    args = copy.copy(args)  # (per rank: args.gpus is overwritten below)
     import torch
     import starkpack_winterfell_amd.capi as capi
     from starkpack_winterfell_amd import shard
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
     # one rank per GPU; the modulo only matters for rehearsals of the multi-rank control flow on a box with fewer GPUs
     # than ranks (WF_BENCH_BACKEND=gloo, see DESIGN.md §6) -- RCCL itself refuses two ranks on one device
@@ -586,7 +668,14 @@ def main():
 
     ctx = capi.Context(dev_index)
     comm = None
-    if world > 1:
+    if world > 1 and route == "threads":
+        # one communicator per thread, all from the id the parent drew: ncclCommInitRank returns when all `world` threads
+        # have called it (or the rehearsal transport: the same partitioning and kernels, bytes through host memory)
+        if shared.backend == "loopback":
+            comm = shard.Comm.with_transport(ctx, rank, world, *shared.loopback.collectives(rank))
+        else:
+            comm = shard.Comm.with_unique_id(ctx, shared.uid, rank, world)
+    elif world > 1:
         if backend == "gloo":
             import torch.distributed as dist
             dist.init_process_group("gloo")
@@ -691,11 +780,20 @@ def main():
         for name, ms in ctx.profile_read():
             per_launch.setdefault(name, []).append(ms)
 
+    per_rank_ms, comm_info = None, None
     if comm is not None:
+        if comm.transport != "torch":
+            # every rank's own time for its K steps, and what the transport says about the communicator each rank holds
+            per_rank_ms = [t / args.steps * 1e3 for t in comm.gather_f64(elapsed)]
+            mine = comm.info()
+            comm_info = {"transport": mine["transport"], "count": mine["count"],
+                         "user_ranks": [int(x) for x in comm.gather_f64(mine["user_rank"])],
+                         "devices": [int(x) for x in comm.gather_f64(mine["device"])],
+                         "counts": [int(x) for x in comm.gather_f64(mine["count"])]}
         elapsed = comm.max_f64(elapsed)  # MAX over ranks
     verified = None
     if args.inject_fault == "hang" and rank == world - 1 and world > 1:
-        time.sleep(3600)
+        time.sleep(3600)  # (threads route: a daemon thread -- the parent's limit ends the process)
     if args.inject_fault == "root" and world > 1:
         torch.cuda.synchronize()
         if packed and rank == world - 1:
@@ -798,7 +896,16 @@ def main():
             "collective": (None if comm is None else
                            {"transport": "RCCL inside libwf_lde.so (wf_comm, C ABI)" if comm.transport == "rccl"
                             else ("FALLBACK: torch.distributed nccl (= RCCL), wf_comm failed: " + comm.reason) if comm.transport == "torch"
+                            else "wf_transport through host memory between the threads of one process (rehearsal)" if route == "threads"
                             else "wf_transport over torch.distributed gloo (rehearsal)",
+                            "ranks": ("one host thread per GPU in one process" if route == "threads" else "one process per GPU (torch.distributed.run)"),
+                            # ncclCommCount / ncclCommUserRank / ncclCommCuDevice as every rank's communicator reports them
+                            # (wf_comm_info): RCCL itself saying that it spans `world` ranks on `world` distinct devices
+                            "nccl_comm_count": comm_info["count"] if comm_info else None,
+                            "nccl_comm_counts": comm_info["counts"] if comm_info else None,
+                            "nccl_user_ranks": comm_info["user_ranks"] if comm_info else None,
+                            "nccl_devices": comm_info["devices"] if comm_info else None,
+                            "ms_per_step_per_rank": [round(x, 4) for x in per_rank_ms] if per_rank_ms else None,
                             "rccl_version": capi.load().wf_comm_rccl_version() if comm.transport == "rccl" else None,
                             "rccl_path": (capi.load().wf_comm_rccl_path() or b"").decode() if comm.transport == "rccl" else None,
                             "verified": verified,
@@ -840,7 +947,7 @@ def main():
     if comm is not None:
         comm.barrier()
         comm.close()
-        if backend == "gloo":
+        if backend == "gloo" and route == "processes":
             import torch.distributed as dist
             dist.destroy_process_group()
     ctx.close()

@@ -51,7 +51,7 @@ enum wf_status {
     WF_ERR_ARG = -19,          /* null pointer or other malformed argument */
     WF_ERR_BUSY = -20,         /* the context is inside a call of another thread (one call at a time per wf_ctx) */
     WF_ERR_HIP = -30,          /* HIP runtime failure (no device, out of memory, launch failure) */
-    WF_ERR_DIGEST = -31,       /* digest_bytes != 32 */
+    WF_ERR_DIGEST = -31,       /* digest_bytes is neither 32 (Blake3_256) nor 24 (Blake3_192) */
     WF_ERR_COMM = -32          /* RCCL (or caller-supplied transport) failure, librccl.so.1 not loadable */
 };
 
@@ -221,6 +221,14 @@ int wf_comm_all_gather_roots(wf_comm *comm, const void *d_roots, size_t n_roots,
  * the context's stream has finished when it returns) and the maximum of one double over all ranks (in place). */
 int wf_comm_barrier(wf_comm *comm);
 int wf_comm_max_f64(wf_comm *comm, double *value);
+/* One double of every rank to every rank (all_out: wf_comm_world values, rank-major) -- the per-rank step times of a
+ * multi-GPU benchmark record.  Host-blocking, under the watchdog. */
+int wf_comm_gather_f64(wf_comm *comm, double value, double *all_out);
+/* What the transport itself reports about this communicator: transport = 0 (RCCL) or 1 (caller-supplied); for RCCL
+ * ncclCommCount / ncclCommUserRank / ncclCommCuDevice of the ncclComm_t in use -- the record of a multi-GPU run shows
+ * with these that RCCL really spans `world` ranks, one per device -- for a caller-supplied transport the world, rank
+ * and device the communicator was created with.  Any output pointer may be NULL. */
+int wf_comm_info(const wf_comm *comm, int *transport, int *nccl_count, int *nccl_user_rank, int *nccl_device);
 /* Host-blocking wait for everything queued on `stream` (NULL = the context's stream), collectives included, under the
  * communicator's watchdog: after WF_COMM_TIMEOUT_S seconds (environment, read at wf_comm_create; default 300) without
  * completion -- a peer died or never entered the collective -- the communicator is aborted (ncclCommAbort) and

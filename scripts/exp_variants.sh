@@ -1,5 +1,7 @@
 #!/bin/bash
-# Tuning aid: build variants of libwf_lde.so with experiment macros into build/exp_<name>/ and time cfg 2 with each
+# Tuning aid: build variants of libwf_lde.so into build/exp_<name>/ -- any flags (a kernel change behind a macro of its own), or
+# the diagnostic switches of the experiment build (-DWF_EXPERIMENTS -DWF_EXP_SKIP_LOAD / _SKIP_NTT / _SKIP_STORE / _LOCAL_STORE=1|2 /
+# _STAMPS; the product build ignores them) -- and time cfg 2 with each
 # (run the timing part on the GPU box:  WF_LDE_LIB=build/exp_<name>/libwf_lde.so python scripts/time_config.py 1 1 20 3 8 1).
 #   scripts/exp_variants.sh [name "flags"]...   (default: the time-attribution set of DESIGN.md §4)
 set -e
@@ -19,11 +21,9 @@ if [ $# -ge 2 ]; then
     while [ $# -ge 2 ]; do build_variant "$1" "$2"; shift 2; done
     exit 0
 fi
-build_variant skip_ntt "-DWF_EXP_SKIP_NTT"
-build_variant no_xcd "-DWF_EXP_NO_XCD_REMAP"
-build_variant skip_store "-DWF_EXP_SKIP_STORE"
-build_variant skip_load "-DWF_EXP_SKIP_LOAD"
-build_variant skip_mem "-DWF_EXP_SKIP_LOAD -DWF_EXP_SKIP_STORE"
-build_variant skip_ntt_store "-DWF_EXP_SKIP_NTT -DWF_EXP_SKIP_STORE"
-build_variant skip_ntt_load "-DWF_EXP_SKIP_NTT -DWF_EXP_SKIP_LOAD"
-build_variant nt_store "-DWF_EXP_NT_STORE"
+build_variant skip_ntt "-DWF_EXPERIMENTS -DWF_EXP_SKIP_NTT"
+build_variant skip_store "-DWF_EXPERIMENTS -DWF_EXP_SKIP_STORE"
+build_variant skip_load "-DWF_EXPERIMENTS -DWF_EXP_SKIP_LOAD"
+build_variant skip_mem "-DWF_EXPERIMENTS -DWF_EXP_SKIP_LOAD -DWF_EXP_SKIP_STORE"
+build_variant skip_ntt_store "-DWF_EXPERIMENTS -DWF_EXP_SKIP_NTT -DWF_EXP_SKIP_STORE"
+build_variant skip_ntt_load "-DWF_EXPERIMENTS -DWF_EXP_SKIP_NTT -DWF_EXP_SKIP_LOAD"

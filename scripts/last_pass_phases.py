@@ -1,4 +1,4 @@
-"""Diagnostic (needs build/exp_stamps/libwf_lde.so = the library built with -DWF_EXP_STAMPS): where a work-group of the
+"""Diagnostic (needs build/exp_stamps/libwf_lde.so = the library built with -DWF_EXPERIMENTS -DWF_EXP_STAMPS): where a work-group of the
 persistent last pass (k_seg_last_hash) spends its cycles, phase by phase, on cfg 2.  Thread 0 of every work-group sums
 s_memtime differences between phase boundaries over its tiles.
     WF_LDE_LIB=build/exp_stamps/libwf_lde.so python scripts/last_pass_phases.py"""

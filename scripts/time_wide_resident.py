@@ -1,5 +1,5 @@
 """Wall clock of wf_trace_commit_resident from HOST columns for a wide trace (several segments), with the upload running
-under the kernels (default) -- run once more with WF_EXP_NO_PIPELINE=1 for the serial order.
+under the kernels (default) -- run once more with WF_EXP_ENABLE=1 WF_EXP_NO_PIPELINE=1 for the serial order.
     python scripts/time_wide_resident.py [logR] [cols] [polys]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

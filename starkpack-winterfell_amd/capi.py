@@ -31,7 +31,7 @@ SYMBOLS = [
     "wf_fft_interpolate_poly_with_offset", "wf_evaluate_polys_over", "wf_hash_rows", "wf_merkle_build",
     "wf_comm_unique_id", "wf_comm_create", "wf_comm_create_with_transport", "wf_comm_destroy", "wf_comm_rank",
     "wf_comm_world", "wf_comm_rccl_version", "wf_comm_rccl_path", "wf_comm_stream_wait", "wf_comm_all_gather", "wf_comm_all_gather_roots", "wf_comm_barrier",
-    "wf_comm_max_f64", "wf_shard_proofs", "wf_shard_cosets", "wf_shard_route", "wf_comm_all_gather_leaf_shards",
+    "wf_comm_max_f64", "wf_comm_gather_f64", "wf_comm_info", "wf_shard_proofs", "wf_shard_cosets", "wf_shard_route", "wf_comm_all_gather_leaf_shards",
     "wf_trace_commit_sharded_dev", "wf_trace_commit_sharded_resident", "wf_sharded_commitment_destroy",
     "wf_sharded_commitment_root", "wf_sharded_commitment_query", "wf_sharded_commitment_polys",
 ]
@@ -218,6 +218,8 @@ def load():
         L.wf_comm_all_gather_roots.argtypes = [vp, vp, sz, vp, vp]
         L.wf_comm_barrier.argtypes = [vp]
         L.wf_comm_max_f64.argtypes = [vp, C.POINTER(C.c_double)]
+        L.wf_comm_gather_f64.argtypes = [vp, C.c_double, C.POINTER(C.c_double)]
+        L.wf_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
         L.wf_shard_proofs.argtypes = [u32, u32, u32, pu32, pu32]
         L.wf_shard_cosets.argtypes = [u32, u32, u32, pu32, pu32]
         L.wf_shard_route.argtypes = [u32, u32, u32, C.c_uint64, pu32, pu64, pu32, pu64]

@@ -32,6 +32,9 @@ struct Rccl {
     decltype(&ncclGetVersion) GetVersion = nullptr;
     decltype(&ncclCommAbort) CommAbort = nullptr;                  // optional: the watchdog of the blocking calls
     decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;  // optional
+    decltype(&ncclCommCount) CommCount = nullptr;                  // optional: wf_comm_info
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;            // optional
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;            // optional
     char path[512] = "";         // the file the symbols came from (dladdr): which copy of RCCL a process really runs
     char load_error[256] = "";   // dlerror() of the failed load, kept (dlerror() itself reports an error only once)
 };
@@ -64,6 +67,9 @@ static bool rccl_load(Rccl &r) {
 #undef WF_SYM
     r.CommAbort = (decltype(r.CommAbort))dlsym(h, "ncclCommAbort");
     r.CommGetAsyncError = (decltype(r.CommGetAsyncError))dlsym(h, "ncclCommGetAsyncError");
+    r.CommCount = (decltype(r.CommCount))dlsym(h, "ncclCommCount");
+    r.CommUserRank = (decltype(r.CommUserRank))dlsym(h, "ncclCommUserRank");
+    r.CommCuDevice = (decltype(r.CommCuDevice))dlsym(h, "ncclCommCuDevice");
     Dl_info info;
     if (dladdr((const void *)r.AllGather, &info) && info.dli_fname) snprintf(r.path, sizeof(r.path), "%s", info.dli_fname);
     r.load_error[0] = 0;
@@ -272,6 +278,9 @@ void wf_comm_destroy(wf_comm *c) {
     }
     if (c->stage.p) (void)hipFree(c->stage.p);
     if (c->small.p) (void)hipFree(c->small.p);
+    // (hipHostFree waits for the device: a copy into these buffers that a timed-out collective left queued has either run
+    // or been dropped with its aborted communicator's kernels before the memory goes away)
+    if (c->pin) (void)hipHostFree(c->pin);
     delete c;
 }
 
@@ -308,19 +317,45 @@ int wf_comm_all_gather_roots(wf_comm *c, const void *d_roots, size_t n_roots, vo
 
 }  // extern "C"
 
-// all-gather of one 8-byte word per rank through the device, result on the host (blocking)
+// Pinned host memory owned by the communicator for what its host-blocking calls copy back (the gathered words of
+// barrier / max / agree, the top levels of a sharded commitment, the merged messages of a collective query).  The
+// destination of such a copy must not be pageable (hipMemcpyAsync into pageable memory holds the HOST until the
+// collective in front of it has run: a missing peer would hang the caller before the watchdog is ever reached) and must
+// outlive a timed-out call (the copy may still be queued when WF_ERR_COMM is returned): it lives here until
+// wf_comm_destroy, and is read only after comm_wait has succeeded.
+int comm_pinned(wf_comm *c, size_t bytes, void **out) {
+    if (bytes > c->pin_cap) {
+        // (growing means freeing: only while nothing of an earlier, failed call can still be in flight)
+        if (c->dead) return fail(WF_ERR_COMM, "the communicator was aborted after a failed or timed-out collective");
+        if (c->pin) HIP_TRY(hipHostFree(c->pin));
+        c->pin = nullptr;
+        c->pin_cap = 0;
+        const size_t cap = std::max<size_t>(bytes, 4096);
+        HIP_TRY(hipHostMalloc(&c->pin, cap, hipHostMallocDefault));
+        c->pin_cap = cap;
+    }
+    *out = c->pin;
+    return 0;
+}
+
+// all-gather of one 8-byte word per rank through the device, result on the host (blocking, under the watchdog)
 static int comm_gather_words(wf_comm *c, uint64_t mine, std::vector<uint64_t> &all) {
     HIP_TRY(hipSetDevice(c->ctx->device));
     int rc = ensure(c->ctx, c->small, 8 * (size_t)(c->world + 1));
     if (rc) return rc;
+    void *pin;
+    if ((rc = comm_pinned(c, 8 * (size_t)(c->world + 1), &pin))) return rc;
+    uint64_t *h = (uint64_t *)pin;  // [0] = this rank's word on its way up, [1 ..] = everybody's on their way back
     hipStream_t st = c->ctx->stream;
     uint64_t *d = (uint64_t *)c->small.p;
-    HIP_TRY(hipMemcpyAsync(d, &mine, 8, hipMemcpyHostToDevice, st));
+    h[0] = mine;
+    HIP_TRY(hipMemcpyAsync(d, h, 8, hipMemcpyHostToDevice, st));
     rc = comm_all_gather(c, d, d + 1, 8, st);
     if (rc) return rc;
-    all.resize(c->world);
-    HIP_TRY(hipMemcpyAsync(all.data(), d + 1, 8 * (size_t)c->world, hipMemcpyDeviceToHost, st));
-    return comm_wait(c, st);
+    HIP_TRY(hipMemcpyAsync(h + 1, d + 1, 8 * (size_t)c->world, hipMemcpyDeviceToHost, st));
+    if ((rc = comm_wait(c, st))) return rc;  // on a time-out the copy may still be queued: its destination stays allocated
+    all.assign(h + 1, h + 1 + c->world);
+    return 0;
 }
 
 // Collective entry points agree on a status word before their data exchange: a rank that failed locally (allocation, a
@@ -360,6 +395,35 @@ int wf_comm_max_f64(wf_comm *c, double *value) {
         if (v > m) m = v;
     }
     *value = m;
+    return 0;
+}
+
+int wf_comm_gather_f64(wf_comm *c, double value, double *all_out) {
+    if (!c || !all_out) return fail(WF_ERR_ARG, "null argument");
+    uint64_t bits;
+    memcpy(&bits, &value, 8);
+    std::vector<uint64_t> all;
+    int rc = comm_gather_words(c, bits, all);
+    if (rc) return rc;
+    memcpy(all_out, all.data(), 8 * all.size());
+    return 0;
+}
+
+int wf_comm_info(const wf_comm *c, int *transport, int *nccl_count, int *nccl_user_rank, int *nccl_device) {
+    if (!c) return fail(WF_ERR_ARG, "comm is null");
+    int count = c->world, user = c->rank, dev = c->ctx->device;
+    if (transport) *transport = c->custom ? 1 : 0;
+    if (!c->custom && ((ncclComm_t &)const_cast<wf_comm *>(c)->nccl)) {
+        // what RCCL itself says about this communicator (not what the caller passed to wf_comm_create)
+        wfcomm::Rccl *R = wfcomm::rccl();
+        ncclComm_t comm = (ncclComm_t &)const_cast<wf_comm *>(c)->nccl;
+        if (R && R->CommCount) RCCL_TRY(R->CommCount(comm, &count));
+        if (R && R->CommUserRank) RCCL_TRY(R->CommUserRank(comm, &user));
+        if (R && R->CommCuDevice) RCCL_TRY(R->CommCuDevice(comm, &dev));
+    }
+    if (nccl_count) *nccl_count = count;
+    if (nccl_user_rank) *nccl_user_rank = user;
+    if (nccl_device) *nccl_device = dev;
     return 0;
 }
 

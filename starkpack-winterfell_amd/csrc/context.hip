@@ -20,10 +20,16 @@ int fail(int code, const char *fmt, ...) {
 
 const char *last_error_text() { return g_err; }
 
-// WF_EXP_* switches: read here, once per context (see wf_tuning)
+// WF_EXP_* switches: read here, once per context, and only under WF_EXP_ENABLE=1 (see wf_tuning); out-of-range values are
+// ignored (the planner holds at most four digits: a digit cap below 4 bits cannot plan 2^16 rows and up)
 wf_tuning tuning_from_env() {
     wf_tuning t;
-    if (const char *e = getenv("WF_EXP_MAX_DIGIT")) t.max_digit = (uint32_t)atoi(e);
+    const char *on = getenv("WF_EXP_ENABLE");
+    if (!on || strcmp(on, "1") != 0) return t;
+    if (const char *e = getenv("WF_EXP_MAX_DIGIT")) {
+        const int v = atoi(e);
+        if (v >= 4 && v <= 11) t.max_digit = (uint32_t)v;
+    }
     t.no_specialized = getenv("WF_EXP_NO_SPECIALIZED") != nullptr;
     t.full_tiles = getenv("WF_EXP_FULL_TILES") != nullptr;
     t.no_fused_hash = getenv("WF_EXP_NO_FUSED_HASH") != nullptr;
@@ -35,10 +41,14 @@ wf_tuning tuning_from_env() {
         if (v >= 10 && v <= 30) t.merkle_l2_min = (uint32_t)v;
     }
     t.no_pipeline = getenv("WF_EXP_NO_PIPELINE") != nullptr;
-    t.single_fused = getenv("WF_EXP_SINGLE_FUSED") != nullptr;
-    t.fold_input = getenv("WF_EXP_FOLD_INPUT") != nullptr;
-    if (const char *e = getenv("WF_EXP_PIPELINE_MIN_BYTES")) t.pipeline_min_bytes = (size_t)atoll(e);
-    if (const char *e = getenv("WF_EXP_FAIL_AFTER_SEGMENT")) t.fail_after_segment = atoi(e);
+    if (const char *e = getenv("WF_EXP_PIPELINE_MIN_BYTES")) {
+        const long long v = atoll(e);
+        if (v >= 0 && v <= (1ll << 40)) t.pipeline_min_bytes = (size_t)v;
+    }
+    if (const char *e = getenv("WF_EXP_FAIL_AFTER_SEGMENT")) {  // error-path test of the pipelined upload
+        const int v = atoi(e);
+        if (v >= 0 && v < 4096) t.fail_after_segment = v;
+    }
     return t;
 }
 
@@ -55,6 +65,12 @@ bool ctx_alive(const wf_ctx *ctx) {
 bool ctx_alive(const wf_ctx *ctx, uint64_t generation) {
     std::lock_guard<std::mutex> lock(g_ctx_mutex);
     return g_live_ctx.count(ctx) != 0 && ctx->generation == generation;
+}
+// The registry's lock, for the few places that must keep a context alive while they touch it from a thread that does not
+// own a call on it (a handle destroyed or waited for on a finaliser thread): wf_ctx_destroy takes the same lock to retire
+// the context, so whoever holds it and finds the context in the registry may use the context's pool and pinned slots.
+CtxPin::CtxPin(const wf_ctx *ctx, uint64_t generation) : lock(g_ctx_mutex) {
+    alive = g_live_ctx.count(ctx) != 0 && ctx->generation == generation;
 }
 
 // hipMalloc that gives the context's parked buffers back to the driver and retries once when the device is full
@@ -95,23 +111,22 @@ hipError_t pool_alloc(wf_ctx *ctx, void **p, size_t bytes) {
 // host's finalisers run on, possibly while a call of another thread is in progress on the context.
 void pool_free(wf_ctx *ctx, uint64_t generation, void *p, size_t bytes) {
     if (!p) return;
-    if (!ctx_alive(ctx, generation)) {  // (see g_live_ctx: the handle outlived its context)
-        (void)hipFree(p);
-        return;
-    }
-    if (!bytes || bytes > ctx->pool_cap) {
-        (void)hipFree(p);
-        return;
-    }
     std::vector<void *> drop;
     {
-        std::lock_guard<std::mutex> lock(ctx->pool_mutex);
-        ctx->pool.emplace_back(p, bytes);
-        ctx->pool_bytes += bytes;
-        while (!ctx->pool.empty() && (ctx->pool.size() > 16 || ctx->pool_bytes > ctx->pool_cap)) {
-            drop.push_back(ctx->pool.front().first);
-            ctx->pool_bytes -= ctx->pool.front().second;
-            ctx->pool.erase(ctx->pool.begin());
+        // the registry stays locked while the context is touched: a concurrent wf_ctx_destroy waits until the buffer is parked
+        // (and then releases it with the rest of the pool) or has already retired the context (the buffer is freed directly)
+        CtxPin pin(ctx, generation);
+        if (!pin.alive || !bytes || bytes > ctx->pool_cap) {  // (not alive: the handle outlived its context)
+            drop.push_back(p);
+        } else {
+            std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+            ctx->pool.emplace_back(p, bytes);
+            ctx->pool_bytes += bytes;
+            while (!ctx->pool.empty() && (ctx->pool.size() > 16 || ctx->pool_bytes > ctx->pool_cap)) {
+                drop.push_back(ctx->pool.front().first);
+                ctx->pool_bytes -= ctx->pool.front().second;
+                ctx->pool.erase(ctx->pool.begin());
+            }
         }
     }
     for (void *d : drop) (void)hipFree(d);
@@ -323,9 +338,12 @@ void wf_ctx_destroy(wf_ctx *ctx) {
         if (b.p) (void)hipFree(b.p);
     if (ctx->hash_tmp.p) (void)hipFree(ctx->hash_tmp.p);
     if (ctx->tickets.p) (void)hipFree(ctx->tickets.p);
-    if (ctx->chain_flags.p) (void)hipFree(ctx->chain_flags.p);
     if (ctx->pack_tmp.p) (void)hipFree(ctx->pack_tmp.p);
-    for (auto &b : ctx->pool) (void)hipFree(b.first);
+    {
+        std::lock_guard<std::mutex> lock(ctx->pool_mutex);  // (nobody can be inside pool_free any more: the context is retired)
+        for (auto &b : ctx->pool) (void)hipFree(b.first);
+        ctx->pool.clear();
+    }
     for (hipEvent_t e : ctx->seg_events) (void)hipEventDestroy(e);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->pin) (void)hipHostFree(ctx->pin);

@@ -667,11 +667,8 @@ static __global__ void __launch_bounds__(256) k_gather_digests(const uint4 *__re
 // Two Merkle levels per launch: lane i reads four children (128 contiguous bytes), writes parents 2i, 2i+1 and
 // grandparent i.  Halves the launches and the re-reads of the level-per-launch form for the wide levels.
 // (six waves per SIMD instead of the seven its 72 VGPRs allow: 0.251 -> 0.240 ms for the 2^23-leaf tree, same box, same code)
-#ifndef WF_EXP_MERKLE_WAVES
-#define WF_EXP_MERKLE_WAVES 6
-#endif
 template <int DW>
-__attribute__((amdgpu_waves_per_eu(WF_EXP_MERKLE_WAVES, WF_EXP_MERKLE_WAVES)))
+__attribute__((amdgpu_waves_per_eu(6, 6)))
 __global__ void __launch_bounds__(256) k_merkle_level2(const uint32_t *__restrict__ children,
                                                        uint32_t *__restrict__ parents,
                                                        uint32_t *__restrict__ grandparents, uint64_t n_grand) {

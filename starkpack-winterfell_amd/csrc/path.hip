@@ -10,7 +10,7 @@
 
 using namespace wf;
 
-#ifdef WF_EXP_STAMPS
+#if defined(WF_EXPERIMENTS) && defined(WF_EXP_STAMPS)
 // diagnostic build (scripts/last_pass_phases.py): cycle sums per work-group and phase of the persistent last pass
 static unsigned long long *g_exp_stamps = nullptr;
 static unsigned long long *exp_stamps_buffer() {
@@ -135,6 +135,7 @@ static int run_transform(wf_ctx *ctx, hipStream_t st, const XformDesc<F> &d) {
         if (rc) return rc;
         const uint64_t grid = (uint64_t)d.batch * a.O * (a.I / a.Tl);
         if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
+        prof_mark(ctx, st, d.inverse ? "fft.interpolate.strided_pass" : "fft.evaluate.strided_pass");
         hipLaunchKernelGGL(k_ntt_strided<F>, dim3((uint32_t)grid), dim3(threads), lds, st, a);
         HIP_TRY(hipGetLastError());
         done_bits += a.logD;
@@ -160,8 +161,10 @@ static int run_transform(wf_ctx *ctx, hipStream_t st, const XformDesc<F> &d) {
         if (rc) return rc;
         const uint64_t grid = (uint64_t)d.batch * (a.O / a.Tl);
         if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
+        prof_mark(ctx, st, d.inverse ? "fft.interpolate.last_pass" : "fft.evaluate.last_pass");
         hipLaunchKernelGGL(k_ntt_last<F>, dim3((uint32_t)grid), dim3(threads), lds, st, a);
         HIP_TRY(hipGetLastError());
+        prof_mark(ctx, st, "between_calls");
     }
     return 0;
 }
@@ -171,11 +174,7 @@ static int seg_launch_dims(uint32_t logD, uint32_t &threads, size_t &lds, bool l
     const size_t D = (size_t)1 << logD;
     // tile + digit twiddles (+ the factor table of a strided pass; a last pass keeps its input factors where the
     // twiddles go afterwards: a 2^10-row f128 tile is 80 KiB, two work-groups per CU)
-#ifdef WF_EXP_TWO_TABLES
-    constexpr bool one_table = false;
-#else
     constexpr bool one_table = F::BYTES == 16;  // k_seg_strided, ONE_TABLE: the f128 strided pass time-shares one table region
-#endif
     lds = (D * SegCfg<F>::S + (last_pass || one_table ? 1 : 2) * D) * sizeof(typename F::T);
     if (lds > 160 * 1024) return fail(WF_ERR_ARG, "internal: pass needs %zu bytes of LDS", lds);
     // one work item of the widest round per thread (radix-16 on 8 lanes for f64, radix-4 on lane pairs for f128: D/2
@@ -237,7 +236,6 @@ struct SegDesc {
     const T *in;
     T *work;
     T *out;
-    const T *in_cols = nullptr;  // interpolation, tuning (wf_tuning::fold_input): the first strided pass reads these COLUMNS
     uint32_t logN, n_seg, n_cosets;
     bool rows_out;
     void *leaves = nullptr;     // rows_out: hash the leaves in the last pass when the shape allows (sets *fused)
@@ -324,8 +322,6 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         } else {
             a.src = first ? d.in : d.work;  // interpolation: first pass in -> work, later passes in place
             a.dst = d.work;
-            a.src_cols = first ? d.in_cols : nullptr;
-            a.src_cols_rows = N;
             a.src_shared = 0;
             a.pre_on = 0;
             a.scale_on = first ? 1 : 0;     // 1/n rides on the first inter-pass twiddle table
@@ -341,30 +337,16 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         const uint64_t grid = (uint64_t)n_groups * run_cnt * a.O * a.I;
         if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
         prof_mark(ctx, st, tag_s);
-        // f64 tiles of 2^10 rows (the digits of the 2^19 .. 2^21 plans) run the tile-size-specialised instantiation
-        // (seg_kernels.hpp, WF_TILE_BOUNDS: strided pass of cfg 2 0.347 -> 0.324 ms); everything else the generic kernel.
-        // Measured and left out: 2^7 / 2^8-row tiles (2^22 x 64: 36.8 -> 37.5 ms, no gain), and the last passes, which
-        // specialised for the tile size need more registers than two work-groups per CU allow (scratch spills).
+        // f64 tiles of 2^10 and 2^9 rows (the digits of the 2^17 .. 2^21 plans) run the tile-size-specialised instantiations
+        // (seg_kernels.hpp, WF_TILE_BOUNDS: strided pass of cfg 2 0.347 -> 0.324 ms); everything else the generic kernel
+        // (2^7 / 2^8-row tiles and the f128 tiles measured slower or the same specialised: DESIGN.md section 9).
         const bool spec_ok = F::BYTES == 8 && !packed && threads * 2 == (1u << a.logD) && !ctx->tune.no_specialized;
         const void *kern = nullptr;
-#ifdef WF_EXP_SPEC9_F128
-        if (F::BYTES == 16 && !packed && threads * 2 == (1u << a.logD) && a.logD == 9 && !ctx->tune.no_specialized)
-            kern = d.rows_out ? (const void *)k_seg_strided<F, 1, false, F::BYTES == 16 ? 9 : 0> : (const void *)k_seg_strided<F, 0, false, F::BYTES == 16 ? 9 : 0>;
-#endif
         if (spec_ok) {
             constexpr bool F8 = F::BYTES == 8;  // (the specialised instantiations exist for f64 only)
             switch (a.logD) {
                 case 10: kern = d.rows_out ? (const void *)k_seg_strided<F, 1, false, F8 ? 10 : 0> : (const void *)k_seg_strided<F, 0, false, F8 ? 10 : 0>; break;
-#ifndef WF_EXP_NO_SPEC9
                 case 9: kern = d.rows_out ? (const void *)k_seg_strided<F, 1, false, F8 ? 9 : 0> : (const void *)k_seg_strided<F, 0, false, F8 ? 9 : 0>; break;
-#endif
-#ifdef WF_EXP_SPEC8
-                case 8: kern = d.rows_out ? (const void *)k_seg_strided<F, 1, false, F8 ? 8 : 0> : (const void *)k_seg_strided<F, 0, false, F8 ? 8 : 0>; break;
-#endif
-#ifdef WF_EXP_SPEC7
-                // 2^7-row tiles (the middle digit of the 2^22 plan): the radix-4 round's twiddles w_8^(j k) are shifts there
-                case 7: kern = d.rows_out ? (const void *)k_seg_strided<F, 1, false, F8 ? 7 : 0> : (const void *)k_seg_strided<F, 0, false, F8 ? 7 : 0>; break;
-#endif
                 default: break;
             }
         }
@@ -434,41 +416,6 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         a.leaves = fuse ? (uint32_t *)d.leaves : nullptr;
         a.hash_epr = d.hash_epr;
         if (d.fused) *d.fused = fuse;
-        // single pass, rows of several BLAKE3 chunks (many packed traces of few steps: the reference's own example): every
-        // tile its own ticket, chunk chaining values handed from work-group to work-group (k_seg_single_hash).  OPT-IN
-        // (wf_tuning::single_fused): bit-exact, but measured SLOWER than the separate chunk kernels on the shape it was
-        // built for (512 x 2^10 x 10 f128: 1.63 ms against 0.76 + 0.38 ms; DESIGN.md §9 has the breakdown)
-        const uint64_t resident_single = (uint64_t)ctx->num_cus * std::max<size_t>(1, (160 * 1024) / lds);
-        const bool single_fused = single && may_fuse && chunked && threads * 2 == (1u << a.logD) && threads <= 512 &&
-                                  (uint64_t)d.n_cosets * d.n_seg >= 2 * resident_single && launch_rows * n_chunks * 32 < (1ull << 40) &&
-                                  (uint64_t)d.n_cosets * n_chunks * 16 < (1ull << 28) && ctx->tune.single_fused;
-        if (single_fused) {
-            a.leaves = (uint32_t *)d.leaves;
-            a.hash_epr = d.hash_epr;
-            if (d.fused) *d.fused = true;
-            prof_mark(ctx, st, tag_l);
-            int rcs = ensure(ctx, ctx->hash_tmp, (size_t)launch_rows * n_chunks * 32);
-            if (rcs) return rcs;
-            if ((rcs = ensure_tickets(ctx, st))) return rcs;
-            const size_t flag_bytes = (size_t)d.n_cosets * n_chunks * 16 * 4;
-            if (flag_bytes > ctx->chain_flags.cap || ctx->chain_epoch == 0xFFFFFFFFu) {  // new (or exhausted) flags start at zero
-                if ((rcs = ensure(ctx, ctx->chain_flags, flag_bytes))) return rcs;
-                HIP_TRY(hipMemsetAsync(ctx->chain_flags.p, 0, ctx->chain_flags.cap, st));
-                ctx->chain_epoch = 0;
-            }
-            a.chunk_cvs = (uint32_t *)ctx->hash_tmp.p;
-            a.n_chunks = n_chunks;
-            a.tile_counters = (uint32_t *)ctx->tickets.p;
-            a.chain_flags = (uint32_t *)ctx->chain_flags.p;
-            a.chain_epoch = ++ctx->chain_epoch;
-            const void *kern = a.pad_traces ? (const void *)k_seg_single_hash<F, true> : (const void *)k_seg_single_hash<F, false>;
-            if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            void *kargs[] = {&a};
-            HIP_TRY(hipLaunchKernel(kern, dim3((uint32_t)std::min<uint64_t>((uint64_t)d.n_cosets * d.n_seg, resident_single)), dim3(threads), kargs, lds, st));
-            launch_merge_chunks(st, ctx->hash_tmp.p, n_chunks, launch_rows, d.leaves, a.digest_words);
-            HIP_TRY(hipGetLastError());
-            return 0;
-        }
         prof_mark(ctx, st, tag_l);
         if (persistent) {
             const bool multi = d.n_seg > 1 || d.total_base_cols != d.base_cols;
@@ -479,46 +426,32 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
                 : multi ? (a.pad_traces ? (small ? (const void *)k_seg_last_hash<F, true, true, false, true> : (const void *)k_seg_last_hash<F, true, true>)
                                         : (small ? (const void *)k_seg_last_hash<F, true, false, false, true> : (const void *)k_seg_last_hash<F, true, false>))
                         : (a.pad_traces ? (const void *)k_seg_last_hash<F, false, true> : (const void *)k_seg_last_hash<F, false, false>);
-#ifndef WF_EXP_NO_SPEC_LAST
             // one segment of one trace in 2^10-row f64 tiles (the bench workload): the tile-size-specialised instantiation
             if (F::BYTES == 8 && !chunked && !multi && !a.pad_traces && a.logD == 10 && !ctx->tune.no_specialized)
                 kern = (const void *)k_seg_last_hash<F, false, false, false, false, F::BYTES == 8 ? 10 : 0>;
-#endif
-#ifndef WF_EXP_NO_SPEC_LAST10_MULTI
             // several segments in 2^10-row tiles (2^20 x 64: last pass 3.68 -> 3.55 ms; the STARKPack shape of eight packed traces
             // of eight columns: 3.62 -> 3.52)
             if (F::BYTES == 8 && !chunked && multi && a.logD == 10 && !small && !ctx->tune.no_specialized)
                 kern = a.pad_traces ? (const void *)k_seg_last_hash<F, true, true, false, false, F::BYTES == 8 ? 10 : 0>
                                     : (const void *)k_seg_last_hash<F, true, false, false, false, F::BYTES == 8 ? 10 : 0>;
-#endif
-#ifndef WF_EXP_NO_SPEC_LAST_CHUNKED
             // rows longer than a BLAKE3 chunk (chunk by chunk inside the pass): 2^10-row tiles (2^20 x 200: last pass 14.39 -> 14.08 ms),
             // 2^9-row tiles (2^18 x 255: 3.65 -> 3.55)
             if (F::BYTES == 8 && chunked && !a.pad_traces && !ctx->tune.no_specialized) {
                 if (a.logD == 10 && !small) kern = (const void *)k_seg_last_hash<F, true, false, true, false, F::BYTES == 8 ? 10 : 0>;
                 if (a.logD == 9 && small) kern = (const void *)k_seg_last_hash<F, true, false, true, true, F::BYTES == 8 ? 9 : 0>;
             }
-#endif
-#ifndef WF_EXP_NO_SPEC_LAST7
             // several segments in 2^7-row tiles (the last digit of the 2^22 plan: cfg 3's last pass 11.44 -> 11.12 ms)
             if (F::BYTES == 8 && !chunked && multi && !a.pad_traces && a.logD == 7 && small && !ctx->tune.no_specialized)
                 kern = (const void *)k_seg_last_hash<F, true, false, false, true, F::BYTES == 8 ? 7 : 0>;
-#endif
-#ifndef WF_EXP_NO_SPEC_LAST9
             // ... and in 2^9-row tiles (2^18 x 32: last pass 0.547 -> 0.521 ms)
             if (F::BYTES == 8 && !chunked && multi && !a.pad_traces && a.logD == 9 && small && !ctx->tune.no_specialized)
                 kern = (const void *)k_seg_last_hash<F, true, false, false, true, F::BYTES == 8 ? 9 : 0>;
-#endif
-#ifndef WF_EXP_NO_SPEC_LAST9_F128
             // f128, 2^9-row tiles (cfg 5: last pass 0.513 -> 0.500 ms)
             if (F::BYTES == 16 && !chunked && multi && !a.pad_traces && a.logD == 9 && small && !ctx->tune.no_specialized)
                 kern = (const void *)k_seg_last_hash<F, true, false, false, true, F::BYTES == 16 ? 9 : 0>;
-#endif
-#ifndef WF_EXP_NO_SPEC_LAST8
             // ... and in 2^8-row tiles (2^17 x 32: last pass 0.278 -> 0.259 ms)
             if (F::BYTES == 8 && !chunked && multi && !a.pad_traces && a.logD == 8 && small && !ctx->tune.no_specialized)
                 kern = (const void *)k_seg_last_hash<F, true, false, false, true, F::BYTES == 8 ? 8 : 0>;
-#endif
             if (chunked) {
                 int rcc = ensure(ctx, ctx->hash_tmp, (size_t)launch_rows * n_chunks * 32);
                 if (rcc) return rcc;
@@ -531,7 +464,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             int rcq = ensure_tickets(ctx, st);
             if (rcq) return rcq;
             a.tile_counters = (uint32_t *)ctx->tickets.p;
-#ifdef WF_EXP_STAMPS
+#if defined(WF_EXPERIMENTS) && defined(WF_EXP_STAMPS)
             a.stamps = exp_stamps_buffer();
 #endif
             void *kargs[] = {&a};
@@ -545,7 +478,6 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         else {
             // one work-group per tile: 2^10- and 2^9-row f64 tiles run the tile-size-specialised instantiations
             const void *kern = d.rows_out ? (const void *)k_seg_last<F, SEG_OUT_ROWS> : (const void *)k_seg_last<F, SEG_OUT_SEG>;
-#ifndef WF_EXP_NO_SPEC_LAST1
             constexpr bool F8 = F::BYTES == 8;
             if (F8 && threads * 2 == (1u << a.logD) && !ctx->tune.no_specialized) {
                 if (a.logD == 10)
@@ -553,7 +485,6 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
                 else if (a.logD == 9)
                     kern = d.rows_out ? (const void *)k_seg_last<F, SEG_OUT_ROWS, false, F8 ? 9 : 0> : (const void *)k_seg_last<F, SEG_OUT_SEG, false, F8 ? 9 : 0>;
             }
-#endif
             if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             void *kargs[] = {&a};
             HIP_TRY(hipLaunchKernel(kern, dim3((uint32_t)grid), dim3(threads), kargs, lds, st));
@@ -646,10 +577,7 @@ static int run_merkle_dw(wf_ctx *ctx, hipStream_t st, const void *leaves, uint64
         const uint32_t l2_min = ctx->tune.merkle_l2_min;
         if (n_par >= ((uint64_t)1 << l2_min)) {  // two levels that still fill the chip: one lane per grandparent
             const uint64_t n_grand = n_par >> 1;
-#ifndef WF_EXP_MERKLE_GRID_WAVES
-#define WF_EXP_MERKLE_GRID_WAVES 8
-#endif
-            const uint64_t blocks2 = std::min<uint64_t>((n_grand + threads - 1) / threads, (uint64_t)ctx->num_cus * WF_EXP_MERKLE_GRID_WAVES);  // grid-stride
+            const uint64_t blocks2 = std::min<uint64_t>((n_grand + threads - 1) / threads, (uint64_t)ctx->num_cus * 8);  // grid-stride
             hipLaunchKernelGGL(k_merkle_level2<DW>, dim3((uint32_t)blocks2), dim3(threads), 0, st,
                                children, (uint32_t *)nodes + n_par * 8, (uint32_t *)nodes + n_grand * 8, n_grand);
             HIP_TRY(hipGetLastError());
@@ -798,29 +726,22 @@ static int trace_commit_dev(wf_ctx *ctx, const wf_params *p, const void *d_trace
     int rc = path_buffers<F>(ctx, p, b);
     if (rc) return rc;
     const uint64_t R = (uint64_t)1 << p->log2_trace_len;
-    // columns -> segments (tuning, wf_tuning::fold_input: not launched -- the first strided pass of a 2^20-row f64 interpolation
-    // gathers the columns itself; measured slower)
-    const bool fold = ctx->tune.fold_input && F::BYTES == 8 && p->ext_degree == 1 && p->log2_trace_len == 20 && !ctx->tune.no_specialized;
-    if (!fold) {
-        rc = run_xpose<F>(ctx, st, true, d_trace, b.segA, R, p->ext_degree, b.total_base_cols, b.n_seg);
-        if (rc) return rc;
-        if (input_read) HIP_TRY(hipEventRecord(input_read, st));  // nothing below reads d_trace: its buffer may be refilled
-    }
+    // columns -> segments
+    rc = run_xpose<F>(ctx, st, true, d_trace, b.segA, R, p->ext_degree, b.total_base_cols, b.n_seg);
+    if (rc) return rc;
+    if (input_read) HIP_TRY(hipEventRecord(input_read, st));  // nothing below reads d_trace: its buffer may be refilled
     // ColMatrix::interpolate_columns (col_matrix.rs:196-206)
     SegDesc<F> d;
     memset(&d, 0, sizeof(d));
     d.in = b.segA;
     d.work = b.segA;  // strided passes run in place
     d.out = b.segB;
-    d.in_cols = fold ? (const typename F::T *)d_trace : nullptr;
-    d.total_base_cols = b.total_base_cols;  // (read by the column gather only)
     d.logN = p->log2_trace_len;
     d.n_seg = b.n_seg;
     d.n_cosets = 1;
     d.rows_out = false;
     rc = run_seg_transform<F>(ctx, st, d);
     if (rc) return rc;
-    if (fold && input_read) HIP_TRY(hipEventRecord(input_read, st));
     // the caller's copy of the polynomials, column layout
     rc = run_xpose<F>(ctx, st, false, b.segB, d_polys, R, p->ext_degree, b.total_base_cols, b.n_seg);
     if (rc) return rc;

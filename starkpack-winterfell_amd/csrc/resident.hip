@@ -9,19 +9,36 @@
 
 using namespace wf;
 
-// completes an asynchronous commitment: waits for its kernels, fetches the root, gives the pinned slot back
+// completes an asynchronous commitment: waits for its kernels, fetches the root and the device error word that travelled
+// with it, gives the pinned slot back.  May run on a thread that holds no call on the context (a finaliser destroying a
+// pending handle): the context is touched only under the registry's lock (CtxPin), its slot table under pool_mutex.
 static int commitment_wait(wf_commitment *c) {
     if (!c->pending) return 0;
     int rc = 0;
-    if (ctx_alive(c->ctx, c->ctx_generation)) {
-        (void)hipSetDevice(c->ctx->device);
-        const hipError_t e = hipEventSynchronize(c->done);
+    (void)hipSetDevice(c->device);
+    if (c->done) {
+        const hipError_t e = hipEventSynchronize(c->done);  // (the event is the handle's own: no context needed to wait for it)
         if (e != hipSuccess) rc = fail(WF_ERR_HIP, "the commitment's kernels failed: %s", hipGetErrorString(e));
-        if (c->root_slot1) {
-            if (rc == 0) memcpy(c->root, c->ctx->root_pin + (size_t)(c->root_slot1 - 1) * 32, 32);
+    }
+    bool device_error = false;
+    {
+        CtxPin pin(c->ctx, c->ctx_generation);
+        if (pin.alive && c->root_slot1) {
+            const uint8_t *slot = c->ctx->root_pin + (size_t)(c->root_slot1 - 1) * WF_ROOT_SLOT_BYTES;
+            if (rc == 0) {
+                memcpy(c->root, slot, 32);
+                uint32_t err;
+                memcpy(&err, slot + 32, 4);
+                device_error = err != 0;
+            }
+            std::lock_guard<std::mutex> lock(c->ctx->pool_mutex);
             c->ctx->root_used[c->root_slot1 - 1] = 0;
         }
     }
+    // a persistent kernel of this commitment flagged a chaining time-out: the leaves are wrong (path_device_error also
+    // clears the flag, so that it is not blamed on the context's next commitment)
+    if (device_error && ctx_alive(c->ctx, c->ctx_generation)) rc = path_device_error(c->ctx);
+    if (device_error && rc == 0) rc = fail(WF_ERR_HIP, "a persistent kernel of this commitment reported an internal error");
     if (c->done) (void)hipEventDestroy(c->done);
     c->done = nullptr;
     c->root_slot1 = 0;
@@ -34,6 +51,7 @@ wf_commitment *commitment_new(wf_ctx *ctx) {
     memset(c, 0, sizeof(*c));
     c->ctx = ctx;
     c->ctx_generation = ctx->generation;
+    c->device = ctx->device;
     return c;
 }
 
@@ -170,7 +188,9 @@ static int commit_resident_async(wf_ctx *ctx, const wf_params *p, const void *co
         if (!cols_in[i]) return fail(WF_ERR_ARG, "column %zu is null", i);
     if (!ctx->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     if (!ctx->root_pin) {
-        HIP_TRY(hipHostMalloc((void **)&ctx->root_pin, WF_ROOT_SLOTS * 32, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&ctx->root_pin, WF_ROOT_SLOTS * WF_ROOT_SLOT_BYTES, hipHostMallocDefault));
+        memset(ctx->root_pin, 0, WF_ROOT_SLOTS * WF_ROOT_SLOT_BYTES);
+        std::lock_guard<std::mutex> lock(ctx->pool_mutex);
         ctx->root_used.assign(WF_ROOT_SLOTS, 0);
     }
     for (int i = 0; i < 2; i++) {
@@ -178,16 +198,33 @@ static int commit_resident_async(wf_ctx *ctx, const wf_params *p, const void *co
         if (!ctx->upload_done[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->upload_done[i], hipEventDisableTiming));
     }
     uint32_t slot1 = 0;
-    for (size_t i = 0; i < WF_ROOT_SLOTS && !slot1; i++)
-        if (!ctx->root_used[i]) slot1 = (uint32_t)i + 1;
+    {
+        std::lock_guard<std::mutex> lock(ctx->pool_mutex);  // (slots come back from other threads: commitment_wait)
+        for (size_t i = 0; i < WF_ROOT_SLOTS && !slot1; i++)
+            if (!ctx->root_used[i]) {
+                slot1 = (uint32_t)i + 1;
+                ctx->root_used[i] = 1;  // taken here; handed back below if the call fails
+            }
+    }
+    auto give_back = [&]() {
+        std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+        ctx->root_used[slot1 - 1] = 0;
+    };
     if (!slot1) return fail(WF_ERR_BUSY, "%zu asynchronous commitments are in flight: wait for (or destroy) some first", WF_ROOT_SLOTS);
     const int sb = (int)(ctx->async_seq & 1);
-    if ((rc = ensure(ctx, ctx->stage[sb], TC * colb))) return rc;
+    if ((rc = ensure(ctx, ctx->stage[sb], TC * colb))) {
+        give_back();
+        return rc;
+    }
     wf_commitment *c = nullptr;
     bool dense = false;
-    if ((rc = commitment_alloc(ctx, p, false, &c, &dense))) return rc;
+    if ((rc = commitment_alloc(ctx, p, false, &c, &dense))) {
+        give_back();
+        return rc;
+    }
     hipError_t e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
     if (e != hipSuccess) {
+        give_back();
         free_commitment(c);
         return fail(WF_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
     }
@@ -200,20 +237,25 @@ static int commit_resident_async(wf_ctx *ctx, const wf_params *p, const void *co
     if (rc == 0 && e == hipSuccess) e = hipStreamWaitEvent(st, ctx->upload_done[sb], 0);
     if (rc == 0 && e == hipSuccess)
         rc = path_trace_commit(ctx, p, ctx->stage[sb].p, c->polys, c->lde, c->leaves, c->nodes, st, ctx->stage_free[sb]);
-    if (rc == 0 && e == hipSuccess)
-        e = hipMemcpyAsync(ctx->root_pin + (size_t)(slot1 - 1) * 32, (char *)c->nodes + 32, 32, hipMemcpyDeviceToHost, st);
+    uint8_t *slot = ctx->root_pin + (size_t)(slot1 - 1) * WF_ROOT_SLOT_BYTES;
+    if (rc == 0 && e == hipSuccess) e = hipMemcpyAsync(slot, (char *)c->nodes + 32, 32, hipMemcpyDeviceToHost, st);
+    // the persistent kernels' error word (word 16 of the ticket block) travels with the root: wf_commitment_wait reports a
+    // chaining time-out of THIS commitment without another round trip
+    memset(slot + 32, 0, 4);
+    if (rc == 0 && e == hipSuccess && ctx->tickets.p)
+        e = hipMemcpyAsync(slot + 32, (const char *)ctx->tickets.p + 64, 4, hipMemcpyDeviceToHost, st);
     if (rc == 0 && e == hipSuccess) e = hipEventRecord(c->done, st);
     if (rc || e != hipSuccess) {
         // whatever was queued from the caller's columns or into this handle's buffers must have drained before either goes away
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamSynchronize(st);
         ctx->stage_busy[sb] = false;
+        give_back();
         free_commitment(c);
         return rc ? rc : fail(WF_ERR_HIP, "queueing the commitment failed: %s", hipGetErrorString(e));
     }
     ctx->stage_busy[sb] = true;
     ctx->async_seq++;
-    ctx->root_used[slot1 - 1] = 1;
     c->root_slot1 = slot1;
     c->pending = true;
     *out = c;
@@ -787,6 +829,7 @@ int wf_trace_commit_sharded_resident(wf_comm *comm, const wf_params *p, const vo
     c->polys_bytes = TC * colb;
     hipStream_t st = ctx->stream;
     // local stage (allocations, upload), then the ranks agree that all of them got this far before the first exchange
+    void *top_pin = nullptr;
     const int local_rc = [&]() -> int {
         hipError_t e;
         if ((e = pool_alloc(ctx, &c->lde_shard, c->lde_bytes)) != hipSuccess || (e = pool_alloc(ctx, &c->leaves, c->dig_bytes)) != hipSuccess ||
@@ -795,6 +838,7 @@ int wf_trace_commit_sharded_resident(wf_comm *comm, const wf_params *p, const vo
         int rl;
         if ((rl = ensure(ctx, ctx->io[0], TC * colb)) || (rl = ensure(ctx, ctx->io[4], (size_t)2 * W * 32))) return rl;
         if ((rl = ensure(ctx, comm->stage, 2 * (size_t)R * per * 32))) return rl;  // (the exchange staging of trace_commit_sharded)
+        if ((rl = comm_pinned(comm, (size_t)2 * W * 32, &top_pin))) return rl;      // (allocated while nothing is queued: see comm_pinned)
         return upload_columns(ctx, ctx->io[0].p, trace_cols, TC, colb, st);
     }();
     if ((rc = comm_agree(comm, local_rc, "wf_trace_commit_sharded_resident"))) {
@@ -803,13 +847,21 @@ int wf_trace_commit_sharded_resident(wf_comm *comm, const wf_params *p, const vo
     }
     rc = path_trace_commit_sharded(comm, p, ctx->io[0].p, c->polys, c->lde_shard, c->leaves, c->nodes, ctx->io[4].p, st);
     c->top.resize((size_t)2 * W * 32);
-    if (rc == 0 && hipMemcpyAsync(c->top.data(), ctx->io[4].p, c->top.size(), hipMemcpyDeviceToHost, st) != hipSuccess)
+    // the top levels come back through the communicator's pinned memory: a copy into the (pageable) vector would hold the
+    // host inside hipMemcpyAsync until the exchanges in front of it have run -- out of the watchdog's reach -- and would
+    // write into freed memory if it were still queued when a time-out frees the handle
+    if (rc == 0 && hipMemcpyAsync(top_pin, ctx->io[4].p, c->top.size(), hipMemcpyDeviceToHost, st) != hipSuccess)
         rc = fail(WF_ERR_HIP, "commitment failed: %s", hipGetErrorString(hipGetLastError()));
     if (rc == 0) rc = comm_wait(comm, st);  // (with the watchdog: a peer that failed inside the exchanges never arrives)
+    if (rc == 0) rc = path_device_error(ctx);
     if (rc) {
+        // (after a time-out the kernels behind the dead exchange may still hold these buffers: they go back to the driver
+        // through hipFree, which waits for the device, not into the pool)
+        if (comm->dead) c->lde_bytes = c->dig_bytes = c->polys_bytes = 0;
         free_sharded(c);
         return rc;
     }
+    memcpy(c->top.data(), top_pin, c->top.size());
     memset(&c->polys_view, 0, sizeof(c->polys_view));
     c->polys_view.ctx = ctx;
     c->polys_view.ctx_generation = ctx->generation;
@@ -884,16 +936,18 @@ int wf_sharded_commitment_query(wf_sharded_commitment *c, const uint64_t *positi
     }
     // message of a rank: [ids.size()][32] digests then [n] rows, zero where it owns nothing; exchanged with one all-gather
     const size_t msg = ((ids.size() * 32 + n * row_bytes + 255) / 256) * 256;
-    std::vector<uint8_t> mine(msg, 0), all(msg * W);
+    std::vector<uint8_t> mine(msg, 0);
     const size_t nd = my_dig_local.size(), nr = my_row_local.size();
     const size_t idx_bytes = (nd + nr) * 8, dig_off = (idx_bytes + 255) / 256 * 256, row_off = dig_off + (nd * 32 + 255) / 256 * 256;
     hipStream_t st = ctx->stream;
     char *d_msg = nullptr;
+    void *all_pin = nullptr;
     // local stage: nothing below the agreement may fail on one rank alone
     const int local_rc = [&]() -> int {
         int rl;
         if ((rl = ensure(ctx, ctx->io[3], row_off + nr * row_bytes + 256))) return rl;
         if ((rl = ensure(ctx, ctx->io[4], msg * (W + 1)))) return rl;
+        if ((rl = comm_pinned(comm, msg * W, &all_pin))) return rl;  // (allocated while nothing is queued: see comm_pinned)
         char *work = (char *)ctx->io[3].p;
         if (nd + nr) {
             std::vector<uint64_t> idx(my_dig_local);
@@ -929,8 +983,10 @@ int wf_sharded_commitment_query(wf_sharded_commitment *c, const uint64_t *positi
     }();
     if ((rc = comm_agree(comm, local_rc, "wf_sharded_commitment_query"))) return rc;
     if ((rc = comm_all_gather(comm, d_msg, d_msg + msg, msg, st))) return rc;
-    HIP_TRY(hipMemcpyAsync(all.data(), d_msg + msg, msg * W, hipMemcpyDeviceToHost, st));
+    // the merged messages land in the communicator's pinned memory (see comm_pinned) and are read after the wait succeeded
+    HIP_TRY(hipMemcpyAsync(all_pin, d_msg + msg, msg * W, hipMemcpyDeviceToHost, st));
     if ((rc = comm_wait(comm, st))) return rc;
+    const uint8_t *all = (const uint8_t *)all_pin;
 
     // every entry from its owner's message
     std::vector<uint8_t> dig(ids.size() * 32);

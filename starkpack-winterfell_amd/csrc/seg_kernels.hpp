@@ -12,8 +12,9 @@
 // order.  Inside LDS (x[D][S]): radix-16 rounds with the 16 values of one lane in registers (f64), then radix-4 /
 // radix-2 rounds on two lanes per thread (16-byte LDS accesses for f64); f128 uses the radix-4 / radix-2 rounds only.
 // Work-groups have D/2 threads (one work item of the widest round each).  DESIGN.md §4 describes the kernels, §9 the
-// variants that were measured and dropped; the WF_EXP_* macros switch parts off for time attribution
-// (scripts/exp_variants.sh) and are never defined in the product build.
+// variants that were measured and dropped (their code is in the history, not here).  A -DWF_EXPERIMENTS build
+// (scripts/exp_variants.sh) adds the time-attribution switches WF_EXP_SKIP_LOAD / _SKIP_NTT / _SKIP_STORE, the
+// wrong-output store orders WF_EXP_LOCAL_STORE and the phase stamps WF_EXP_STAMPS; the product build has none of them.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -21,6 +22,14 @@
 
 #include "field.hpp"
 #include "kernels.hpp"
+
+#ifndef WF_EXPERIMENTS  // the diagnostic switches exist in experiment builds only
+#undef WF_EXP_SKIP_LOAD
+#undef WF_EXP_SKIP_NTT
+#undef WF_EXP_SKIP_STORE
+#undef WF_EXP_LOCAL_STORE
+#undef WF_EXP_STAMPS
+#endif
 
 namespace wf {
 
@@ -39,18 +48,10 @@ struct alignas(16) Pair {
     T a, b;
 };
 
-// 16- or 32-byte store of a lane pair; WF_EXP_NT_STORE: as non-temporal stores (tuning experiment)
+// 16- or 32-byte store of a lane pair
 template <class T>
 __device__ __forceinline__ void store_pair(T *dst, const Pair<T> &v) {
-#ifdef WF_EXP_NT_STORE
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 *s = reinterpret_cast<const u32x4 *>(&v);
-    u32x4 *d = reinterpret_cast<u32x4 *>(dst);
-#pragma unroll
-    for (unsigned q = 0; q < sizeof(Pair<T>) / 16; q++) __builtin_nontemporal_store(s[q], d + q);
-#else
     *reinterpret_cast<Pair<T> *>(dst) = v;
-#endif
 }
 
 // Zero padding of an LDE row (segments.rs:65-72) from its first padding element `pz` (column `cols` of a row of
@@ -104,13 +105,9 @@ __device__ __forceinline__ uint32_t tile_threads() {
 // work-groups that write neighbouring 64-byte pieces of the same 512 bytes (adjacent inner positions of a strided pass,
 // the cosets of one row group in the last pass), so that the pieces meet in that XCD's L2 and leave as whole lines.
 __device__ __forceinline__ uint64_t xcd_group_index(uint64_t b, uint64_t total) {
-#ifndef WF_EXP_NO_XCD_REMAP
     if ((total & 63) != 0) return b;
     const uint64_t xcd = b & 7, seq = b >> 3;
     return (((seq >> 3) << 3) + xcd) * 8 + (seq & 7);
-#else
-    return b;
-#endif
 }
 
 // Tile indices are decoded with shifts where a factor is a power of two (I and O always are) and with 32-bit divisions
@@ -123,8 +120,6 @@ struct SegArgs {
     typedef typename F::T T;
     const T *src;
     T *dst;
-    const T *src_cols;      // k_seg_strided, direct first round only (tuning: wf_tuning::fold_input): the rows come from a column-major
-    uint64_t src_cols_rows; //   matrix (column B at src_cols + B * src_cols_rows) instead of segment layout; nullptr: segment layout
     uint32_t logN, logD;
     uint64_t I, O;          // inner / outer row counts of the [O][D][I] view (last pass: I = 1)
     uint32_t n_seg;         // segments per coset
@@ -166,8 +161,6 @@ struct SegArgs {
     uint32_t *chunk_cvs;       // k_seg_last_hash<.., CHUNKED>: [LDE row][n_chunks][8] chunk chaining values (rows > 1024 bytes)
     uint32_t n_chunks;         //   ceil(n_seg / 16): a BLAKE3 chunk is 16 blocks = 16 segments of a row
     uint32_t *tile_counters;   // k_seg_last_hash: 8 ticket + 8 exit counters, one per XCD, zero between launches (self-resetting)
-    uint32_t *chain_flags;     // k_seg_single_hash: [coset][chunk][16] = the launch's epoch once that block's chaining values are written
-    uint32_t chain_epoch;
 #ifdef WF_EXP_STAMPS
     unsigned long long *stamps;  // diagnostic build only: per work-group phase cycle sums of k_seg_last_hash (8 words each)
 #endif
@@ -189,22 +182,6 @@ __device__ __forceinline__ uint32_t seg_digit_reverse(uint32_t pos, uint32_t log
     }
     if (cur == 1) k |= (pos & 1u) << sh;
     return k;
-}
-
-// LDS row swizzle (SWZ instantiations: f64 tiles of the cfg-2 shape kernels).  A tile row is 64 bytes, a quarter of the 256-byte
-// bank row, and the rounds / read-outs whose lanes walk rows a multiple of four apart (the last radix-4 round: rows
-// 4p + k across p; its ds_read_b128 lane groups hold p, p+3, p+5, p+6) put four lanes on every 16-byte slot: 4-way
-// conflicts (SQ_LDS_BANK_CONFLICT 21.8 M cycles per launch of the fused last pass, round 2's counters).  Storing row n at
-// row n ^ ((-(n >> 2)) & 3) -- the 64-byte column within the bank row becomes (n0 ^ n2, n1 ^ n2 ^ n3) -- makes the
-// radix-4 round's reads and writes, the row-store read-out (rows {0,3,5,6} + 8i per lane group) and both radix-16 rounds
-// conflict-free at once (searched over all GF(2)-linear maps of the row index: DESIGN.md §9).
-// MEASURED AND LEFT OFF (build with -DWF_EXP_SWIZZLE to get it): the conflict cycles fall as predicted (fused last pass
-// 21.8 M -> 11.3 M per launch, strided pass 16.5 M -> 6.0 M; the rest is the hash read-out, one row per lane: 4-way by
-// construction), the passes take the same time (0.580 / 0.375 ms either way, same box, three interleaved runs) -- the
-// conflicts were hidden under VALU issue, and the address arithmetic adds 4 % VALU instructions to the last pass.
-template <bool SWZ>
-__device__ __forceinline__ uint32_t swz_row(uint32_t n) {
-    return SWZ ? n ^ ((0u - (n >> 2)) & 3u) : n;
 }
 
 __host__ __device__ constexpr uint32_t bitrev4(uint32_t v) {
@@ -318,16 +295,12 @@ __device__ __forceinline__ void shift_tw_apply(typename F::T (&v)[16]) {
     if constexpr (K < 16) {
         constexpr int E = shift_tw_exp<DIR, STEP, K>();
         constexpr int q = bitrev4(K);
-#ifndef WF_EXP_NO_SHIFT_FENCE
-        asm volatile("" : "+v"(v[q]));
-#endif
+        asm volatile("" : "+v"(v[q]));  // one shift after the other (measured the same as interleaved, one register fewer)
         if constexpr (E > 96 && E <= 128)
             v[q] = F::template mul_pow2<E - 96>(v[q]);  // v[q] = -X_k already
         else
             v[q] = F::template mul_pow2_192<E>(v[q]);
-#ifndef WF_EXP_NO_SHIFT_FENCE
         asm volatile("" : "+v"(v[q]));
-#endif
         shift_tw_apply<F, DIR, STEP, K + 1>(v);
     }
 }
@@ -346,7 +319,7 @@ __device__ __forceinline__ void radix16_shift_tw(typename F::T (&v)[16], const t
 // `nthr` = blockDim.x, passed in so that the tile-size-specialised kernels (LOGD != 0, below) make it a constant.
 // One radix-16 round of seg_lds_ntt at `cur` remaining bits (no trailing barrier): work item wk = lane wk % S of the
 // 16 rows base + a * 2^(cur-4), a = 0..15.  w16[j] = w_16^j.
-template <class F, int DIR, bool SWZ = false, bool UNI = false>
+template <class F, int DIR, bool UNI = false>
 __device__ __forceinline__ void seg_round16(typename F::T *x, const typename F::T *twd, const typename F::T (&w16)[8],
                                             uint32_t logD, uint32_t cur, uint32_t nthr, const typename F::T *first,
                                             uint32_t tid, bool use_first) {  // tid: threadIdx.x; first: read only if use_first
@@ -365,7 +338,7 @@ __device__ __forceinline__ void seg_round16(typename F::T *x, const typename F::
     // compile-time constants.
     // UNI: only from seg_lds_fixed (logD and cur compile-time constants there; as a run-time branch of the generic round
     // loop the extra paths cost every kernel registers).
-    constexpr bool SHIFT_TW = UNI && F::FIELD_ID == 1 && DIR != 0 && !SWZ && SegCfg<F>::S == 8;
+    constexpr bool SHIFT_TW = UNI && F::FIELD_ID == 1 && DIR != 0 && SegCfg<F>::S == 8;
     const bool uni = SHIFT_TW && ((logD == 10 && cur == 6) || (logD == 9 && cur == 5));
     for (uint32_t wk = tid; wk < nwork; wk += nthr) {
         const uint32_t l = wk & (S - 1), u = wk >> s_shift;
@@ -376,23 +349,11 @@ __device__ __forceinline__ void seg_round16(typename F::T *x, const typename F::
             p = ((wv >> mlog) << 3) | (u & 7u);
         }
         const uint32_t row0 = (p << cur) + jp;
-        // element offsets of the item's 16 rows row0 + a * m.  Swizzled: with m >= 16 the swizzle term is the same for all of
-        // them (one XOR on the base); with m == 4 it depends on a mod 4 only (four bases, compile-time offsets); else per row
-        uint32_t off[16];
-        if (!SWZ || mlog >= 4) {
-            const uint32_t base = swz_row<SWZ>(row0) * S + l;
+        uint32_t off[16];  // element offsets of the item's 16 rows row0 + a * m
+        {
+            const uint32_t base = row0 * S + l;
 #pragma unroll
             for (int a = 0; a < 16; a++) off[a] = base + a * st;
-        } else if (mlog == 2) {
-            const uint32_t t0 = (0u - (row0 >> 2)) & 3u, hi = ((row0 & ~3u) * S) + l;
-            uint32_t b4[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) b4[r] = hi + ((jp ^ ((t0 - r) & 3u)) * S);
-#pragma unroll
-            for (int a = 0; a < 16; a++) off[a] = b4[a & 3] + a * st;
-        } else {
-#pragma unroll
-            for (int a = 0; a < 16; a++) off[a] = swz_row<SWZ>(row0 + a * m) * S + l;
         }
         T v[16];
         if (use_first) {  // uniform
@@ -442,7 +403,7 @@ __device__ __forceinline__ typename F::T mul_w4(typename F::T u, typename F::T t
 }
 
 // One radix-4 round (two lanes per work item, 16-byte LDS accesses for f64); w4 = w_4.
-template <class F, int DIR = 0, bool SWZ = false, bool UNI = false>
+template <class F, int DIR = 0, bool UNI = false>
 __device__ __forceinline__ void seg_round4(typename F::T *x, const typename F::T *twd, typename F::T w4, uint32_t logD,
                                            uint32_t cur, uint32_t nthr, uint32_t tid) {
     typedef typename F::T T;
@@ -456,7 +417,7 @@ __device__ __forceinline__ void seg_round4(typename F::T *x, const typename F::T
     const uint32_t st = m * S;
     // cur == 3 (tiles of 2^7 and 2^11 rows): the twiddles are w_8^(jp k) = 2^(24 jp k), jp = 0, 1.  As in seg_round16 a wave
     // (4 lane pairs x 16 items) takes sixteen blocks of one jp, and the products become shifts (or nothing).
-    constexpr bool SHIFT_TW = UNI && F::FIELD_ID == 1 && DIR != 0 && !SWZ && HP == 4;
+    constexpr bool SHIFT_TW = UNI && F::FIELD_ID == 1 && DIR != 0 && HP == 4;
     const bool uni = SHIFT_TW && cur == 3 && logD >= 7;
     for (uint32_t wk = tid; wk < nwork; wk += nthr) {
         const uint32_t lp = wk & (HP - 1), u = wk >> hp_shift;
@@ -467,24 +428,8 @@ __device__ __forceinline__ void seg_round4(typename F::T *x, const typename F::T
             p = ((wv >> 1) << 4) | (u & 15u);
         }
         const uint32_t row0 = (p << cur) + jp;
-        uint32_t o0, o1, o2, o3;  // element offsets of rows row0 + k * m
-        if (!SWZ || mlog >= 4) {
-            o0 = swz_row<SWZ>(row0) * S + 2 * lp;
-            o1 = o0 + st;
-            o2 = o0 + 2 * st;
-            o3 = o0 + 3 * st;
-        } else if (mlog == 0) {  // rows 4 p + k: the swizzle term (-p) & 3 permutes the four rows among themselves
-            const uint32_t t = (0u - p) & 3u, b0 = row0 * S + 2 * lp;
-            o0 = b0 + t * S;
-            o1 = b0 + (t ^ 1u) * S;
-            o2 = b0 + (t ^ 2u) * S;
-            o3 = b0 + (t ^ 3u) * S;
-        } else {
-            o0 = swz_row<SWZ>(row0) * S + 2 * lp;
-            o1 = swz_row<SWZ>(row0 + m) * S + 2 * lp;
-            o2 = swz_row<SWZ>(row0 + 2 * m) * S + 2 * lp;
-            o3 = swz_row<SWZ>(row0 + 3 * m) * S + 2 * lp;
-        }
+        // element offsets of rows row0 + k * m
+        const uint32_t o0 = row0 * S + 2 * lp, o1 = o0 + st, o2 = o0 + 2 * st, o3 = o0 + 3 * st;
         P2 x0 = *reinterpret_cast<P2 *>(x + o0);
         P2 x1 = *reinterpret_cast<P2 *>(x + o1);
         P2 x2 = *reinterpret_cast<P2 *>(x + o2);
@@ -538,7 +483,7 @@ __device__ __forceinline__ void seg_round4(typename F::T *x, const typename F::T
     }
 }
 
-template <class F, bool SWZ = false>
+template <class F>
 __device__ __forceinline__ void seg_round2(typename F::T *x, uint32_t logD, uint32_t nthr, uint32_t tid) {
     typedef typename F::T T;
     typedef Pair<T> P2;
@@ -547,7 +492,7 @@ __device__ __forceinline__ void seg_round2(typename F::T *x, uint32_t logD, uint
     const uint32_t nwork = (1u << (logD - 1)) * HP;
     for (uint32_t wk = tid; wk < nwork; wk += nthr) {
         const uint32_t lp = wk & (HP - 1), u = wk >> hp_shift;
-        const uint32_t base = swz_row<SWZ>(u << 1) * S + 2 * lp, base1 = swz_row<SWZ>((u << 1) + 1) * S + 2 * lp;
+        const uint32_t base = (u << 1) * S + 2 * lp, base1 = base + S;
         P2 x0 = *reinterpret_cast<P2 *>(x + base);
         P2 x1 = *reinterpret_cast<P2 *>(x + base1);
         P2 y0, y1;
@@ -570,7 +515,7 @@ __device__ __forceinline__ uint32_t opaque_tid() {
 
 // The rounds of a tile of 2^LOGD rows with every size a compile-time constant: what the Goldilocks tiles with power-of-two
 // inter-round twiddles run (2^10 and 2^9 rows: after the second radix-16 round; 2^7 and 2^11: in the radix-4 round).
-template <class F, int DIR, bool SWZ, int LOGD, int CUR>
+template <class F, int DIR, int LOGD, int CUR>
 __device__ __forceinline__ void seg_lds_fixed(typename F::T *x, const typename F::T *twd, const typename F::T (&w16)[8],
                                               typename F::T w4, uint32_t nthr, const typename F::T *first, bool use_first,
                                               bool opaque) {
@@ -578,15 +523,15 @@ __device__ __forceinline__ void seg_lds_fixed(typename F::T *x, const typename F
     // out of the kernel's tile loop and held in registers across it
     const uint32_t tid = opaque ? opaque_tid() : threadIdx.x;
     if constexpr (SegCfg<F>::RADIX16 && CUR >= 4) {
-        seg_round16<F, DIR, SWZ, true>(x, twd, w16, LOGD, CUR, nthr, first, tid, use_first && CUR == LOGD);
+        seg_round16<F, DIR, true>(x, twd, w16, LOGD, CUR, nthr, first, tid, use_first && CUR == LOGD);
         __syncthreads();
-        seg_lds_fixed<F, DIR, SWZ, LOGD, CUR - 4>(x, twd, w16, w4, nthr, first, false, opaque);
+        seg_lds_fixed<F, DIR, LOGD, CUR - 4>(x, twd, w16, w4, nthr, first, false, opaque);
     } else if constexpr (CUR >= 2) {
-        seg_round4<F, DIR, SWZ, true>(x, twd, w4, LOGD, CUR, nthr, tid);
+        seg_round4<F, DIR, true>(x, twd, w4, LOGD, CUR, nthr, tid);
         __syncthreads();
-        seg_lds_fixed<F, DIR, SWZ, LOGD, CUR - 2>(x, twd, w16, w4, nthr, first, false, opaque);
+        seg_lds_fixed<F, DIR, LOGD, CUR - 2>(x, twd, w16, w4, nthr, first, false, opaque);
     } else if constexpr (CUR == 1) {
-        seg_round2<F, SWZ>(x, LOGD, nthr, tid);
+        seg_round2<F>(x, LOGD, nthr, tid);
         __syncthreads();
     }
 }
@@ -595,28 +540,23 @@ __device__ __forceinline__ void seg_lds_fixed(typename F::T *x, const typename F
 // between rounds); each kernel names the sizes it has the registers for.  `use_first`: whether `first` is to be used (a
 // flag beside an always-valid pointer keeps the caller's register array out of scratch memory).
 constexpr uint32_t FIX10 = 1u << 10, FIX7 = 1u << 7, FIX9 = 1u << 9, FIX11 = 1u << 11;
-#ifndef WF_FIX_BIG
-#define WF_FIX_BIG (FIX10 | FIX11)  // the fused last pass on tiles of 2^10 / 2^11 rows
-#endif
-template <class F, int DIR = 0, bool SWZ = false, uint32_t FIXMASK = FIX10>
+constexpr uint32_t FIX_BIG = FIX10 | FIX11;   // the fused last pass on tiles of 2^10 / 2^11 rows
+constexpr uint32_t FIX_LAST = FIX10 | FIX9;   // the one-work-group-per-tile last pass
+template <class F, int DIR = 0, uint32_t FIXMASK = FIX10>
 __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::T *twd, uint32_t logD, uint32_t nthr,
                                             const typename F::T *first = nullptr, bool use_first = false,
                                             bool opaque = false) {
     typedef typename F::T T;
     const uint32_t D = 1u << logD;
-#ifdef WF_EXP_NO_FIXED  // tuning: the generic round loop everywhere (the code of before the shift-twiddle rounds)
-    constexpr uint32_t fixmask = 0;
-#else
     constexpr uint32_t fixmask = FIXMASK;
-#endif
-    if constexpr (fixmask != 0 && F::FIELD_ID == 1 && DIR != 0 && !SWZ) {  // a transform of known direction reads no radix-16 / w_4 constants
+    if constexpr (fixmask != 0 && F::FIELD_ID == 1 && DIR != 0) {  // a transform of known direction reads no radix-16 / w_4 constants
         T w16[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) w16[j] = F::zero();
 #define WF_FIXED_SIZE(L)                                                                                        \
     if constexpr ((fixmask & (1u << (L))) != 0) {                                                               \
         if (logD == (L)) { /* uniform */                                                                        \
-            seg_lds_fixed<F, DIR, SWZ, (L), (L)>(x, twd, w16, F::zero(), nthr, first, use_first, opaque);       \
+            seg_lds_fixed<F, DIR, (L), (L)>(x, twd, w16, F::zero(), nthr, first, use_first, opaque);       \
             return;                                                                                             \
         }                                                                                                       \
     }
@@ -633,7 +573,7 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
 #pragma unroll
         for (int j = 0; j < 8; j++) w16[j] = twd[j * (D >> 4)];
         while (cur >= 4) {
-            seg_round16<F, DIR, SWZ>(x, twd, w16, logD, cur, nthr, first, threadIdx.x, use_first && cur == logD);
+            seg_round16<F, DIR>(x, twd, w16, logD, cur, nthr, first, threadIdx.x, use_first && cur == logD);
             cur -= 4;
             __syncthreads();
         }
@@ -642,10 +582,10 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
     if (logD >= 2) w4 = twd[D >> 2];
     while (cur > 0) {
         if (cur >= 2) {
-            seg_round4<F, DIR, SWZ>(x, twd, w4, logD, cur, nthr, threadIdx.x);
+            seg_round4<F, DIR>(x, twd, w4, logD, cur, nthr, threadIdx.x);
             cur -= 2;
         } else {
-            seg_round2<F, SWZ>(x, logD, nthr, threadIdx.x);
+            seg_round2<F>(x, logD, nthr, threadIdx.x);
             cur = 0;
         }
         __syncthreads();
@@ -672,17 +612,8 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_strided(SegArgs<F> a) {
     // transform, output factors for the stores -- take turns in ONE region of D entries (two more barriers per tile; the
     // twiddles and the output factors wait in registers): a 2^10-row tile is 80 KiB instead of 96, two work-groups per CU,
     // a 2^9-row tile 40 KiB instead of 48, four instead of three.
-#ifdef WF_EXP_TWO_TABLES
-    constexpr bool ONE_TABLE = false;
-#else
     constexpr bool ONE_TABLE = F::BYTES == 16;
-#endif
     T *aux = ONE_TABLE ? twd : twd + D;  // coset factors of the input rows, later the inter-pass twiddles of the output rows
-#ifdef WF_EXP_SWIZZLE
-    constexpr bool SWZ = LOGD == 10 && F::BYTES == 8 && !PACKED;  // (the direct first round: every access below goes through the rounds or the read-out)
-#else
-    constexpr bool SWZ = false;
-#endif
 
     uint64_t bid = xcd_group_index(blockIdx.x, gridDim.x);  // neighbouring i on one XCD
     const uint32_t logI = ilog2_pow2(a.I), logO = ilog2_pow2(a.O);
@@ -751,14 +682,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_strided(SegArgs<F> a) {
         if (has16) {
             // sixteen rows m16 * I apart: one address, then a running 64-bit add per row
             const T *pr = src + (row0 + ((uint64_t)j16 << logI)) * S + l16;
-            uint64_t rstep = ((uint64_t)m16 << logI) * S;
-            bool live = true;
-            if (a.src_cols) {  // uniform: column-major source (8-byte gathers, one per lane)
-                const uint32_t B = g * S + l16;
-                live = B < a.total_base_cols;
-                pr = a.src_cols + (uint64_t)(live ? B : 0) * a.src_cols_rows + row0 + ((uint64_t)j16 << logI);
-                rstep = (uint64_t)m16 << logI;
-            }
+            const uint64_t rstep = ((uint64_t)m16 << logI) * S;
 #pragma unroll
             for (uint32_t q = 0; q < 16; q++) {
 #ifdef WF_EXP_SKIP_LOAD
@@ -767,10 +691,6 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_strided(SegArgs<F> a) {
                 vr[q] = *pr;
 #endif
                 pr += rstep;
-            }
-            if (!live) {
-#pragma unroll
-                for (uint32_t q = 0; q < 16; q++) vr[q] = F::zero();
             }
         }
     } else if (from_regs) {
@@ -891,7 +811,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_strided(SegArgs<F> a) {
     }
 #ifndef WF_EXP_SKIP_NTT  // tuning experiment: memory phases only (scripts/exp_variants.sh)
     // (the generic kernel runs the generic round loop: with the 16 direct values in registers it has no room for more)
-    seg_lds_ntt<F, EVAL ? 1 : -1, SWZ, (LOGD ? (1u << LOGD) : 0u)>(x, twd, a.logD, NT, direct ? vr : nullptr, direct);
+    seg_lds_ntt<F, EVAL ? 1 : -1, (LOGD ? (1u << LOGD) : 0u)>(x, twd, a.logD, NT, direct ? vr : nullptr, direct);
 #else
     if (direct && has16) {
 #pragma unroll
@@ -918,8 +838,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_strided(SegArgs<F> a) {
     const uint32_t k_shift = logI + (S == 8 ? 3 : 2);  // rows k of the output are I apart: element offset k * I * S
     for (uint32_t pj = 0; pj < D; pj += pstride) {
         const uint32_t k = k0 | seg_digit_reverse<F>(pj, a.logD);
-        // (pj is a multiple of pstride >= 16 in the SWZ instantiation: the swizzle term of row pos0 + pj is that of pos0)
-        P2 v = *reinterpret_cast<P2 *>(x + (swz_row<SWZ>(pos0) + pj) * S + lane_a);
+        P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
         const T f = aux[k];
         v.a = F::mul(v.a, f);
         v.b = F::mul(v.b, f);
@@ -1168,10 +1087,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
     }
     __syncthreads();
 #ifndef WF_EXP_SKIP_NTT
-#ifndef WF_FIX_LAST
-#define WF_FIX_LAST (FIX10 | FIX9)
-#endif
-    seg_lds_ntt<F, OUT == SEG_OUT_ROWS ? 1 : -1, false, (LOGD ? (1u << LOGD) : WF_FIX_LAST)>(x, twd, logD_, NT);
+    seg_lds_ntt<F, OUT == SEG_OUT_ROWS ? 1 : -1, (LOGD ? (1u << LOGD) : FIX_LAST)>(x, twd, logD_, NT);
 #endif
 
     // Store.  Work item = (row position pos, lane pair); this thread's positions are pos0 + j * pstride, j = 0, 1, ..
@@ -1365,11 +1281,6 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : 1024) k_seg_last_hash(SegArgs
     const uint32_t D = 1u << logD_;
     T *x = reinterpret_cast<T *>(smem_raw);
     T *twd = x + (size_t)D * S;
-#ifdef WF_EXP_SWIZZLE
-    constexpr bool SWZ = !MULTI && !PADT && F::BYTES == 8;  // the one-segment, one-trace f64 instantiation (see swz_row)
-#else
-    constexpr bool SWZ = false;
-#endif
     const uint32_t n_chunks = CHUNKED ? a.n_chunks : 1;
     const uint64_t total = (uint64_t)a.n_cosets * a.O * n_chunks;  // tickets: (coset, row block[, chunk])
     const uint64_t seg_elems = ((uint64_t)1 << a.logN) * S;
@@ -1478,12 +1389,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : 1024) k_seg_last_hash(SegArgs
         {
             uint4 *d_ = reinterpret_cast<uint4 *>(x);
             const uint32_t t_ = opaque_tid();
-            // 16-byte chunk ch of the tile = quarter ch & 3 of row ch >> 2 (every row is 64 bytes)
-#define WF_TILE_PUT(J, Q)                                                              \
-    do {                                                                               \
-        const uint32_t ch_ = t_ + (J) * step;                                          \
-        d_[SWZ ? ((swz_row<SWZ>(ch_ >> 2) << 2) | (ch_ & 3u)) : ch_] = Q;              \
-    } while (0)
+#define WF_TILE_PUT(J, Q) d_[t_ + (J) * step] = Q
             WF_TILE_PUT(0, q0);
             WF_TILE_PUT(1, q1);
             WF_TILE_PUT(2, q2);
@@ -1501,7 +1407,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : 1024) k_seg_last_hash(SegArgs
         __syncthreads();
         WF_STAMP(0);  // tile in LDS (waits for the prefetched rows)
         // (SMALL instantiations -- tiles of at most 2^9 rows -- have no 128-register cap: the 2^7- and 2^9-row sequences too)
-        seg_lds_ntt<F, 1, SWZ, (LOGD ? (1u << LOGD) : SMALL ? (FIX7 | FIX9) : WF_FIX_BIG)>(x, twd, logD_, NT, nullptr, false, true);
+        seg_lds_ntt<F, 1, (LOGD ? (1u << LOGD) : SMALL ? (FIX7 | FIX9) : FIX_BIG)>(x, twd, logD_, NT, nullptr, false, true);
         WF_STAMP(1);  // transform
 
         // row stores: lane pair (2l, 2l+1) of row position pos -> its place in LDE row k * rows_per_k + c of its trace
@@ -1543,7 +1449,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : 1024) k_seg_last_hash(SegArgs
 #else
                     const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, logD_)) << out_shift);
 #endif
-                    const P2 v = *reinterpret_cast<P2 *>(x + swz_row<SWZ>(pos0 + pj) * S + lane_a);
+                    const P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
 #if defined(WF_EXP_LOCAL_STORE) && WF_EXP_LOCAL_STORE == 2
                     const uint64_t off = (((uint64_t)c * a.O + o) << logD_) * S + (uint64_t)(pos0 + pj) * S - (uint64_t)c * a.row_width;
 #else
@@ -1594,7 +1500,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : 1024) k_seg_last_hash(SegArgs
                 const uint32_t pos = tid + r * step;
                 T ev[S];
                 uint4 *evq = reinterpret_cast<uint4 *>(ev);
-                const uint4 *q = reinterpret_cast<const uint4 *>(x + (size_t)swz_row<SWZ>(pos) * S);
+                const uint4 *q = reinterpret_cast<const uint4 *>(x + (size_t)pos * S);
 #pragma unroll
                 for (uint32_t w = 0; w < 4; w++) evq[w] = q[w];
                 uint32_t m[16], cv[8];
@@ -1655,234 +1561,6 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : 1024) k_seg_last_hash(SegArgs
 
 #undef WF_TILE_LOAD
 #undef WF_STAMP
-
-// ---------------------------------------------------------------------------------------------------------------
-// SINGLE-pass evaluation with fused leaf hashing for rows LONGER than one BLAKE3 chunk -- the reference's own example at
-// its defaults (examples/src/lib.rs:97-135: 512 packed f128 traces of 2^10 steps: 1280 segments per coset, combined rows
-// of 80 chunks).  A tile is (coset c, segment g): the whole transform of 2^logN <= 2^10 rows of four / eight columns; tile
-// row k is block g % 16 of chunk g / 16 of LDE row k's message.  BLAKE3 chains the 16 blocks of a chunk, so block r needs
-// the chaining value block r - 1 left.  Walking a chunk's 16 segments in ONE work-group (as the multi-pass CHUNKED kernel
-// does) gives 8 x 80 = 640 tickets of 16 tiles for 512 resident work-groups: a makespan of 32 tiles where 20 would do.
-// Here every tile is its own ticket and the chaining values travel THROUGH MEMORY between work-groups:
-//   * one resident set of work-groups, tickets per XCD from a counter, in the order n = r * P + i: first block 0 of all
-//     P (coset, chunk) pairs of the XCD, then block 1 of all of them, ... -- the predecessor of ticket n is n - P, and
-//     P >= the work-groups resident per XCD in the shapes this kernel is launched for, so that block has normally long
-//     been hashed when its successor gets to its own hashing (the transform comes first);
-//   * a block's chaining values go to chunk_cvs[row][chunk] with agent-scope atomic stores, then (workgroup release fence,
-//     barrier) one lane publishes chain_flags[pair][r] = epoch; the successor spins on that flag (it can only ever wait for
-//     a LOWER ticket of its own XCD, which a resident work-group holds: no deadlock), then reads the values back with
-//     agent-scope atomic loads.  All of it stays inside one XCD's L2.  The spin is bounded: on expiry the work-group sets
-//     the error word tile_counters[16] and goes on (the host reports it; the output is then wrong).
-// MEASURED (round 3, 512 x 2^10 x 10 f128, one box, interleaved): this kernel 1.62 ms; without the wait and the read-back
-// (wrong leaves) 1.30; additionally with plain instead of agent-scope atomic stores 1.14; the chain with plain vector
-// accesses + an L1 invalidate (correct only while producer and consumer share an XCD) 1.27 -- against 0.76 + 0.38 ms for
-// the plain evaluation pass + the separate chunk kernels.  The hand-over costs what the saved re-read of the LDE would
-// have bought (0.34 GB of chaining values written and read back), and a persistent tile loop without prefetch is no
-// faster than one work-group per tile.  NOT USED by default (wf_tuning::single_fused); kept as the measured record.
-// Tile source = the polynomial's segment (shared by the cosets), multiplied on the way into LDS by the coset factors
-// h_c^row, which depend only on (coset, thread): eight per thread, kept in registers while the coset does not change.
-template <class F, bool PADT>
-__global__ void __launch_bounds__(512, 4) k_seg_single_hash(SegArgs<F> a) {  // (4 waves per SIMD: two work-groups per CU)
-    typedef typename F::T T;
-    typedef Pair<T> P2;
-    constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;
-    constexpr uint32_t hp_shift = HP == 4 ? 2 : 1;
-    constexpr uint32_t WPE = F::BYTES / 4;
-    constexpr uint32_t EPC = 16 / F::BYTES;  // elements per 16-byte chunk of a row: 2 (f64) or 1 (f128)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const uint32_t D = 1u << a.logD;  // == 2^logN: single pass
-    const uint32_t NT = blockDim.x;   // == D / 2
-    T *x = reinterpret_cast<T *>(smem_raw);
-    T *twd = x + (size_t)D * S;
-    const uint32_t step = NT;
-    const uint32_t n_chunks = a.n_chunks;
-    const uint32_t k_stride = a.rows_per_k * (uint32_t)a.row_width;
-    const uint32_t hash_bytes = a.hash_epr * F::BYTES;
-    const uint64_t seg_elems = (uint64_t)D * S;
-
-    for (uint32_t e = threadIdx.x; e < D - 1; e += step) twd[e] = a.digit_tw[e];
-    uint32_t *ticket_sh = reinterpret_cast<uint32_t *>(twd + (D - 1));  // (unused last twiddle slot, as in k_seg_last_hash)
-
-    // the (coset, chunk) pairs of this XCD: cosets xcd, xcd + 8, .. when the cosets divide over the XCDs, else pairs q = xcd + 8 i
-    const uint32_t xcd = blockIdx.x & 7;
-    const bool by_coset = (a.n_cosets & 7) == 0;
-    const uint32_t total_pairs = a.n_cosets * n_chunks;
-    const uint32_t P = by_coset ? (a.n_cosets >> 3) * n_chunks : (total_pairs > xcd ? (total_pairs - xcd + 7) >> 3 : 0);
-    const uint32_t per_xcd = P * 16;
-    auto next_ticket = [&]() -> uint32_t {
-        __syncthreads();  // (everybody has read the previous ticket word; the tile in x is free)
-        if (threadIdx.x == 0) ticket_sh[0] = atomicAdd(a.tile_counters + xcd, 1u);
-        __syncthreads();
-        return ticket_sh[0];
-    };
-    auto sign_off = [&]() {
-        if (threadIdx.x == 0) {
-            const uint32_t mine = (gridDim.x + 7 - xcd) >> 3;
-            if (atomicAdd(a.tile_counters + 8 + xcd, 1u) == mine - 1) {
-                atomicExch(a.tile_counters + xcd, 0u);
-                atomicExch(a.tile_counters + 8 + xcd, 0u);
-            }
-        }
-    };
-
-    T fc[8];  // h_c^row of this thread's eight 16-byte chunks (rows (tid + j * NT) / 4)
-#pragma unroll
-    for (int j = 0; j < 8; j++) fc[j] = F::one();
-    uint32_t c_have = 0xFFFFFFFFu;
-
-    while (true) {
-        const uint32_t n = next_ticket();
-        if (n >= per_xcd) break;
-        const uint32_t r = n / P, idx = n - r * P;
-        uint32_t c, ch;
-        if (by_coset) {
-            const uint32_t i = idx / n_chunks;
-            ch = idx - i * n_chunks;
-            c = xcd + 8 * i;
-        } else {
-            const uint32_t q = xcd + 8 * idx;
-            c = q / n_chunks;
-            ch = q - c * n_chunks;
-        }
-        const uint32_t g = 16 * ch + r;
-        if (g >= a.n_seg) continue;  // the last chunk of a row may have fewer than 16 blocks
-        const uint32_t tid = opaque_tid();
-        if (c != c_have) {  // (uniform) coset factors of this thread's rows
-            Pow2L<F> pre = a.pre;
-            pre.lo += (uint64_t)(a.coset0 + c) * a.pre_lo_stride;
-            pre.hi += (uint64_t)(a.coset0 + c) * a.pre_hi_stride;
-#pragma unroll
-            for (int j = 0; j < 8; j++) fc[j] = pre.get((tid + j * step) >> 2);
-            c_have = c;
-        }
-        {   // tile: the segment's D rows (contiguous 4 D chunks of 16 bytes), scaled, into LDS
-            const uint4 *s_ = reinterpret_cast<const uint4 *>(a.src + (uint64_t)g * seg_elems) + tid;
-            uint4 *d_ = reinterpret_cast<uint4 *>(x) + tid;
-            uint4 q[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) q[j] = s_[j * step];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                T e[EPC];
-                *reinterpret_cast<uint4 *>(e) = q[j];
-#pragma unroll
-                for (uint32_t w = 0; w < EPC; w++) e[w] = F::mul(e[w], fc[j]);
-                d_[j * step] = *reinterpret_cast<uint4 *>(e);
-            }
-        }
-        __syncthreads();
-        seg_lds_ntt<F, 1>(x, twd, a.logD, NT);
-
-        // row stores: as the multi-segment branch of k_seg_last_hash (k = digit-reversed position: a single pass has no outer digits)
-        {
-            const uint32_t pstride = step >> hp_shift, pos0 = tid >> hp_shift, lane_a = 2 * (tid & (HP - 1));
-            const uint32_t B = g * S + lane_a;
-            T *pa = nullptr, *pb = nullptr, *pz = nullptr, *pz2 = nullptr;
-            bool pair = false;
-            if (F::BYTES == 16 && !(PADT && a.row_width == 8)) {
-                store_rows_by_element<F>(x, a, g, c, 0, 0, k_stride, tid, NT, a.tail_pad && g + 1 == a.n_seg, PADT);
-            } else if (PADT && (a.row_width == 8 || (F::BYTES == 8 && a.row_width == 16 && a.store_cols <= 10))) {
-                store_rows_narrow<F>(x, a, g, c, 0, 0, k_stride, tid, NT);
-            } else if (pos0 < D && B < a.total_store_cols) {
-                const uint32_t t0 = B / a.store_cols, c0 = B - t0 * a.store_cols;
-                pa = a.dst + (uint64_t)t0 * a.trace_lde_elems + (uint64_t)c * a.row_width + c0;
-                pair = c0 + 1 < a.store_cols && (c0 & 1) == 0;
-                if (PADT && c0 + 1 == a.store_cols) pz = pa + 1;
-                if (B + 1 < a.total_store_cols) {
-                    const uint32_t t1 = (B + 1) / a.store_cols, c1 = (B + 1) - t1 * a.store_cols;
-                    pb = a.dst + (uint64_t)t1 * a.trace_lde_elems + (uint64_t)c * a.row_width + c1;
-                    if (PADT && c1 + 1 == a.store_cols) pz2 = pb + 1;
-                }
-            }
-            if (pa) {
-                const uint32_t k0 = seg_digit_reverse<F>(pos0, a.logD);
-                for (uint32_t pj = 0; pj < D; pj += pstride) {
-                    const uint32_t k = k0 | seg_digit_reverse<F>(pj, a.logD);
-                    const P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a);
-                    const uint64_t off = (uint64_t)k * k_stride;
-                    if (pair) {
-                        store_pair(pa + off, v);
-                    } else {
-                        pa[off] = v.a;
-                        if (pb) pb[off] = v.b;
-                    }
-                    if (PADT && pz) store_row_padding<F>(pz + off, a.store_cols, (uint32_t)a.row_width);
-                    if (PADT && pz2) store_row_padding<F>(pz2 + off, a.store_cols, (uint32_t)a.row_width);
-                }
-            }
-        }
-
-        // block r of chunk ch of this tile's rows: wait for block r - 1 (a lower ticket of this XCD), chain, publish
-        const uint32_t flag_base = (c * n_chunks + ch) * 16;
-        const uint32_t g_end = min(16 * ch + 16, a.n_seg);
-        const bool first = r == 0, last = g + 1 == g_end;
-#ifndef WF_EXP_SINGLE_VARIANT
-#define WF_EXP_SINGLE_VARIANT 0   // tuning: 1 = no wait / IV always (wrong leaves), 2 = also plain stores, 3 = plain vector accesses + L1 invalidate
-#endif
-        if (!first && WF_EXP_SINGLE_VARIANT != 1 && WF_EXP_SINGLE_VARIANT != 2) {
-            if (threadIdx.x == 0) {
-                uint32_t spins = 0;
-                while (__hip_atomic_load(a.chain_flags + flag_base + r - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.chain_epoch) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1u << 24)) {  // (seconds: the predecessor is held by a resident work-group -- this cannot happen)
-                        atomicExch(a.tile_counters + 16, 1u);
-                        break;
-                    }
-                }
-            }
-            __syncthreads();
-            if (WF_EXP_SINGLE_VARIANT == 3) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // invalidates this CU's L1
-        }
-        {
-            const uint32_t flags = (first ? (uint32_t)b3::CHUNK_START : 0u) | (last ? (uint32_t)b3::CHUNK_END : 0u);
-            const uint32_t blen = min(64u, hash_bytes - 64u * g);
-#pragma unroll 1
-            for (uint32_t rr = 0; rr < 2; rr++) {
-                const uint32_t pos = tid + rr * step;
-                const uint32_t k = seg_digit_reverse<F>(pos, a.logD);
-                const uint64_t row = (uint64_t)k * a.rows_per_k + c;
-                unsigned long long *cvp = reinterpret_cast<unsigned long long *>(a.chunk_cvs + (row * n_chunks + ch) * 8);
-                T ev[S];
-                uint4 *evq = reinterpret_cast<uint4 *>(ev);
-                const uint4 *q = reinterpret_cast<const uint4 *>(x + (size_t)pos * S);
-#pragma unroll
-                for (uint32_t w = 0; w < 4; w++) evq[w] = q[w];
-                uint32_t m[16], cv[8];
-#pragma unroll
-                for (uint32_t e = 0; e < S; e++) elem_words<F>(ev[e], &m[e * WPE]);
-                if (first || WF_EXP_SINGLE_VARIANT == 1 || WF_EXP_SINGLE_VARIANT == 2) {
-                    b3::set_iv(cv);
-                } else if (WF_EXP_SINGLE_VARIANT == 3) {
-                    const uint4 lo = reinterpret_cast<const uint4 *>(cvp)[0], hi = reinterpret_cast<const uint4 *>(cvp)[1];
-                    cv[0] = lo.x; cv[1] = lo.y; cv[2] = lo.z; cv[3] = lo.w;
-                    cv[4] = hi.x; cv[5] = hi.y; cv[6] = hi.z; cv[7] = hi.w;
-                } else {
-#pragma unroll
-                    for (int w = 0; w < 4; w++) {
-                        const unsigned long long v = __hip_atomic_load(cvp + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        cv[2 * w] = (uint32_t)v;
-                        cv[2 * w + 1] = (uint32_t)(v >> 32);
-                    }
-                }
-                b3::compress(cv, m, ch, 0, blen, flags);
-                if (WF_EXP_SINGLE_VARIANT >= 2) {
-                    reinterpret_cast<uint4 *>(cvp)[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
-                    reinterpret_cast<uint4 *>(cvp)[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
-                } else {
-#pragma unroll
-                    for (int w = 0; w < 4; w++)
-                        __hip_atomic_store(cvp + w, ((unsigned long long)cv[2 * w + 1] << 32) | cv[2 * w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-        if (!last) {  // publish: every lane's stores have completed (release fence = wait for them), then the flag
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_store(a.chain_flags + flag_base + r, a.chain_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    sign_off();
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Layout changes between the caller's columns ([col][row][ext coordinate]) and segments.

@@ -50,9 +50,11 @@ struct TableSet {  // device-resident Pow2L tables
     uint64_t lo_stride = 0, hi_stride = 0;  // per-coset strides (elements)
 };
 
-// Test / tuning switches (WF_EXP_* environment variables).  They are read ONCE, when a context is created, into this
-// struct: the launch path consults ctx->tune and never the environment, so nothing a process does to its environment
-// later changes which kernel a customer's call runs.  All off by default; tests/test_gpu_plans.py forces each one.
+// Test / tuning switches (WF_EXP_* environment variables): they force the planner's and launcher's ALTERNATIVES (all
+// product code: every one is the default for some shape) so that the parity suites reach each of them on small inputs.
+// Read ONCE, when a context is created, and only when WF_EXP_ENABLE=1 is set as well (a stray WF_EXP_* variable in a
+// production environment changes nothing); values are range-checked.  The launch path consults ctx->tune and never the
+// environment.  All off by default; tests/test_gpu_plans.py forces each one.
 struct wf_tuning {
     uint32_t max_digit = 0;           // WF_EXP_MAX_DIGIT: cap the digit size (more, smaller passes); 0 = planner's own
     bool full_tiles = false;          // WF_EXP_FULL_TILES: allow plans of two maximal digits (one work-group per CU in both passes)
@@ -64,8 +66,6 @@ struct wf_tuning {
     uint32_t merkle_l2_min = 18;      // WF_EXP_MERKLE_L2_MIN: log2 of the narrowest level the two-level launches take
     bool no_pipeline = false;         // WF_EXP_NO_PIPELINE: host columns uploaded in front of the kernels, never under them
     size_t pipeline_min_bytes = (size_t)1 << 20;  // WF_EXP_PIPELINE_MIN_BYTES
-    bool fold_input = false;          // WF_EXP_FOLD_INPUT: the interpolation's first pass reads the caller's COLUMNS (no cols->segments launch): measured, off
-    bool single_fused = false;        // WF_EXP_SINGLE_FUSED: single-pass long rows hashed inside the pass (k_seg_single_hash: measured slower, off)
     int fail_after_segment = -1;      // WF_EXP_FAIL_AFTER_SEGMENT: the pipelined upload fails after that many segments (error-path test)
 };
 wf_tuning tuning_from_env();
@@ -92,8 +92,6 @@ struct wf_ctx {
     DevBuf io[5];     // staging for the host-buffer API: trace, polys, lde, leaves, nodes
     DevBuf hash_tmp;  // chunk chaining values of rows longer than one BLAKE3 chunk
     DevBuf tickets;   // per-XCD tile counters of the persistent last passes (+ word 16: their error flag)
-    DevBuf chain_flags;  // k_seg_single_hash: per (coset, chunk, block) publication flags, compared with chain_epoch
-    uint32_t chain_epoch = 0;
     // Buffers of destroyed resident commitments, kept for the next commitment of the same shape (four hipFree + four
     // hipMalloc of 64..512 MiB cost about as much as the commitment itself); released by wf_ctx_release_cached / destroy.
     // Guarded by pool_mutex: a handle may be destroyed by another thread (a finaliser, Rust's Drop) while a call runs.
@@ -123,11 +121,11 @@ struct wf_ctx {
     hipEvent_t stage_free[2] = {nullptr, nullptr}, upload_done[2] = {nullptr, nullptr};
     bool stage_busy[2] = {false, false};
     uint64_t async_seq = 0;
-    uint8_t *root_pin = nullptr;
-    std::vector<uint8_t> root_used;
+    uint8_t *root_pin = nullptr;       // WF_ROOT_SLOTS slots of WF_ROOT_SLOT_BYTES: the root, then the device error word behind that commitment
+    std::vector<uint8_t> root_used;    // guarded by pool_mutex (slots are handed back by whatever thread completes a handle)
     uint64_t generation = 0;  // distinguishes this context from an earlier one at the same address (stale handles)
 };
-static constexpr size_t WF_ROOT_SLOTS = 256;
+static constexpr size_t WF_ROOT_SLOTS = 256, WF_ROOT_SLOT_BYTES = 64;
 
 // RAII entry of every ctx-taking entry point (see the two comments above).  Re-entrant for the owning thread: the
 // host-buffer forms call the device-buffer forms.
@@ -179,6 +177,13 @@ struct CallGuard {
 // sit at the old address is not mistaken for the handle's own -- and frees its device buffers directly.
 bool ctx_alive(const wf_ctx *ctx);
 bool ctx_alive(const wf_ctx *ctx, uint64_t generation);
+// holds the registry's lock for its lifetime; `alive`: the context (address AND generation) exists and cannot be retired
+// by wf_ctx_destroy while this object lives
+struct CtxPin {
+    std::unique_lock<std::mutex> lock;
+    bool alive;
+    CtxPin(const wf_ctx *ctx, uint64_t generation);
+};
 
 hipError_t dev_malloc(wf_ctx *ctx, void **p, size_t bytes);
 hipError_t pool_alloc(wf_ctx *ctx, void **p, size_t bytes);
@@ -199,6 +204,8 @@ struct wf_comm {
     wf_transport tr{};
     DevBuf stage;  // receive staging of the leaf exchanges ([world][...] rank-major, before the interleave)
     DevBuf small;  // barrier / reduction words
+    void *pin = nullptr;  // pinned host memory the host-blocking calls copy back into (comm_pinned); freed by wf_comm_destroy only
+    size_t pin_cap = 0;
     // Watchdog of the host-blocking calls (barrier, reductions, collective queries, wf_comm_stream_wait): a rank that died
     // or never arrives must not leave the others waiting for ever.  WF_COMM_TIMEOUT_S, read once at creation.
     double timeout_s = 300.0;
@@ -209,6 +216,7 @@ int comm_all_gather(wf_comm *c, const void *d_send, void *d_recv, size_t bytes, 
 // block s (`bytes` bytes at d_send + s * bytes) of rank r lands at d_recv + r * bytes on rank s
 int comm_all_to_all(wf_comm *c, const void *d_send, void *d_recv, size_t bytes, hipStream_t st);
 int comm_wait(wf_comm *c, hipStream_t st);                         // host-blocking, under the watchdog
+int comm_pinned(wf_comm *c, size_t bytes, void **out);             // communicator-owned pinned memory of at least `bytes`
 int comm_agree(wf_comm *c, int local_rc, const char *what);        // every rank returns an error if one of them failed locally
 int comm_interleave(hipStream_t st, const void *src, void *dst, uint64_t n_k, uint32_t world, uint32_t per);
 
@@ -265,6 +273,7 @@ struct wf_commitment {
     bool pending;
     hipEvent_t done;
     uint32_t root_slot1;
+    int device;  // of its context (a handle may be completed after its context is gone)
 };
 void free_commitment(wf_commitment *c);
 int commitment_alloc(wf_ctx *ctx, const wf_params *p, bool constraint, wf_commitment **out, bool *dense_out);

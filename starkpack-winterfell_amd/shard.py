@@ -54,6 +54,47 @@ def route(log2_lde_rows: int, blowup: int, world: int, position: int):
 
 
 # ---- rendezvous ---------------------------------------------------------------------------------------------------
+def unique_id() -> bytes:
+    """ncclGetUniqueId through the library (wf_comm_unique_id): the 128 bytes rank 0 hands to every rank."""
+    uid = (C.c_uint8 * 128)()
+    capi._check(capi.load().wf_comm_unique_id(uid))
+    return bytes(uid)
+
+
+class Loopback:
+    """An in-process transport for wf_comm -- W ranks as W threads of one process, the bytes of the two collectives handed
+    over through host memory (`collectives(rank)` -> the pair `Comm.with_transport` takes).  Lets one GPU (or none, for the
+    callbacks alone) run the multi-rank code paths of libwf_lde.so exactly as RCCL would drive them: rehearsals of the
+    thread-per-GPU route of bench.py and the tests."""
+
+    def __init__(self, world: int, timeout: float = 120.0):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world, timeout=timeout)
+        self.slots = [None] * world
+
+    def collectives(self, rank: int):
+        import numpy as np
+        world = self.world
+
+        def all_gather(mine):
+            self.slots[rank] = np.array(mine, copy=True)
+            self.barrier.wait()
+            out = np.concatenate(self.slots)
+            self.barrier.wait()  # nobody overwrites a slot before everybody has read it
+            return out
+
+        def all_to_all(mine):
+            self.slots[rank] = np.array(mine, copy=True)
+            self.barrier.wait()
+            n = mine.size // world
+            out = np.concatenate([self.slots[s][rank * n:(rank + 1) * n] for s in range(world)])
+            self.barrier.wait()
+            return out
+
+        return all_gather, all_to_all
+
+
 def store_from_env(rank: int, world: int, timeout_s: float = 300.0):
     """The TCP key-value store at MASTER_ADDR:MASTER_PORT (rank 0 hosts it) -- the env torch.distributed.run sets."""
     import datetime
@@ -106,6 +147,15 @@ class Comm:
         return cls(h, ctx)
 
     @classmethod
+    def with_unique_id(cls, ctx, uid: bytes, rank: int, world: int):
+        """RCCL communicator from an id the caller already holds (ranks that are threads of one process hand it over in
+        memory: `unique_id()` on one thread, this on every thread -- ncclCommInitRank returns once all `world` have called)."""
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid[:128])
+        capi._check(capi.load().wf_comm_create(ctx._h, buf, rank, world, C.byref(h)))
+        return cls(h, ctx)
+
+    @classmethod
     def with_transport(cls, ctx, rank: int, world: int, all_gather, all_to_all):
         """Caller-supplied transport (wf_transport).  `all_gather(mine)` takes this rank's bytes (numpy uint8 [n]) and
         returns everybody's, rank-major [world * n]; `all_to_all(mine)` takes [world * n] (block s is for rank s) and
@@ -148,6 +198,19 @@ class Comm:
         v = C.c_double(value)
         capi._check(capi.load().wf_comm_max_f64(self._h, C.byref(v)))
         return v.value
+
+    def gather_f64(self, value: float):
+        """One double of every rank on every rank, rank-major (wf_comm_gather_f64)."""
+        out = (C.c_double * self.world)()
+        capi._check(capi.load().wf_comm_gather_f64(self._h, float(value), out))
+        return list(out)
+
+    def info(self):
+        """What the transport reports about this communicator (wf_comm_info): for RCCL ncclCommCount / ncclCommUserRank /
+        ncclCommCuDevice of the ncclComm_t in use."""
+        t, n, r, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        capi._check(capi.load().wf_comm_info(self._h, C.byref(t), C.byref(n), C.byref(r), C.byref(d)))
+        return {"transport": "rccl" if t.value == 0 else "caller", "count": n.value, "user_rank": r.value, "device": d.value}
 
     def all_gather_roots(self, d_roots: int, n_roots: int, d_all: int, stream: int = 0):
         """The one collective of the independent-proofs sharding: [n_roots][32] per rank -> [world][n_roots][32]."""

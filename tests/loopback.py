@@ -1,36 +1,12 @@
-"""Test helper: an in-process transport for wf_comm -- W ranks as W threads of one process, the bytes of the two
-collectives handed over through host memory.  Lets one GPU (or none, for the callbacks alone) run the multi-rank code
-paths of libwf_lde.so exactly as RCCL would drive them."""
+"""Test helper: W ranks as W threads of one process on the in-process transport of the package (shard.Loopback: the bytes of
+the two collectives handed over through host memory) -- one GPU (or none, for the callbacks alone) runs the multi-rank
+code paths of libwf_lde.so exactly as RCCL would drive them."""
+import os
+import sys
 import threading
 
-import numpy as np
-
-
-class Loopback:
-    def __init__(self, world: int, timeout: float = 120.0):
-        self.world = world
-        self.barrier = threading.Barrier(world, timeout=timeout)
-        self.slots = [None] * world
-
-    def collectives(self, rank: int):
-        world = self.world
-
-        def all_gather(mine):
-            self.slots[rank] = np.array(mine, copy=True)
-            self.barrier.wait()
-            out = np.concatenate(self.slots)
-            self.barrier.wait()  # nobody overwrites a slot before everybody has read it
-            return out
-
-        def all_to_all(mine):
-            self.slots[rank] = np.array(mine, copy=True)
-            self.barrier.wait()
-            n = mine.size // world
-            out = np.concatenate([self.slots[s][rank * n:(rank + 1) * n] for s in range(world)])
-            self.barrier.wait()
-            return out
-
-        return all_gather, all_to_all
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from starkpack_winterfell_amd.shard import Loopback  # noqa: E402,F401  (re-exported for the tests)
 
 
 def run_ranks(world: int, fn):

@@ -155,12 +155,13 @@ def test_failed_pipelined_upload_drains_its_streams_and_leaves_the_context_usabl
     it allocated, and leave the context serving other shapes."""
     import os
     from conftest import rand_cols
+    os.environ["WF_EXP_ENABLE"] = "1"
     os.environ["WF_EXP_FAIL_AFTER_SEGMENT"] = "2"
     os.environ["WF_EXP_PIPELINE_MIN_BYTES"] = "0"
     try:
         ctx = capi.Context(0)
     finally:
-        del os.environ["WF_EXP_FAIL_AFTER_SEGMENT"], os.environ["WF_EXP_PIPELINE_MIN_BYTES"]
+        del os.environ["WF_EXP_FAIL_AFTER_SEGMENT"], os.environ["WF_EXP_PIPELINE_MIN_BYTES"], os.environ["WF_EXP_ENABLE"]
     rng = np.random.default_rng(9)
     wide = capi.make_params(1, 1, 12, 3, 40, 1)      # five segments, two passes: the pipelined route
     cols = rand_cols(rng, 1, 40, 1 << 12)

@@ -149,6 +149,8 @@ out = torch.zeros_like(roots)
 comm.all_gather_roots(roots.data_ptr(), 3, out.data_ptr())
 comm.barrier()
 assert comm.max_f64(2.5) == 2.5
+assert comm.gather_f64(7.25) == [7.25]
+assert comm.info() == {"transport": "rccl", "count": 1, "user_rank": 0, "device": 0}, comm.info()   # ncclCommCount / UserRank / CuDevice
 ctx.synchronize()
 assert torch.equal(out, roots)
 rng = np.random.default_rng(3)
@@ -291,3 +293,97 @@ def test_sharded_resident_commitment_and_collective_queries(orc, capi, field, lo
         assert np.array_equal(rows1.reshape(-1), want_rows[0].reshape(-1)) and proof1 == want_proof1
         assert codes == [-19, -18, -18]
         assert np.array_equal(ood.reshape(want_ood.shape), want_ood)
+
+
+def test_watchdog_covers_the_blocking_calls_when_a_peer_never_arrives(orc, capi, monkeypatch):
+    """WF_COMM_TIMEOUT_S at the C level: rank 1 leaves (it never enters the next collective), so what rank 0's transport
+    queues on the stream cannot complete -- here a host function that blocks the stream.  wf_comm_barrier and
+    wf_sharded_commitment_query must come back with WF_ERR_COMM after the time-out instead of hanging inside a copy into
+    pageable memory, every later collective must be refused, and the copies that were still queued when the calls gave up
+    must land in memory that is still there (the communicator's pinned buffer) once the stream is released."""
+    import threading
+    import time
+    from starkpack_winterfell_amd import shard
+    monkeypatch.setenv("WF_COMM_TIMEOUT_S", "2")
+    world, logR, logB, n_cols = 2, 9, 3, 8
+    rng = np.random.default_rng(5)
+    cols = rand_cols(rng, F64, n_cols, 1 << logR)
+    params = capi.make_params(F64, 1, logR, logB, n_cols, 1)
+    want = orc.build_trace_commitment(F64, [cols], 1, logR, logB, 7)
+    hip = shard._hip_runtime()
+    HOSTFN = C.CFUNCTYPE(None, C.c_void_p)
+    hip.hipLaunchHostFunc.argtypes = [C.c_void_p, HOSTFN, C.c_void_p]
+    release, peer_gone, done = threading.Event(), threading.Event(), threading.Event()
+    blocker = HOSTFN(lambda _u: (release.wait(60), None)[1])
+    lb = Loopback(world)
+    out = {}
+
+    def rank_fn(r):
+        ctx = capi.Context(0)
+        ag, a2a = shard.transport_callbacks(world, *lb.collectives(r))
+
+        def guarded(inner):
+            def cb(user, d_send, d_recv, nbytes, stream):
+                if r == 0 and peer_gone.is_set():  # the peer never arrives: the exchange stays queued for ever
+                    return hip.hipLaunchHostFunc(C.c_void_p(stream), blocker, None)
+                return inner(user, d_send, d_recv, nbytes, stream)
+            return capi.TRANSPORT_FN(cb)
+
+        cbs = (guarded(ag), guarded(a2a))
+        tr = capi.Transport(None, cbs[0], cbs[1])
+        h = C.c_void_p()
+        capi._check(capi.load().wf_comm_create_with_transport(ctx._h, C.byref(tr), r, world, C.byref(h)))
+        comm = shard.Comm(h, ctx, keep=(cbs, tr, ag, a2a))
+        com = comm.trace_commit_sharded_resident(params, cols)
+        assert com.root() == want["root"]
+        rows, _ = com.query(np.array([1, 77], dtype=np.uint64))   # a working collective query first
+        comm.barrier()
+        if r == 1:
+            peer_gone.set()
+            done.wait(120)   # keeps its handles alive; never calls another collective
+        else:
+            peer_gone.wait(60)
+            t0 = time.perf_counter()
+            with pytest.raises(capi.WfError) as e:
+                com.query(np.array([5, 9], dtype=np.uint64))
+            waited = time.perf_counter() - t0
+            out["query"] = (e.value.code, waited)
+            for call in (comm.barrier, lambda: comm.max_f64(1.0), lambda: com.query(np.array([5], dtype=np.uint64))):
+                with pytest.raises(capi.WfError) as e2:   # a dead communicator refuses further collectives at once
+                    call()
+                out.setdefault("after", []).append(e2.value.code)
+            release.set()       # the stream drains: the copies queued behind the dead exchange run now
+            ctx.synchronize()
+            done.set()
+        com.close()
+        comm.close()
+        ctx.close()
+        return True
+
+    try:
+        assert run_ranks(world, rank_fn) == [True, True]
+    finally:
+        release.set()
+        done.set()
+    code, waited = out["query"]
+    assert code == -32 and 1.5 < waited < 30, out
+    assert out["after"] == [-32, -32, -32]
+
+
+def test_comm_info_and_gather_f64(capi):
+    """wf_comm_info / wf_comm_gather_f64 on the loopback transport (what bench.py puts into `collective`)."""
+    from starkpack_winterfell_amd import shard
+    world = 4
+    lb = Loopback(world)
+
+    def rank_fn(r):
+        ctx = capi.Context(0)
+        comm = shard.Comm.with_transport(ctx, r, world, *lb.collectives(r))
+        got = comm.gather_f64(1.5 * r), comm.info()
+        comm.close()
+        ctx.close()
+        return got
+
+    for r, (vals, info) in enumerate(run_ranks(world, rank_fn)):
+        assert vals == [0.0, 1.5, 3.0, 4.5]
+        assert info == {"transport": "caller", "count": world, "user_rank": r, "device": 0}

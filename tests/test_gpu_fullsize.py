@@ -239,18 +239,21 @@ def test_packed_8_traces_2_20_x8_full(ctx, orc, capi):
 
 
 def test_tuning_switches_of_the_2_20_shape_give_the_same_bytes(ctx, capi, monkeypatch):
-    """The switches that only this shape reaches (read once per context, at wf_ctx_create): WF_EXP_FOLD_INPUT -- the first
-    interpolation pass gathers the caller's columns itself -- and WF_EXP_NO_SPECIALIZED -- every tile on the generic kernels.
-    Same polynomials, LDE, leaves, nodes and root as the default context (which test_cfg2_2_20_x8 checks against the oracle)."""
+    """The switches whose effect on 2^10-row tiles only this shape reaches (read once per context, at wf_ctx_create, under
+    WF_EXP_ENABLE=1): WF_EXP_NO_SPECIALIZED -- every tile on the generic kernels -- and WF_EXP_NO_PERSISTENT -- the fused
+    last pass as one work-group per tile.  Same polynomials, LDE, leaves, nodes and root as the default context (which
+    test_cfg2_2_20_x8 checks against the oracle)."""
     logR, logB, C = 20, 3, 8
     rng = np.random.default_rng(77)
     cols = [rand_f64(rng, 1 << logR) for _ in range(C)]
     params = capi.make_params(F64, 1, logR, logB, C, 1)
     want = ctx.trace_commit(params, cols)
-    for switch in ("WF_EXP_FOLD_INPUT", "WF_EXP_NO_SPECIALIZED"):
+    for switch in ("WF_EXP_NO_SPECIALIZED", "WF_EXP_NO_PERSISTENT"):
+        monkeypatch.setenv("WF_EXP_ENABLE", "1")
         monkeypatch.setenv(switch, "1")
         other = capi.Context(0)
         monkeypatch.delenv(switch)
+        monkeypatch.delenv("WF_EXP_ENABLE")
         try:
             got = other.trace_commit(params, cols)
         finally:

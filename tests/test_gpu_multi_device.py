@@ -6,7 +6,11 @@
     device count, capped by WF_TEST_RANKS (default 4: the GPU boxes of this pool allow few processes per card).
   * On any GPU box: the very same rank script and the same bench gates over the gloo rehearsal transport, the ranks
     sharing the device(s) -- so the code the multi-GPU run executes is exercised by every `pytest -m gpu`.
-  * The gates themselves: a corrupted root must take the run down with a non-zero exit code and no benchmark line."""
+  * The gates themselves: a corrupted root must take the run down with a non-zero exit code and no benchmark line.
+  * The ONE-PROCESS route (`bench.py --gpus W --ranks threads`: a host thread, a context and a communicator per GPU): on
+    >= 2 devices over real RCCL with W = ALL devices (largest power of two; no cap -- it costs one process whatever W is),
+    on any box over the in-process rehearsal transport; its record must carry what RCCL says about the communicator
+    (ncclCommCount, user ranks, devices) and every rank's own step time."""
 import json
 import os
 import socket
@@ -83,6 +87,69 @@ def test_rccl_bench_verifies_itself(capi, mode):
     assert j["collective"]["verified"]["ok"] is True
     assert j["collective"]["rccl_path"] and j["collective"]["rccl_version"] > 0
     assert j["roots_gathered"] == (3 * w if mode == "proofs" else 3)
+
+
+# ---- one process, one host thread per GPU ---------------------------------------------------------------------------------
+def all_devices_world(capi):
+    n = capi.device_count()
+    if n < 2:
+        pytest.skip(f"{n} HIP device(s): RCCL needs one device per rank (the thread route runs over the loopback transport below)")
+    w = 1
+    while 2 * w <= n:
+        w *= 2
+    return w
+
+
+@pytest.mark.parametrize("mode", ["proofs", "packed"])
+def test_rccl_thread_route_verifies_itself_on_all_devices(capi, mode):
+    w = all_devices_world(capi)
+    j = bench_line(run_bench("--gpus", str(w), "--ranks", "threads", "--steps", "3", "--warmup", "1", "--mode", mode))
+    c = j["collective"]
+    assert j["n_gpus"] == w and "RCCL inside libwf_lde.so" in c["transport"] and "thread" in c["ranks"]
+    assert c["verified"]["ok"] is True
+    assert c["nccl_comm_count"] == w and c["nccl_comm_counts"] == [w] * w     # RCCL itself: one communicator of w ranks
+    assert c["nccl_user_ranks"] == list(range(w)) and sorted(c["nccl_devices"]) == list(range(w))   # ... on w distinct devices
+    assert len(c["ms_per_step_per_rank"]) == w and all(x > 0 for x in c["ms_per_step_per_rank"])
+    assert j["roots_gathered"] == (3 * w if mode == "proofs" else 3)
+
+
+@pytest.mark.parametrize("mode,world", [("proofs", 2), ("packed", 2), ("proofs", 4), ("packed", 8)])
+def test_thread_route_over_the_loopback_transport(capi, mode, world):
+    """The same thread-per-rank control flow with the ranks sharing the device(s): gates pass, the record says what ran."""
+    capi.load()
+    j = bench_line(run_bench("--gpus", str(world), "--ranks", "threads", "--steps", "2", "--warmup", "1", "--mode", mode,
+                             env_extra={"WF_BENCH_BACKEND": "loopback"}))
+    c = j["collective"]
+    assert j["n_gpus"] == world and c["verified"]["ok"] is True and "thread" in c["ranks"] and "rehearsal" in c["transport"]
+    assert c["nccl_comm_counts"] == [world] * world and c["nccl_user_ranks"] == list(range(world))
+    assert len(c["ms_per_step_per_rank"]) == world
+    assert j["ms_per_step"] >= max(c["ms_per_step_per_rank"]) * 0.999    # the line's time is the MAX over the ranks
+    assert j["roots_gathered"] == (2 * world if mode == "proofs" else 2)
+
+
+@pytest.mark.parametrize("mode", ["proofs", "packed"])
+def test_thread_route_gate_fires_on_a_corrupted_root(capi, mode):
+    capi.load()
+    out = run_bench("--gpus", "2", "--ranks", "threads", "--steps", "2", "--warmup", "1", "--mode", mode, "--inject-fault", "root",
+                    env_extra={"WF_BENCH_BACKEND": "loopback"})
+    assert out.returncode != 0
+    assert "PARITY FAILURE" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_thread_route_gives_up_on_a_rank_that_hangs(capi):
+    capi.load()
+    out = run_bench("--gpus", "2", "--ranks", "threads", "--steps", "1", "--warmup", "0", "--inject-fault", "hang",
+                    env_extra={"WF_BENCH_BACKEND": "loopback", "WF_BENCH_LAUNCH_TIMEOUT_S": "25", "WF_COMM_TIMEOUT_S": "60"}, timeout=300)
+    assert out.returncode == 124, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "did not finish within" in out.stderr
+
+
+def test_thread_route_refuses_rccl_with_fewer_devices_than_ranks(capi):
+    n = capi.device_count()
+    out = run_bench("--gpus", str(2 * n), "--ranks", "threads", "--steps", "1", "--warmup", "0")
+    assert out.returncode == 1 and "one device per rank" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
 
 
 # ---- the same code over the gloo rehearsal transport (any GPU box) -----------------------------------------------------

@@ -21,6 +21,7 @@ RESIDENT_FILES = ["test_gpu_queries.py", "test_gpu_deep.py", "test_gpu_pipeline.
 
 def _run_suite(switches, files):
     env = dict(os.environ)
+    env["WF_EXP_ENABLE"] = "1"  # the library reads its WF_EXP_* switches only under this one
     for sw in switches.split():
         name, value = sw.split("=")
         env[name] = value
