@@ -1,14 +1,6 @@
-// Column-layout NTT kernels (the stand-alone math::fft entry points: evaluate_poly, interpolate_poly,
-// interpolate_poly_with_offset on one column of E), leaf hashing and Merkle kernels (gfx950).
-// The commitment path itself runs the segment-layout kernels of seg_kernels.hpp.  See DESIGN.md.
-//
-// NTT of size N = 2^L is split into 1..4 "digit" passes (digits of <= 11 bits).  Input index
-// n = (n1, n2, .., nP) (n1 most significant), output index k = k1 + N1*k2 + N1*N2*k3 + ..  Pass i transforms digit
-// n_i -> k_i in place, inside LDS, for a tile of adjacent inner positions, then multiplies by the inter-pass
-// twiddle w_{Ni*..*NP}^(k_i * inner).  The last pass has inner = 1 (contiguous rows) and scatters its outputs to
-// natural order.
-// Nothing is ever bit-reverse permuted in memory (the reference's permute passes, math/src/fft/fft_inputs.rs:56-64
-// and prover/src/matrix/segments.rs:276-298, disappear into the index arithmetic).
+// Two-level power tables, leaf hashing and Merkle kernels, query gathers (gfx950).  The transforms are in seg_kernels.hpp
+// (segment layout: the commitment path) and col_kernels.hpp (one column: the stand-alone math::fft entry points).
+// See DESIGN.md.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -41,224 +33,6 @@ struct Pow2L {
 };
 
 enum : uint32_t { SCALE_NONE = 0, SCALE_CONST = 1, SCALE_SERIES = 2 };
-
-template <class F>
-struct NttArgs {
-    typedef typename F::T T;
-    const T *src;
-    T *dst;
-    // transform
-    uint32_t logN;     // full transform size
-    uint32_t logD;     // this pass's digit
-    uint32_t W;        // coordinates per element (extension degree)
-    uint32_t Tl;       // tile: adjacent inner positions (strided pass) or adjacent k1 rows (last pass)
-    uint32_t V;        // values per LDS row = Tl*W
-    uint64_t I;        // strided pass: inner count (product of later digits)
-    uint64_t O;        // outer count (product of earlier digits)
-    uint32_t n_prev;   // last pass: number of earlier digits and their sizes (most significant first)
-    uint32_t prev_log[3];
-    uint64_t col_elems; // elements per column (= N); grid covers a batch of columns
-    // twiddles: powers of the N-th root used by this transform (forward or inverse)
-    Pow2L<F> tw;
-    // output scaling of the last pass
-    uint32_t scale_mode;
-    T scale;            // SCALE_CONST
-    Pow2L<F> out_pow;   // SCALE_SERIES: multiply output k by out_pow^k (lo table pre-multiplied by 1/n)
-};
-
-__device__ __forceinline__ uint32_t digit_reverse(uint32_t pos, uint32_t logD) {
-    // LDS position -> output index of the in-LDS transform (radix-4 digits, a trailing radix-2 digit if logD is odd)
-    uint32_t k = 0, cur = logD, sh = 0;
-    while (cur >= 2) {
-        k |= ((pos >> (cur - 2)) & 3u) << sh;
-        sh += 2;
-        cur -= 2;
-    }
-    if (cur == 1) k |= (pos & 1u) << sh;
-    return k;
-}
-
-// In-place NTT of D = 2^logD rows of V values each, held in LDS as x[row*V + v]; twd[e] = w_D^e.
-// Natural order in, digit-reversed order out (see digit_reverse).
-template <class F>
-__device__ __forceinline__ void lds_ntt(typename F::T *x, const typename F::T *twd, uint32_t logD, uint32_t V) {
-    typedef typename F::T T;
-    const uint32_t D = 1u << logD;
-    const bool vpow2 = (V & (V - 1)) == 0;
-    const uint32_t vshift = 31 - __builtin_clz(V);
-    uint32_t cur = logD;
-    __syncthreads();  // x and twd were just written by other lanes
-    T w4 = F::one();
-    if (logD >= 2) w4 = twd[D >> 2];
-    while (cur > 0) {
-        if (cur != logD) __syncthreads();
-        if (cur >= 2) {
-            const uint32_t mlog = cur - 2, m = 1u << mlog;
-            const uint32_t nwork = (D >> 2) * V;
-            const uint32_t tstep = 1u << (logD - cur);
-            const uint32_t st = m * V;
-            for (uint32_t wk = threadIdx.x; wk < nwork; wk += blockDim.x) {
-                uint32_t u, v;
-                if (vpow2) {
-                    u = wk >> vshift;
-                    v = wk & (V - 1);
-                } else {
-                    u = wk / V;
-                    v = wk - u * V;
-                }
-                const uint32_t jp = u & (m - 1), p = u >> mlog;
-                const uint32_t base = ((p << cur) + jp) * V + v;
-                T x0 = x[base], x1 = x[base + st], x2 = x[base + 2 * st], x3 = x[base + 3 * st];
-                T a = F::add(x0, x2), b = F::sub(x0, x2), c = F::add(x1, x3), d = F::mul(F::sub(x1, x3), w4);
-                T y0 = F::add(a, c), y2 = F::sub(a, c), y1 = F::add(b, d), y3 = F::sub(b, d);
-                if (jp != 0) {
-                    const uint32_t e = jp * tstep;
-                    y1 = F::mul(y1, twd[e]);
-                    y2 = F::mul(y2, twd[2 * e]);
-                    y3 = F::mul(y3, twd[3 * e]);
-                }
-                x[base] = y0;
-                x[base + st] = y1;
-                x[base + 2 * st] = y2;
-                x[base + 3 * st] = y3;
-            }
-            cur -= 2;
-        } else {
-            const uint32_t nwork = (D >> 1) * V;
-            for (uint32_t wk = threadIdx.x; wk < nwork; wk += blockDim.x) {
-                uint32_t u, v;
-                if (vpow2) {
-                    u = wk >> vshift;
-                    v = wk & (V - 1);
-                } else {
-                    u = wk / V;
-                    v = wk - u * V;
-                }
-                const uint32_t base = (u << 1) * V + v;
-                T x0 = x[base], x1 = x[base + V];
-                x[base] = F::add(x0, x1);
-                x[base + V] = F::sub(x0, x1);
-            }
-            cur = 0;
-        }
-    }
-    __syncthreads();
-}
-
-template <class F>
-__device__ __forceinline__ void build_digit_twiddles(typename F::T *twd, const Pow2L<F> &tw, uint32_t logN,
-                                                     uint32_t logD) {
-    const uint32_t D = 1u << logD;
-    for (uint32_t e = threadIdx.x; e < D; e += blockDim.x) twd[e] = tw.get((uint64_t)e << (logN - logD));
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Strided pass: view [O][D][I] of every column (I contiguous), transform the D axis for a tile of Tl inner positions.
-// grid.x = batch * O * (I / Tl)
-template <class F>
-__global__ void __launch_bounds__(1024) k_ntt_strided(NttArgs<F> a) {
-    typedef typename F::T T;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const uint32_t D = 1u << a.logD, V = a.V;
-    T *x = reinterpret_cast<T *>(smem_raw);
-    T *twd = x + (size_t)D * V;
-
-    const uint64_t tiles = a.I / a.Tl;
-    uint64_t bid = blockIdx.x;
-    const uint64_t tile = bid % tiles;
-    bid /= tiles;
-    const uint64_t o = bid % a.O;
-    const uint64_t b = bid / a.O;
-    const uint64_t i0 = tile * a.Tl;
-    const T *src = a.src + b * a.col_elems * a.W;
-    T *dst = a.dst + b * a.col_elems * a.W;
-
-    build_digit_twiddles<F>(twd, a.tw, a.logN, a.logD);
-    const uint32_t total = D * V;
-    for (uint32_t wk = threadIdx.x; wk < total; wk += blockDim.x) {
-        const uint32_t d = wk / V, v = wk - d * V;
-        x[wk] = src[((o * D + d) * a.I + i0) * a.W + v];
-    }
-    lds_ntt<F>(x, twd, a.logD, V);
-    // inter-pass twiddle w_{D*I}^(k*i) = w_N^(k*i*N/(D*I)), store with digit d -> k
-    const uint32_t tw_shift = a.logN - a.logD - (63 - __builtin_clzll(a.I));
-    for (uint32_t wk = threadIdx.x; wk < total; wk += blockDim.x) {
-        const uint32_t pos = wk / V, v = wk - pos * V;
-        const uint32_t k = digit_reverse(pos, a.logD);
-        const uint64_t i = i0 + v / a.W;
-        const uint64_t e = ((uint64_t)k * i) << tw_shift;
-        T val = x[wk];
-        if (e) val = F::mul(val, a.tw.get(e));
-        dst[((o * D + k) * a.I + i0) * a.W + v] = val;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Last pass: view [O][D] (D contiguous) of one column; Tl adjacent k1 rows per work-group so that the natural-order
-// outputs form Tl-element runs.  grid.x = batch * (O / Tl)
-template <class F>
-__global__ void __launch_bounds__(1024) k_ntt_last(NttArgs<F> a) {
-    typedef typename F::T T;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const uint32_t D = 1u << a.logD, V = a.V, W = a.W;
-    T *x = reinterpret_cast<T *>(smem_raw);
-    T *twd = x + (size_t)D * V;
-
-    // tiles over the most significant earlier digit k1
-    const uint32_t log1 = a.n_prev ? a.prev_log[0] : 0;
-    const uint64_t O_lo = a.O >> log1;  // combinations of the remaining earlier digits
-    const uint64_t k1_tiles = ((uint64_t)1 << log1) / a.Tl;
-    const uint64_t tiles = k1_tiles * O_lo;
-    uint64_t bid = blockIdx.x;
-    const uint64_t tile = bid % tiles;
-    const uint64_t b = bid / tiles;
-    const uint64_t k1_0 = (tile % k1_tiles) * a.Tl;
-    const uint64_t o_rest = tile / k1_tiles;
-    // natural output index contributed by the earlier digits other than k1: o_rest = (k2, k3, ..), k2 most significant
-    uint64_t rev_rest = 0;
-    {
-        uint32_t sh_out = log1, bits_rest = 0;
-        for (uint32_t i = 1; i < a.n_prev; i++) bits_rest += a.prev_log[i];
-        uint32_t hi = bits_rest;
-        for (uint32_t i = 1; i < a.n_prev; i++) {
-            hi -= a.prev_log[i];
-            const uint64_t dig = (o_rest >> hi) & (((uint64_t)1 << a.prev_log[i]) - 1);
-            rev_rest |= dig << sh_out;
-            sh_out += a.prev_log[i];
-        }
-    }
-    const T *src_base = a.src + b * a.col_elems * W;
-    build_digit_twiddles<F>(twd, a.tw, a.logN, a.logD);
-
-    // load: line t_in is D*W contiguous values; read in 8-value chunks per line
-    const uint32_t lines = a.Tl;
-    const uint32_t line_vals = D * W;
-    const uint32_t CH = (line_vals % 8 == 0) ? 8 : 1;
-    const uint32_t total = D * V;
-    for (uint32_t wk = threadIdx.x; wk < total; wk += blockDim.x) {
-        const uint32_t gg = wk % CH;
-        const uint32_t r = wk / CH;
-        const uint32_t t_in = r % lines;
-        const uint32_t g = (r / lines) * CH + gg;  // value index inside the line
-        const uint32_t d = g / W, w = g - d * W;
-        const uint64_t o_t = ((k1_0 + t_in) * O_lo) + o_rest;
-        x[d * V + t_in * W + w] = src_base[o_t * D * W + g];
-    }
-    lds_ntt<F>(x, twd, a.logD, V);
-
-    T *dst = a.dst + b * a.col_elems * W;
-    for (uint32_t wk = threadIdx.x; wk < total; wk += blockDim.x) {
-        const uint32_t pos = wk / V, v = wk - pos * V;
-        const uint32_t t_in = v / W, w = v - t_in * W;
-        const uint64_t k = (k1_0 + t_in) + rev_rest + ((uint64_t)digit_reverse(pos, a.logD) << (a.logN - a.logD));
-        T val = x[wk];
-        if (a.scale_mode == SCALE_CONST)
-            val = F::mul(val, a.scale);
-        else if (a.scale_mode == SCALE_SERIES)
-            val = F::mul(val, a.out_pow.get(k));
-        dst[k * W + w] = val;
-    }
-}
 
 // Zero fill (n 16-byte words) -- a kernel rather than hipMemsetAsync: memset nodes of a captured graph were seen to
 // replay wrongly on this ROCm (tests/test_gpu_graph.py), kernels replay as launched.

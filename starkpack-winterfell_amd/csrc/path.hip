@@ -5,6 +5,7 @@
 
 #include "kernels.hpp"
 #include "seg_kernels.hpp"
+#include "col_kernels.hpp"
 #include "fri_kernels.hpp"
 #include "tables.hpp"
 
@@ -64,27 +65,10 @@ static Plan seg_plan(uint32_t logN, uint32_t n_seg, uint32_t digit_cap = 0, bool
     return make_plan(logN, max_digit, !full_tiles && F::BYTES == 8, n_seg <= 8, !full_tiles);
 }
 
-template <class F>
-static uint32_t tile_target(uint32_t W) {  // adjacent elements so that a global chunk is ~64 bytes
-    uint32_t t = 64 / (W * F::BYTES);
-    return t < 1 ? 1 : t;
-}
-
-template <class F>
-static int launch_dims(uint32_t logD, uint32_t V, uint32_t &threads, size_t &lds) {
-    const size_t vals = ((size_t)1 << logD) * V;
-    lds = (vals + ((size_t)1 << logD)) * sizeof(typename F::T);
-    if (lds > 160 * 1024) return fail(WF_ERR_ARG, "internal: pass needs %zu bytes of LDS", lds);
-    threads = vals >= 16384 ? 1024 : (vals >= 8192 ? 512 : 256);
-    if (lds > 64 * 1024) {
-        HIP_TRY(hipFuncSetAttribute((const void *)k_ntt_strided<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_ntt_last<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
-    return 0;
-}
-
-// One transform of a batch of columns in the caller's column layout (the stand-alone math::fft entry points):
-// src = [batch] columns of N elements of W coordinates, dst likewise, natural order, scaled per scale_mode.
+// One transform of a batch of columns in the caller's column layout (the stand-alone math::fft entry points, the offset
+// interpolation of the constraint side, the FRI remainder): src = [batch] columns of N elements of W coordinates, dst
+// likewise, natural order, scaled per scale_mode.  col_kernels.hpp: the lanes of a tile row are adjacent inner positions
+// of the one column, the in-LDS transform is the segment kernels' own.
 template <class F>
 struct XformDesc {
     typedef typename F::T T;
@@ -97,47 +81,57 @@ struct XformDesc {
     const TableSet *out_series;
 };
 
-template <class F>
-static int run_transform(wf_ctx *ctx, hipStream_t st, const XformDesc<F> &d) {
+template <class F, int W>
+static int run_transform_w(wf_ctx *ctx, hipStream_t st, const XformDesc<F> &d) {
     typedef typename F::T T;
+    constexpr uint32_t S = SegCfg<F>::S;
     TableSet *tw;
     int rc = root_tables<F>(ctx, d.logN, d.inverse, &tw);
     if (rc) return rc;
     const Plan plan = make_plan(d.logN, F::BYTES == 8 ? 11 : 10);
     const uint64_t N = (uint64_t)1 << d.logN;
 
-    NttArgs<F> a;
+    ColArgs<F> a;
     memset(&a, 0, sizeof(a));
     a.logN = d.logN;
-    a.W = d.W;
     a.col_elems = N;
     a.tw = as_pow2l<F>(*tw);
     // multi-pass transforms go  src -> scratch (first pass), scratch in place (middle), scratch -> dst (last pass):
     // the last pass scatters to natural order and therefore cannot run in place
     T *scratch = nullptr;
     if (plan.n_pass > 1) {
-        rc = ensure(ctx, ctx->scratch, (size_t)d.batch * N * d.W * sizeof(T));
+        rc = ensure(ctx, ctx->scratch, (size_t)d.batch * N * W * sizeof(T));
         if (rc) return rc;
         scratch = (T *)ctx->scratch.p;
     }
+    auto dims = [&](uint32_t logD, uint32_t &threads, size_t &lds, const void *kern) -> int {
+        const size_t D = (size_t)1 << logD;
+        lds = (D * S + D) * sizeof(T);
+        if (lds > 160 * 1024) return fail(WF_ERR_ARG, "internal: pass needs %zu bytes of LDS", lds);
+        threads = (uint32_t)std::min<size_t>(1024, std::max<size_t>(64, D / 2));
+        if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        return 0;
+    };
+    const uint32_t tl_full = std::max<uint32_t>(1, S / W);  // adjacent positions that fill the S lanes of a tile row
     uint32_t done_bits = 0;
     for (int pi = 0; pi + 1 < plan.n_pass; pi++) {
         a.logD = plan.dig[pi];
         a.O = (uint64_t)1 << done_bits;
         a.I = N >> (done_bits + a.logD);
-        a.Tl = (uint32_t)std::min<uint64_t>(tile_target<F>(d.W), a.I);
-        a.V = a.Tl * d.W;
+        a.Tl = (uint32_t)std::min<uint64_t>(tl_full, a.I);
         a.src = pi == 0 ? d.src : scratch;
         a.dst = scratch;
+        rc = digit_table<F>(ctx, a.logD, d.inverse, &a.digit_tw);
+        if (rc) return rc;
+        const void *kern = d.inverse ? (const void *)k_col_strided<F, W, -1> : (const void *)k_col_strided<F, W, 1>;
         uint32_t threads;
         size_t lds;
-        rc = launch_dims<F>(a.logD, a.V, threads, lds);
-        if (rc) return rc;
+        if ((rc = dims(a.logD, threads, lds, kern))) return rc;
         const uint64_t grid = (uint64_t)d.batch * a.O * (a.I / a.Tl);
         if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
         prof_mark(ctx, st, d.inverse ? "fft.interpolate.strided_pass" : "fft.evaluate.strided_pass");
-        hipLaunchKernelGGL(k_ntt_strided<F>, dim3((uint32_t)grid), dim3(threads), lds, st, a);
-        HIP_TRY(hipGetLastError());
+        void *kargs[] = {&a};
+        HIP_TRY(hipLaunchKernel(kern, dim3((uint32_t)grid), dim3(threads), kargs, lds, st));
         done_bits += a.logD;
     }
     {
@@ -151,22 +145,35 @@ static int run_transform(wf_ctx *ctx, hipStream_t st, const XformDesc<F> &d) {
         a.scale_mode = d.scale_mode;
         a.scale = d.scale;
         if (d.out_series) a.out_pow = as_pow2l<F>(*d.out_series);
-        a.Tl = single ? 1 : std::min<uint32_t>(tile_target<F>(d.W), 1u << plan.dig[0]);
-        a.V = a.Tl * d.W;
+        a.Tl = single ? 1 : std::min<uint32_t>(tl_full, 1u << plan.dig[0]);
         a.src = single ? d.src : scratch;
         a.dst = d.dst;
+        rc = digit_table<F>(ctx, a.logD, d.inverse, &a.digit_tw);
+        if (rc) return rc;
+        const void *kern = d.inverse ? (const void *)k_col_last<F, W, -1> : (const void *)k_col_last<F, W, 1>;
         uint32_t threads;
         size_t lds;
-        rc = launch_dims<F>(a.logD, a.V, threads, lds);
-        if (rc) return rc;
+        if ((rc = dims(a.logD, threads, lds, kern))) return rc;
         const uint64_t grid = (uint64_t)d.batch * (a.O / a.Tl);
         if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
         prof_mark(ctx, st, d.inverse ? "fft.interpolate.last_pass" : "fft.evaluate.last_pass");
-        hipLaunchKernelGGL(k_ntt_last<F>, dim3((uint32_t)grid), dim3(threads), lds, st, a);
-        HIP_TRY(hipGetLastError());
+        void *kargs[] = {&a};
+        HIP_TRY(hipLaunchKernel(kern, dim3((uint32_t)grid), dim3(threads), kargs, lds, st));
         prof_mark(ctx, st, "between_calls");
     }
     return 0;
+}
+
+template <class F>
+static int run_transform(wf_ctx *ctx, hipStream_t st, const XformDesc<F> &d) {
+    switch (d.W) {
+        case 1: return run_transform_w<F, 1>(ctx, st, d);
+        case 2: return run_transform_w<F, 2>(ctx, st, d);
+        case 3:
+            if constexpr (F::FIELD_ID == 1) return run_transform_w<F, 3>(ctx, st, d);
+            [[fallthrough]];
+        default: return fail(WF_ERR_EXTENSION, "unsupported extension degree %u", d.W);
+    }
 }
 
 template <class F>

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import golden_util as G
+from conftest import rand_f128
 
 pytestmark = pytest.mark.gpu
 F64, F128 = 1, 2
@@ -99,3 +100,65 @@ def test_reference_held_known_answers(ctx, orc):
     layer = ctx.fri_layer_commit(F64, 1, np.array(c["values"], dtype=np.uint64), c["N"])
     assert np.asarray(layer["transposed"]).reshape(-1, c["N"]).tolist() == c["expected"], c["where"]
 
+
+
+def test_reference_held_known_answers_division_split_and_base_field(ctx, orc, capi):
+    """The rest of the vectors the reference's own tests hold, through the C ABI (round 4: these were checked on the oracle only).
+      * polynom::syn_div (math/src/polynom/tests.rs:178-207) -> wf_deep_compose: with the trace coefficients zero the DEEP
+        composition polynomial is exactly syn_div(H, 1, z) of the one composition column H (prover/src/composer/mod.rs:168-186:
+        H'(x) = (H(x) - H(z)) / (x - z), the constant dropped with the remainder) -- the reference's dividend, divisor root and
+        quotient, over f128 as in its test;
+      * the composition polynomial's column split (prover/src/constraints/composition_poly.rs:109-123, values 0 .. 4 n - 1 cut
+        into four columns) -> wf_constraint_commit_from_evaluations, at the smallest trace length the reference's TraceInfo
+        admits (8; the literal itself uses 4, which no entry point accepts): coefficients 0 .. 31 evaluated over the constraint
+        evaluation domain by wf_fft_evaluate_poly_with_offset, interpolated back and cut into columns by the device;
+      * the base-field assertions with literal operands (math/src/field/f64/tests.rs:17-86, f128/tests.rs:19-88): products as
+        P(z) of a * x at z = b (wf_evaluate_columns_at, extension degree 1), sums and differences as the two outputs
+        a + b, a - b of a 2-point transform (wf_fft_evaluate_poly: w_2 = -1)."""
+    g = G.load("reference_kat.json")
+    ints = lambda v: [int(x) for x in v]  # noqa: E731
+    n = 8
+    # ---- syn_div through the DEEP composition
+    for c in g["f128_syn_div"]:
+        poly = ints(c["poly"]) + [0] * (n - len(c["poly"]))
+        H = orc.f128_from_ints(poly)
+        rng = np.random.default_rng(1)
+        trace = rand_f128(rng, n)
+        c_trace, _ = ctx.trace_commit_resident(capi.make_params(F128, 1, 3, 1, 1, 1), [trace])
+        c_cons = ctx.constraint_commit_resident(capi.make_params(F128, 1, 3, 1, 1, 1), [H])
+        got = ctx.deep_compose(F128, 1, n, [c_trace], c_cons, orc.f128_from_ints([int(c["b"])]), orc.f128_from_ints([0]),
+                               orc.f128_from_ints([1]))
+        q = orc.f128_to_ints(got)
+        want = ints(c["expected"])
+        assert q[:len(want)] == want and not any(q[len(want):]), c["where"]
+        c_trace.close()
+        c_cons.close()
+    # ---- CompositionPoly::new's split, the literal's pattern at trace length 8
+    c = g["f128_composition_segment"]
+    trace_len, num_cols = 8, c["num_cols"]
+    coeffs = orc.f128_from_ints(list(range(trace_len * num_cols)))
+    p = capi.make_params(F128, 1, 3, 1, num_cols, 1)
+    evals = ctx.fft_evaluate_poly_with_offset(F128, 1, coeffs, 3, 1)   # over the constraint evaluation domain (offset 3)
+    com, cols = ctx.constraint_commit_from_evaluations(p, [evals], want_polys=True)
+    assert [orc.f128_to_ints(col) for col in cols] == [list(range(i * trace_len, (i + 1) * trace_len)) for i in range(num_cols)], c["where"]
+    assert c["expected"] == [list(range(i * 4, (i + 1) * 4)) for i in range(4)]   # (the same pattern as the literal's)
+    com.close()
+    # ---- base-field literals
+    M64, M128 = 2**64 - 2**32 + 1, 2**128 - 45 * 2**40 + 1
+    for field, M, new, val in ((F64, M64, lambda v: orc.f64_new([x % M64 for x in v]),
+                                lambda a: [int(x) for x in orc.f64_as_int(np.asarray(a).reshape(-1))]),
+                               (F128, M128, lambda v: orc.f128_from_ints([x % M128 for x in v]), lambda a: orc.f128_to_ints(a))):
+        def mul(a, b):
+            col = new([0, a, 0, 0, 0, 0, 0, 0])
+            return val(ctx.evaluate_columns_at(field, 1, [col], new([b]), 1))[0]
+
+        def add_sub(a, b):
+            return val(ctx.fft_evaluate_poly(field, 1, new([a, b])))
+
+        t = M - 1
+        assert mul(5, 3) == 15 and mul(t, t) == 1 and mul(t, 2) == M - 2 and mul(t, 4) == M - 4      # tests.rs: mul, overflow cases
+        assert mul((M + 1) // 2, 2) == 1
+        assert mul(0, 12345) == 0 and mul(1, 12345) == 12345                                       # identities
+        assert add_sub(2, 3) == [5, M - 1]
+        assert add_sub(t, 1) == [0, M - 2] and add_sub(t, 2)[0] == 1                                 # add: overflow
+        assert add_sub(5, 3)[1] == 2 and add_sub(3, 5)[1] == M - 2                                   # sub: underflow

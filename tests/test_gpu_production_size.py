@@ -3,8 +3,9 @@ extension constraint evaluation on a 2^22-row trace; rounds so far had compared 
 up to 2^12..2^13).
 
   (i)   Prover::build_constraint_commitment (prover/src/lib.rs:680-715) with E = quadratic extension:
-        2^20 x 4 columns of E in full against the threaded oracle; 2^22 x 4 columns of E (2 GiB of LDE) through the
-        device-buffer form, checked by definition on samples + the whole tree rebuilt by the oracle from the GPU leaves;
+        2^20 x 4 columns of E in full against the threaded oracle; 2^22 x 4 columns of E (cfg 3's constraint side, 2 GiB of
+        LDE) through the device-buffer form: by definition on samples, the whole tree rebuilt by the oracle from the GPU
+        leaves, and (round 4) the whole commitment -- root, nodes, leaves, LDE -- against the threaded oracle;
   (ii)  fft::interpolate_poly_with_offset (math/src/fft/mod.rs:362; ConstraintEvaluationTable::into_comb_poly,
         prover/src/constraints/evaluation_table.rs:166-186) and fft::evaluate_poly_with_offset (mod.rs:171;
         DeepCompositionPoly::evaluate, prover/src/composer/mod.rs:198-205) at 2^21..2^23 -- the 3-pass column-layout
@@ -81,7 +82,31 @@ def test_constraint_commitment_quadratic_2_22_device(ctx, orc, capi):
     for j, row in zip(js, rows):
         assert bytes(lh[j]) == orc.hash_elements(F64, row[:B])
     assert np.array_equal(orc.build_merkle_nodes(lh, threads=THREADS), nodes.cpu().numpy())
-    del lde, lde2, leaves, nodes, polys
+
+    # the WHOLE constraint commitment of cfg 3 against the threaded oracle (Prover::build_constraint_commitment,
+    # prover/src/lib.rs:680-715 restated): root, every node, every leaf and the 2 GiB of LDE -- as the trace side is in
+    # test_gpu_fullsize.py.  ~4 GiB of host memory for the oracle's outputs.
+    import os
+    avail = 0.0
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) / (1 << 20)
+    except OSError:
+        pass
+    if avail < 12:
+        del lde, lde2, leaves, nodes, polys
+        torch.cuda.empty_cache()
+        pytest.skip(f"sampled checks and the tree passed; the full comparison needs ~6 GiB of host memory, MemAvailable is {avail:.0f} GiB")
+    ph = u64(polys).reshape(n_cols, R * ext)
+    threads = min(64, len(os.sched_getaffinity(0)))
+    want = orc.build_constraint_commitment(F64, [ph[c] for c in range(n_cols)], ext, logR, logB, 7, threads=threads)
+    nh = nodes.cpu().numpy()
+    assert bytes(nh[1]) == want["root"], "cfg 3 constraint side: root differs from the oracle's"
+    assert np.array_equal(nh, want["nodes"])
+    assert np.array_equal(lh, want["leaves"])
+    assert np.array_equal(u64(lde2), np.asarray(want["lde"]).reshape(N, 8))
+    del want, ph, nh, lh, lde, lde2, leaves, nodes, polys
     torch.cuda.empty_cache()
 
 
