@@ -219,16 +219,46 @@ def probe(cmd):
         return None
 
 
+def cpu_budget():
+    """What this process may actually use of the host: the CPUs of its affinity mask AND the cgroup's CPU-time quota (a
+    container handed "16 CPUs' worth" of a 128-thread host sees all 128 in its mask; 64 threads on such a quota are throttled
+    by the scheduler, which is what a 15 % parallel efficiency looks like).  Returns (usable_threads, details)."""
+    det = {"os_cpu_count": os.cpu_count()}
+    try:
+        det["affinity"] = len(os.sched_getaffinity(0))
+    except AttributeError:
+        det["affinity"] = os.cpu_count()
+    quota = None
+    try:  # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        det["cgroup_cpu_max"] = f"{q} {per}"
+        if q != "max":
+            quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            det["cgroup_cfs_quota_us"], det["cgroup_cfs_period_us"] = q, per
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            det["cgroup"] = "no cpu controller file readable"
+    det["quota_cpus"] = quota
+    usable = det["affinity"] or 1
+    if quota:
+        usable = max(1, min(usable, int(quota + 0.5)))
+    return usable, det
+
+
 def cpu_baseline(model, wl, traces_host, gpu_root=None, runs=5, warmups=2):
     """Full commitments of the bench workload (the very traces rank 0 committed on the GPU) with the threaded CPU
     oracle -- test infrastructure, used here only as the reported CPU baseline and as a last parity gate.  The C
-    entry point is timed on preallocated, already faulted-in outputs (no Python allocation inside the clock).
-    traces_host: [n_traces][n_cols] arrays.  Phases (ms) and ns per BLAKE3 compression are those of the median run."""
-    threads = min(os.cpu_count() or 1, 64)
-    try:
-        threads = min(threads, len(os.sched_getaffinity(0)))
-    except AttributeError:
-        pass
+    entry point is timed on preallocated outputs that the worker threads themselves faulted in (first touch in the warm-up
+    run, same static partitioning in every run; no Python allocation inside the clock).
+    Thread count: swept once over 8 / 16 / 32 / 64 (up to the affinity mask; the cgroup quota is reported next to it), the
+    count with the best median is the one quoted.  traces_host: [n_traces][n_cols] arrays.  Phases (ms) are those of the
+    median run; efficiency = the phase's compressions at THIS box's measured single-thread rate / threads / the phase."""
+    usable, budget = cpu_budget()
     # libgomp reads these when liboracle.so (first user of the system libgomp in this process) is loaded
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "cores")
@@ -238,42 +268,69 @@ def cpu_baseline(model, wl, traces_host, gpu_root=None, runs=5, warmups=2):
     field = O.F64 if wl["field"] == "f64" else O.F128
     offset = 7 if wl["field"] == "f64" else 3
     data = [[np.ascontiguousarray(c) for c in t] for t in traces_host]
+    N = 1 << (wl["log_r"] + wl["log_b"])
+    leaf_comp = model["compressions"] - (N - 1)
+
+    # this box's single-thread cost of one 2-to-1 hash (the figure the reference publishes, crypto/README.md:69-75)
+    rng = np.random.default_rng(11)
+    probe_leaves = rng.integers(0, 256, size=(1 << 16, 32), dtype=np.uint8)
+    O.build_merkle_nodes(probe_leaves, 1)
+    t0 = time.perf_counter()
+    O.build_merkle_nodes(probe_leaves, 1)
+    ns_single = (time.perf_counter() - t0) * 1e9 / ((1 << 16) - 1)
+
+    def commit(threads, res):
+        t0 = time.perf_counter()
+        res = O.build_trace_commitment(field, data, 1, wl["log_r"], wl["log_b"], offset, threads=threads, out=res)
+        return (time.perf_counter() - t0) * 1e3, O.last_phase_ms(), res
+
+    max_threads = max(1, min(budget["affinity"] or 1, 64))
     res = None
-    times = []
-    for i in range(warmups):  # threads, page cache, output pages
-        t0 = time.perf_counter()
-        res = O.build_trace_commitment(field, data, 1, wl["log_r"], wl["log_b"], offset, threads=threads, out=res)
-        first_ms = (time.perf_counter() - t0) * 1e3
-        if i == 0 and first_ms > 3000.0:  # a slow workload for the CPU: that commitment is the bounded sample
-            times.append((first_ms, O.last_phase_ms()))
-            runs, warmups = 0, 0
-            break
-    for _ in range(runs):
-        t0 = time.perf_counter()
-        res = O.build_trace_commitment(field, data, 1, wl["log_r"], wl["log_b"], offset, threads=threads, out=res)
-        times.append(((time.perf_counter() - t0) * 1e3, O.last_phase_ms()))
+    first_ms, first_phases, res = commit(min(max_threads, max(usable, 8)), res)   # faults the outputs in; sizes the sample
+    sweep = {}
+    if first_ms > 3000.0:  # a slow workload for the CPU (cfg 3): that commitment is the bounded sample
+        best_t = min(max_threads, max(usable, 8))
+        times = [(first_ms, first_phases)]
+        warmups = 0
+    else:
+        cands = sorted({t for t in (8, 16, 32, 64, usable) if 1 <= t <= max_threads} or {max_threads})
+        for t in cands:
+            commit(t, res)  # threads of this count spun up
+            ts = sorted(commit(t, res)[0] for _ in range(2 if first_ms > 300 else 3))
+            sweep[t] = round(ts[len(ts) // 2], 2)
+        best_t = min(sweep, key=sweep.get)
+        for _ in range(warmups):
+            commit(best_t, res)
+        times = [commit(best_t, res)[:2] for _ in range(runs)]
     runs = len(times)
     times.sort(key=lambda x: x[0])
     median, phases = times[len(times) // 2]
     ms = [t for t, _ in times]
-    N = 1 << (wl["log_r"] + wl["log_b"])
-    leaf_comp = model["compressions"] - (N - 1)
+    threads = best_t
     # one thread's time per compression (the phase's wall clock x threads / compressions): comparable with the reference's
     # published single-thread 2-to-1 hash latency -- the tree phase is exactly N - 1 such hashes
     ns_tree = phases[3] * 1e6 * threads / (N - 1)
     ns_leaf = phases[2] * 1e6 * threads / leaf_comp
+    eff = {"merkle": round(ns_single / ns_tree, 3) if ns_tree > 0 else None,
+           "hash_rows": round(ns_single / ns_leaf, 3) if ns_leaf > 0 else None}
     return dict(value=model["field_ops"] / (median * 1e-3), unit="field-ops/s", cores=threads, kind="port",
                 label="C restatement of the reference's concurrent CPU path (oracle/, OpenMP; BLAKE3 compression vectorised as in the "
-                      "blake3 crate's single-compression SSE form) -- not the Rust binary, which cannot be built here",
+                      "blake3 crate's single-compression SSE form; Merkle tree by sub-trees per thread as merkle/concurrent.rs) -- not the "
+                      "Rust binary, which cannot be built here",
                 sample=f"{runs} full commitments ({wl['n_traces']} x 2^{wl['log_r']} x {wl['n_cols']} {wl['field']}, blowup {1 << wl['log_b']}) "
-                       f"after {warmups} warm-ups, outputs preallocated; median {median:.0f} ms, min {ms[0]:.0f} ms",
-                median_ms=median, min_ms=ms[0], max_ms=ms[-1], runs=runs, warmups=warmups,
+                       f"on {threads} threads after {warmups} warm-ups, outputs preallocated and first-touched by the workers; "
+                       f"median {median:.0f} ms, min {ms[0]:.0f} ms",
+                median_ms=median, min_ms=ms[0], max_ms=ms[-1], spread=round((ms[-1] - ms[0]) / median, 3), runs=runs, warmups=warmups,
+                cpu_budget=budget, threads_usable=usable,
+                thread_sweep_median_ms=sweep or None,
                 phase_ms={"interpolate": round(phases[0], 2), "evaluate": round(phases[1], 2), "hash_rows": round(phases[2], 2),
                           "merkle": round(phases[3], 2)},
-                ns_per_compression={"merkle_2_to_1": round(ns_tree, 1), "leaf_rows": round(ns_leaf, 1), "threads": threads,
+                ns_per_compression={"single_thread_measured_here": round(ns_single, 1), "merkle_2_to_1": round(ns_tree, 1),
+                                    "leaf_rows": round(ns_leaf, 1), "threads": threads,
+                                    "parallel_efficiency": eff,
                                     "reference_published_2_to_1_ns": "62-106 (single thread; /root/reference/crypto/README.md:69-75)",
-                                    "note": "wall clock of the phase x threads / compressions: an upper bound on the per-thread cost "
-                                            "(includes imbalance and memory stalls of the 64-thread run)"},
+                                    "note": "phase wall clock x threads / compressions: an upper bound on the per-thread cost (includes "
+                                            "imbalance and memory stalls); efficiency = single-thread ns measured in this run / that"},
                 cpu_model=cpu_model(), threads_pinned=os.environ.get("OMP_PROC_BIND") == "close",
                 omp_places=os.environ.get("OMP_PLACES"), root=res["root"].hex(),
                 root_matches_gpu=(None if gpu_root is None else res["root"].hex() == gpu_root),

@@ -202,7 +202,10 @@ void orc_merge_with_int(const uint8_t *seed, uint64_t value, uint8_t *out) {
     hash_trunc(buf, g_db + 8, out);
 }
 
-/* build_merkle_nodes, crypto/src/merkle/mod.rs:350-374 (threads<=1) and merkle/concurrent.rs:21-70 (threads>1).
+/* build_merkle_nodes, crypto/src/merkle/mod.rs:350-374 (threads<=1) and merkle/concurrent.rs:21-70 (threads>1: the first
+ * row of internal nodes in parallel, then one SUB-TREE per batch -- num_subtrees = threads.next_power_of_two() -- each walked
+ * from its widest level to its sub-root by one thread (:44-62), then the tip of the tree serially (:65-67); below
+ * MIN_CONCURRENT_LEAVES = 1024 leaves the reference takes the serial form, merkle/mod.rs:126-130).
  * nodes has n_leaves digests: nodes[0] = zero digest, nodes[1] = root. */
 int orc_build_merkle_nodes(const uint8_t *leaves, size_t n_leaves, uint8_t *nodes, int threads) {
     if (n_leaves < 2) return -1;                    /* merkle/mod.rs:118-120 */
@@ -210,13 +213,26 @@ int orc_build_merkle_nodes(const uint8_t *leaves, size_t n_leaves, uint8_t *node
     size_t n = n_leaves / 2;
     const size_t db = g_db; /* two adjacent digests ARE the merge input (merkle/mod.rs:350-374: merge(&[l, r])) */
     memset(nodes, 0, db);
-#pragma omp parallel for num_threads(threads) schedule(static) if (threads > 1 && n > 512)
-    for (size_t i = 0; i < n; i++) hash_trunc(leaves + 2 * db * i, 2 * db, nodes + db * (n + i));
-    /* levels above: level with first index `lo` has `lo` nodes; children are already final */
-    for (size_t lo = n / 2; lo >= 1; lo /= 2) {
-#pragma omp parallel for num_threads(threads) schedule(static) if (threads > 1 && lo > 512)
-        for (size_t i = lo; i < 2 * lo; i++) hash_trunc(nodes + 2 * db * i, 2 * db, nodes + db * i);
+    size_t num_subtrees = 1;
+    while (num_subtrees < (size_t)(threads > 1 ? threads : 1)) num_subtrees *= 2;
+    if (threads <= 1 || n_leaves < 1024 || n / num_subtrees < 2) {
+        for (size_t i = 0; i < n; i++) hash_trunc(leaves + 2 * db * i, 2 * db, nodes + db * (n + i));
+        for (size_t i = n - 1; i >= 1; i--) hash_trunc(nodes + 2 * db * i, 2 * db, nodes + db * i);
+        return 0;
     }
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (size_t i = 0; i < n; i++) hash_trunc(leaves + 2 * db * i, 2 * db, nodes + db * (n + i));
+    const size_t batch0 = n / num_subtrees;
+#pragma omp parallel for num_threads(threads) schedule(static, 1)
+    for (size_t s = 0; s < num_subtrees; s++) {
+        size_t batch = batch0 / 2, start = n / 2 + batch * s;
+        while (start >= num_subtrees) {
+            for (size_t k = start + batch; k-- > start;) hash_trunc(nodes + 2 * db * k, 2 * db, nodes + db * k);
+            start /= 2;
+            batch /= 2;
+        }
+    }
+    for (size_t i = num_subtrees - 1; i >= 1; i--) hash_trunc(nodes + 2 * db * i, 2 * db, nodes + db * i);
     return 0;
 }
 

@@ -357,7 +357,26 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
                 default: break;
             }
         }
-        if (kern) {
+        // transforms of three and more passes: their small tiles (2^7 / 2^8 rows) go two adjacent inner positions at a time --
+        // tile rows of 128 contiguous bytes (k_seg_strided_wide: cfg 3 35.5 -> 33.9 ms; 4 and 8 positions measured slower)
+        uint32_t ti = 0;
+        if (F::BYTES == 8 && !packed && plan.n_pass >= 3 && a.logD >= 4 && a.logD <= 8 && ctx->tune.wide_ti != 1) {
+            ti = ctx->tune.wide_ti ? ctx->tune.wide_ti : 2u;
+            while (ti > 1 && (ti > a.I || ((size_t)(ti * SegCfg<F>::S + 2 + ti) << a.logD) * sizeof(T) > 80 * 1024)) ti >>= 1;
+            if (ti < 2 || ((1u << a.logD) * ti * SegCfg<F>::S) / 16 < 64) ti = 0;
+        }
+        if (ti) {
+            if constexpr (F::BYTES == 8) {
+                const void *kw = ti == 8 ? (d.rows_out ? (const void *)k_seg_strided_wide<F, 1, 8> : (const void *)k_seg_strided_wide<F, 0, 8>)
+                               : ti == 4 ? (d.rows_out ? (const void *)k_seg_strided_wide<F, 1, 4> : (const void *)k_seg_strided_wide<F, 0, 4>)
+                                         : (d.rows_out ? (const void *)k_seg_strided_wide<F, 1, 2> : (const void *)k_seg_strided_wide<F, 0, 2>);
+                const size_t lds_w = ((size_t)(ti * SegCfg<F>::S + 2 + ti) << a.logD) * sizeof(T);
+                const uint32_t threads_w = ((1u << a.logD) * ti * SegCfg<F>::S) / 16;
+                if (lds_w > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                void *kargs[] = {&a};
+                HIP_TRY(hipLaunchKernel(kw, dim3((uint32_t)(grid / ti)), dim3(threads_w), kargs, lds_w, st));
+            }
+        } else if (kern) {
             void *kargs[] = {&a};
             HIP_TRY(hipLaunchKernel(kern, dim3((uint32_t)grid), dim3(threads), kargs, lds, st));
         } else if (d.rows_out && packed)

@@ -114,6 +114,7 @@ __device__ __forceinline__ uint64_t xcd_group_index(uint64_t b, uint64_t total) 
 // otherwise (grids are below 2^31): a 64-bit division by a run-time value costs ~80 VALU instructions on this target,
 // and the prologue of a tile is paid by every thread.
 __device__ __forceinline__ uint32_t ilog2_pow2(uint64_t v) { return 63u - (uint32_t)__builtin_clzll(v); }
+__host__ __device__ constexpr uint32_t ilog2_const(uint32_t v) { return v <= 1 ? 0 : 1 + ilog2_const(v >> 1); }
 
 template <class F>
 struct SegArgs {
@@ -319,13 +320,15 @@ __device__ __forceinline__ void radix16_shift_tw(typename F::T (&v)[16], const t
 // `nthr` = blockDim.x, passed in so that the tile-size-specialised kernels (LOGD != 0, below) make it a constant.
 // One radix-16 round of seg_lds_ntt at `cur` remaining bits (no trailing barrier): work item wk = lane wk % S of the
 // 16 rows base + a * 2^(cur-4), a = 0..15.  w16[j] = w_16^j.
-template <class F, int DIR, bool UNI = false>
+// LANES: elements per tile row -- the S lanes of a segment row, or TI * S when a tile holds TI adjacent inner positions
+// side by side (k_seg_strided_wide); the lanes of a row share every twiddle either way.
+template <class F, int DIR, bool UNI = false, uint32_t LANES = SegCfg<F>::S>
 __device__ __forceinline__ void seg_round16(typename F::T *x, const typename F::T *twd, const typename F::T (&w16)[8],
                                             uint32_t logD, uint32_t cur, uint32_t nthr, const typename F::T *first,
                                             uint32_t tid, bool use_first) {  // tid: threadIdx.x; first: read only if use_first
     typedef typename F::T T;
-    constexpr uint32_t S = SegCfg<F>::S;
-    constexpr uint32_t s_shift = S == 8 ? 3 : 2;
+    constexpr uint32_t S = LANES;
+    constexpr uint32_t s_shift = ilog2_const(S);
     const uint32_t D = 1u << logD;
     const uint32_t mlog = cur - 4, m = 1u << mlog;
     const uint32_t nwork = (D >> 4) * S;
@@ -338,7 +341,7 @@ __device__ __forceinline__ void seg_round16(typename F::T *x, const typename F::
     // compile-time constants.
     // UNI: only from seg_lds_fixed (logD and cur compile-time constants there; as a run-time branch of the generic round
     // loop the extra paths cost every kernel registers).
-    constexpr bool SHIFT_TW = UNI && F::FIELD_ID == 1 && DIR != 0 && SegCfg<F>::S == 8;
+    constexpr bool SHIFT_TW = UNI && F::FIELD_ID == 1 && DIR != 0 && LANES == 8;
     const bool uni = SHIFT_TW && ((logD == 10 && cur == 6) || (logD == 9 && cur == 5));
     for (uint32_t wk = tid; wk < nwork; wk += nthr) {
         const uint32_t l = wk & (S - 1), u = wk >> s_shift;
@@ -403,13 +406,13 @@ __device__ __forceinline__ typename F::T mul_w4(typename F::T u, typename F::T t
 }
 
 // One radix-4 round (two lanes per work item, 16-byte LDS accesses for f64); w4 = w_4.
-template <class F, int DIR = 0, bool UNI = false>
+template <class F, int DIR = 0, bool UNI = false, uint32_t LANES = SegCfg<F>::S>
 __device__ __forceinline__ void seg_round4(typename F::T *x, const typename F::T *twd, typename F::T w4, uint32_t logD,
                                            uint32_t cur, uint32_t nthr, uint32_t tid) {
     typedef typename F::T T;
     typedef Pair<T> P2;
-    constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;
-    constexpr uint32_t hp_shift = HP == 4 ? 2 : 1;
+    constexpr uint32_t S = LANES, HP = LANES / 2;
+    constexpr uint32_t hp_shift = ilog2_const(HP);
     const uint32_t D = 1u << logD;
     const uint32_t mlog = cur - 2, m = 1u << mlog;
     const uint32_t nwork = (D >> 2) * HP;
@@ -483,12 +486,12 @@ __device__ __forceinline__ void seg_round4(typename F::T *x, const typename F::T
     }
 }
 
-template <class F>
+template <class F, uint32_t LANES = SegCfg<F>::S>
 __device__ __forceinline__ void seg_round2(typename F::T *x, uint32_t logD, uint32_t nthr, uint32_t tid) {
     typedef typename F::T T;
     typedef Pair<T> P2;
-    constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP;
-    constexpr uint32_t hp_shift = HP == 4 ? 2 : 1;
+    constexpr uint32_t S = LANES, HP = LANES / 2;
+    constexpr uint32_t hp_shift = ilog2_const(HP);
     const uint32_t nwork = (1u << (logD - 1)) * HP;
     for (uint32_t wk = tid; wk < nwork; wk += nthr) {
         const uint32_t lp = wk & (HP - 1), u = wk >> hp_shift;
@@ -515,7 +518,7 @@ __device__ __forceinline__ uint32_t opaque_tid() {
 
 // The rounds of a tile of 2^LOGD rows with every size a compile-time constant: what the Goldilocks tiles with power-of-two
 // inter-round twiddles run (2^10 and 2^9 rows: after the second radix-16 round; 2^7 and 2^11: in the radix-4 round).
-template <class F, int DIR, int LOGD, int CUR>
+template <class F, int DIR, int LOGD, int CUR, uint32_t LANES = SegCfg<F>::S>
 __device__ __forceinline__ void seg_lds_fixed(typename F::T *x, const typename F::T *twd, const typename F::T (&w16)[8],
                                               typename F::T w4, uint32_t nthr, const typename F::T *first, bool use_first,
                                               bool opaque) {
@@ -523,15 +526,15 @@ __device__ __forceinline__ void seg_lds_fixed(typename F::T *x, const typename F
     // out of the kernel's tile loop and held in registers across it
     const uint32_t tid = opaque ? opaque_tid() : threadIdx.x;
     if constexpr (SegCfg<F>::RADIX16 && CUR >= 4) {
-        seg_round16<F, DIR, true>(x, twd, w16, LOGD, CUR, nthr, first, tid, use_first && CUR == LOGD);
+        seg_round16<F, DIR, true, LANES>(x, twd, w16, LOGD, CUR, nthr, first, tid, use_first && CUR == LOGD);
         __syncthreads();
-        seg_lds_fixed<F, DIR, LOGD, CUR - 4>(x, twd, w16, w4, nthr, first, false, opaque);
+        seg_lds_fixed<F, DIR, LOGD, CUR - 4, LANES>(x, twd, w16, w4, nthr, first, false, opaque);
     } else if constexpr (CUR >= 2) {
-        seg_round4<F, DIR, true>(x, twd, w4, LOGD, CUR, nthr, tid);
+        seg_round4<F, DIR, true, LANES>(x, twd, w4, LOGD, CUR, nthr, tid);
         __syncthreads();
-        seg_lds_fixed<F, DIR, LOGD, CUR - 2>(x, twd, w16, w4, nthr, first, false, opaque);
+        seg_lds_fixed<F, DIR, LOGD, CUR - 2, LANES>(x, twd, w16, w4, nthr, first, false, opaque);
     } else if constexpr (CUR == 1) {
-        seg_round2<F>(x, LOGD, nthr, tid);
+        seg_round2<F, LANES>(x, LOGD, nthr, tid);
         __syncthreads();
     }
 }
@@ -542,7 +545,7 @@ __device__ __forceinline__ void seg_lds_fixed(typename F::T *x, const typename F
 constexpr uint32_t FIX10 = 1u << 10, FIX7 = 1u << 7, FIX9 = 1u << 9, FIX11 = 1u << 11;
 constexpr uint32_t FIX_BIG = FIX10 | FIX11;   // the fused last pass on tiles of 2^10 / 2^11 rows
 constexpr uint32_t FIX_LAST = FIX10 | FIX9;   // the one-work-group-per-tile last pass
-template <class F, int DIR = 0, uint32_t FIXMASK = FIX10>
+template <class F, int DIR = 0, uint32_t FIXMASK = FIX10, uint32_t LANES = SegCfg<F>::S>
 __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::T *twd, uint32_t logD, uint32_t nthr,
                                             const typename F::T *first = nullptr, bool use_first = false,
                                             bool opaque = false) {
@@ -556,7 +559,7 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
 #define WF_FIXED_SIZE(L)                                                                                        \
     if constexpr ((fixmask & (1u << (L))) != 0) {                                                               \
         if (logD == (L)) { /* uniform */                                                                        \
-            seg_lds_fixed<F, DIR, (L), (L)>(x, twd, w16, F::zero(), nthr, first, use_first, opaque);       \
+            seg_lds_fixed<F, DIR, (L), (L), LANES>(x, twd, w16, F::zero(), nthr, first, use_first, opaque);       \
             return;                                                                                             \
         }                                                                                                       \
     }
@@ -573,7 +576,7 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
 #pragma unroll
         for (int j = 0; j < 8; j++) w16[j] = twd[j * (D >> 4)];
         while (cur >= 4) {
-            seg_round16<F, DIR>(x, twd, w16, logD, cur, nthr, first, threadIdx.x, use_first && cur == logD);
+            seg_round16<F, DIR, false, LANES>(x, twd, w16, logD, cur, nthr, first, threadIdx.x, use_first && cur == logD);
             cur -= 4;
             __syncthreads();
         }
@@ -582,10 +585,10 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
     if (logD >= 2) w4 = twd[D >> 2];
     while (cur > 0) {
         if (cur >= 2) {
-            seg_round4<F, DIR>(x, twd, w4, logD, cur, nthr, threadIdx.x);
+            seg_round4<F, DIR, false, LANES>(x, twd, w4, logD, cur, nthr, threadIdx.x);
             cur -= 2;
         } else {
-            seg_round2<F>(x, logD, nthr, threadIdx.x);
+            seg_round2<F, LANES>(x, logD, nthr, threadIdx.x);
             cur = 0;
         }
         __syncthreads();
@@ -850,6 +853,135 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_strided(SegArgs<F> a) {
         if (*reinterpret_cast<const uint32_t *>(&v.a) == a.logN + 77777u)
 #endif
         store_pair(dst_lane + ((uint64_t)k << k_shift), v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Strided pass on WIDE tiles (f64, transforms of three and more passes: 2^22 rows and up).  The small digits of those plans
+// (2^7 / 2^8 rows) make k_seg_strided's tiles 8-16 KiB of isolated 64-byte gathers by one or two waves, and the pass is bound
+// by memory, not by the vector ALU (cfg 3: the pass takes the same 9.3 ms with its transform compiled out, 6.8 ms with its
+// memory accesses compiled out; profiles/r04_attribution.txt).  Here one work-group takes TI ADJACENT inner positions
+// i0 .. i0 + TI - 1 of (coset, segment, outer): a tile row is TI x 64 contiguous bytes -- whole 128-byte lines from TI = 2 --
+// and the TI x S lanes of a row share the digit transform's twiddles (seg_lds_ntt with LANES = TI * S: the tile is a
+// (2^7 rows) x (16 lanes) transform); only the output factor start_i * w_N^(k i N / (D I)) depends on the inner position:
+// a table of TI x D entries, two per thread as in k_seg_strided.  Measured on cfg 3 (same box, interleaved): TI = 2 takes
+// the two strided evaluation passes 9.28 -> 8.71 ms each and the commitment 35.5 -> 33.9 ms; TI = 4 and 8 (64 KiB tiles,
+// two work-groups per CU) give 9.0-9.2 and 9.1 ms.
+// grid.x = n_cosets * n_seg * O * (I / TI); blockDim = D * TI * S / 16 (one radix-16 work item per thread).
+template <class F, int EVAL, int TI>
+__global__ void __launch_bounds__(1024) k_seg_strided_wide(SegArgs<F> a) {
+    static_assert(SegCfg<F>::RADIX16 && TI >= 2 && (TI & (TI - 1)) == 0, "f64 tiles of 2, 4 or 8 inner positions");
+    typedef typename F::T T;
+    typedef Pair<T> P2;
+    constexpr uint32_t S = SegCfg<F>::S, LANES = TI * S, HPW = LANES / 2;
+    constexpr uint32_t LOGS = ilog2_const(S), LOGL = ilog2_const(LANES), LOGTI = ilog2_const(TI), LOGHPW = ilog2_const(HPW);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const uint32_t D = 1u << a.logD, NT = blockDim.x;
+    T *x = reinterpret_cast<T *>(smem_raw);
+    T *twd = x + (size_t)D * LANES;
+    T *fin = twd + D;    // h_c^(d I): factors of the input rows (first pass of a coset evaluation)
+    T *fout = fin + D;   // [TI][D]: factors of the output rows
+
+    const uint64_t bid = xcd_group_index(blockIdx.x, gridDim.x);  // 8 neighbouring tiles (8 * TI * 64 contiguous bytes per row) on one XCD
+    const uint32_t logI = ilog2_pow2(a.I), logO = ilog2_pow2(a.O), logIt = logI - LOGTI;
+    const uint64_t i0 = (bid & ((a.I >> LOGTI) - 1)) << LOGTI;
+    const uint64_t o = (bid >> logIt) & (a.O - 1);
+    const uint32_t rest = (uint32_t)(bid >> (logIt + logO));
+    const uint32_t c = rest / a.n_seg, g = rest - c * a.n_seg;
+    const uint64_t seg_elems = ((uint64_t)1 << a.logN) * S;
+    const T *src = a.src + (a.src_shared ? (uint64_t)g : (uint64_t)c * a.seg_stride + g) * seg_elems;
+    T *dst = a.dst + ((uint64_t)c * a.seg_stride + g) * seg_elems;
+    Pow2L<F> pre = a.pre;
+    const bool scale_in = a.pre_on != 0;
+    if (scale_in) {
+        pre.lo += (uint64_t)(a.coset0 + c) * a.pre_lo_stride;
+        pre.hi += (uint64_t)(a.coset0 + c) * a.pre_hi_stride;
+    }
+    const uint64_t row0 = ((o << a.logD) << logI) + i0;  // row of d = 0, inner position i0; rows of the tile are I apart
+    const uint32_t tw_shift = a.logN - a.logD - logI;
+    const uint32_t tid = threadIdx.x;
+
+    // prologue: every global read of the tile's setup is issued before the first one is used (as in k_seg_strided)
+    const Pow2L<F> pst = scale_in ? pre : a.tw;  // (without input scaling these reads go to the root table and are dropped)
+    T fo_a[2], fo_b[2], st_a[2], st_b[2];
+#pragma unroll
+    for (uint32_t q = 0; q < 2; q++) {  // TI * D = 2 NT table entries: entry e = ti * D + k
+        const uint32_t e = tid + q * NT, k = e & (D - 1), ti = e >> a.logD;
+        const uint64_t i = i0 + ti;
+        a.tw.fetch(((uint64_t)k * i) << tw_shift, fo_a[q], fo_b[q]);
+        pst.fetch(i, st_a[q], st_b[q]);
+    }
+    const bool has_d = tid < D;  // (NT = D * TI / 2 >= D)
+    const uint32_t kd = has_d ? tid : 0;
+    const T twv = a.digit_tw[kd];
+    T fi_a, fi_b;
+    pst.fetch((uint64_t)kd << logI, fi_a, fi_b);
+    // the thread's radix-16 work item straight from global memory: lane tid % LANES of rows a * D/16 + tid / LANES
+    const uint32_t m16 = D >> 4, l16 = tid & (LANES - 1), j16 = tid >> LOGL;
+    T vr[16];
+    {
+        const T *pr = src + (row0 + ((uint64_t)j16 << logI)) * S + l16;
+        const uint64_t rstep = ((uint64_t)m16 << logI) * S;
+#pragma unroll
+        for (uint32_t q = 0; q < 16; q++) {
+#ifdef WF_EXP_SKIP_LOAD
+            vr[q] = src[l16];
+#elif defined(WF_TMP_WIDE_NT)
+            vr[q] = __builtin_nontemporal_load(pr);
+#else
+            vr[q] = *pr;
+#endif
+            pr += rstep;
+        }
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < 2; q++) {
+        T f = F::mul(fo_a[q], fo_b[q]);
+        if (scale_in)
+            f = F::mul(f, F::mul(st_a[q], st_b[q]));  // h_c^i rides on the output factors
+        else if (a.scale_on)
+            f = F::mul(f, a.scale);                    // 1/n of an interpolation
+        fout[tid + q * NT] = f;
+    }
+    if (has_d) {
+        twd[kd] = twv;
+        if (scale_in) fin[kd] = F::mul(fi_a, fi_b);
+    }
+    __syncthreads();
+    if (scale_in) {
+#pragma unroll
+        for (uint32_t q = 0; q < 16; q++) vr[q] = F::mul(vr[q], fin[q * m16 + j16]);
+    }
+#ifndef WF_EXP_SKIP_NTT
+    seg_lds_ntt<F, EVAL ? 1 : -1, 0u, LANES>(x, twd, a.logD, NT, vr, true);
+#else
+#pragma unroll
+    for (uint32_t q = 0; q < 16; q++) x[(q * m16 + j16) * LANES + l16] = vr[q];
+    __syncthreads();
+#endif
+    // store: this thread's lane pair of row positions pos0 + j * pstride (rev(pos) = rev(pos0) | rev(j * pstride))
+    const uint32_t pstride = NT >> LOGHPW, pos0 = tid >> LOGHPW, prw = tid & (HPW - 1);
+    const uint32_t k0 = seg_digit_reverse<F>(pos0, a.logD);
+    const T *fo = fout + (((2 * prw) >> LOGS) << a.logD);
+    T *dst_lane = dst + row0 * S + 2 * prw;
+    const uint32_t k_shift = logI + LOGS;  // output rows k are I apart
+    for (uint32_t pj = 0; pj < D; pj += pstride) {
+        const uint32_t k = k0 | seg_digit_reverse<F>(pj, a.logD);
+        P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * LANES + 2 * prw);
+        const T f = fo[k];
+        v.a = F::mul(v.a, f);
+        v.b = F::mul(v.b, f);
+#ifdef WF_EXP_SKIP_STORE
+        if (*reinterpret_cast<const uint32_t *>(&v.a) == a.logN + 77777u)
+#endif
+#ifdef WF_TMP_WIDE_NT
+        {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(&v), reinterpret_cast<u32x4 *>(dst_lane + ((uint64_t)k << k_shift)));
+        }
+#else
+        store_pair(dst_lane + ((uint64_t)k << k_shift), v);
+#endif
     }
 }
 

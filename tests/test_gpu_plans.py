@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-PARITY_SWITCHES = ["WF_EXP_MAX_DIGIT=5", "WF_EXP_MAX_DIGIT=7", "WF_EXP_NO_FUSED_HASH=1",
+PARITY_SWITCHES = ["WF_EXP_MAX_DIGIT=5", "WF_EXP_MAX_DIGIT=7", "WF_EXP_MAX_DIGIT=5 WF_EXP_WIDE_TI=8", "WF_EXP_MAX_DIGIT=7 WF_EXP_WIDE_TI=1", "WF_EXP_NO_FUSED_HASH=1",
                    "WF_EXP_NO_PERSISTENT=1", "WF_EXP_NO_CHUNKED=1", "WF_EXP_PERSISTENT_ALWAYS=1", "WF_EXP_NO_SPECIALIZED=1"]
 PARITY_FILES = ["test_gpu_coset_shard.py", "test_gpu_parity.py", "test_gpu_golden.py"]
 RESIDENT_SWITCHES = ["WF_EXP_PIPELINE_MIN_BYTES=0", "WF_EXP_PIPELINE_MIN_BYTES=0 WF_EXP_MAX_DIGIT=5", "WF_EXP_NO_PIPELINE=1"]
