@@ -305,9 +305,29 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
     const char *tag_s = d.rows_out ? "evaluate.strided_pass" : "interpolate.strided_pass";
     const char *tag_l = d.rows_out ? "evaluate.last_pass" : "interpolate.last_pass";
 
-    const uint32_t run_cnt = d.seg_cnt ? d.seg_cnt : d.n_seg;
+    // Tail packing (k_seg_last_hash_tp): one trace of several segments whose last segment is at most half full, in the shapes
+    // that take the fused persistent last pass anyway -- the tail segment is evaluated coset-packed (two cosets per tile row:
+    // launch B of every strided pass, the PACKED instantiation) and finished by one tail tile per coset pair in the last pass.
+    constexpr uint32_t S_ = SegCfg<F>::S;
+    const uint32_t nf = d.n_seg - 1, tail_cols = d.total_base_cols - nf * S_;
+    bool tailpack = false;
+    if (d.rows_out && !packed && d.phase == 0 && d.n_seg >= 2 && d.n_seg <= 16 && d.total_base_cols == d.base_cols &&
+        tail_cols >= 1 && tail_cols * 2 <= S_ && d.n_cosets % 2 == 0 && plan.n_pass >= 2 && d.leaves && !ctx->tune.no_fused_hash &&
+        !ctx->tune.no_persistent && !ctx->tune.no_tail_pack) {
+        const uint32_t logDl = plan.dig[plan.n_pass - 1];
+        const uint64_t tickets_tp = (uint64_t)(d.n_cosets / 2) << (d.logN - logDl);
+        const uint64_t launch_rows = (uint64_t)d.n_cosets << d.logN;
+        // measured (profiles/r04_tail_pack.txt): f128 -3 .. -8 % on every shape tried; f64 -3 % with 2^9 / 2^10-row last tiles, +4 %
+        // with the 2^7-row tiles of the 2^22 plan (their specialised instantiation exists for the unpacked kernel only)
+        tailpack = logDl >= (ctx->tune.persistent_always || F::BYTES == 16 ? 7u : 9u) && logDl <= 10 && tickets_tp % 8 == 0 &&
+                   tickets_tp < (1ull << 31) &&
+                   (ctx->tune.persistent_always || launch_rows >= (1ull << 20));  // (as the ticket kernel's own rule for one trace)
+    }
+    T *work_tail = tailpack ? d.work + (size_t)d.n_cosets * nf * N * S_ : nullptr;  // [coset pair][N][S] behind the full segments
+
+    const uint32_t run_cnt = tailpack ? nf : (d.seg_cnt ? d.seg_cnt : d.n_seg);
     const size_t run_off = (size_t)d.seg0 * (N * SegCfg<F>::S);  // elements in front of segment seg0 within one coset
-    a.seg_stride = d.n_seg;
+    a.seg_stride = tailpack ? nf : d.n_seg;
     uint32_t done_bits = 0;
     for (int pi = 0; pi + 1 < plan.n_pass; pi++) {
         if (d.phase == 2) {  // strided passes already run
@@ -386,9 +406,25 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         else
             hipLaunchKernelGGL((k_seg_strided<F, 0>), dim3((uint32_t)grid), dim3(threads), lds, st, a);
         HIP_TRY(hipGetLastError());
+        if (tailpack) {  // launch B: the tail segment, two cosets per tile row
+            SegArgs<F> b = a;
+            b.src = first ? d.in + (size_t)nf * N * S_ : work_tail;
+            b.dst = work_tail;
+            b.src_shared = first ? 1 : 0;
+            b.n_seg = 1;
+            b.seg_stride = 1;
+            b.n_cosets = d.n_cosets / 2;
+            b.cpr_log = 1;
+            b.lg_log = S_ == 8 ? 2 : 1;
+            b.base_cols = b.total_base_cols = tail_cols;
+            const uint64_t grid_b = (uint64_t)(d.n_cosets / 2) * a.O * a.I;
+            hipLaunchKernelGGL((k_seg_strided<F, 1, true>), dim3((uint32_t)grid_b), dim3(threads), lds, st, b);
+            HIP_TRY(hipGetLastError());
+        }
         done_bits += a.logD;
     }
     a.n_seg = d.n_seg;
+    a.seg_stride = d.n_seg;
     if (d.phase == 1) return 0;
     {
         const int pi = plan.n_pass - 1;
@@ -443,7 +479,31 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         a.hash_epr = d.hash_epr;
         if (d.fused) *d.fused = fuse;
         prof_mark(ctx, st, tag_l);
-        if (persistent) {
+        if (tailpack) {
+            const bool small = threads <= 256;
+            const void *kern = small ? (const void *)k_seg_last_hash_tp<F, true> : (const void *)k_seg_last_hash_tp<F, false>;
+            if (!ctx->tune.no_specialized) {
+                if (a.logD == 9 && small) kern = (const void *)k_seg_last_hash_tp<F, true, 9>;
+                if (F::BYTES == 8 && a.logD == 10 && !small) kern = (const void *)k_seg_last_hash_tp<F, false, F::BYTES == 8 ? 10 : 0>;
+            }
+            a.src = d.work;
+            a.src_tail = work_tail;
+            a.tail_cols = tail_cols;
+            a.store_cols = a.total_store_cols = d.base_cols;  // (the tail tile writes the rows' zero padding itself)
+            a.tail_pad = 0;
+            a.pad_traces = 0;
+            a.leaves = (uint32_t *)d.leaves;
+            a.hash_epr = d.hash_epr;
+            if (d.fused) *d.fused = true;
+            if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            const uint64_t tickets_tp = (uint64_t)(d.n_cosets / 2) * a.O;
+            const uint64_t resident = (uint64_t)ctx->num_cus * std::max<size_t>(1, (160 * 1024) / lds);
+            int rcq = ensure_tickets(ctx, st);
+            if (rcq) return rcq;
+            a.tile_counters = (uint32_t *)ctx->tickets.p;
+            void *kargs[] = {&a};
+            HIP_TRY(hipLaunchKernel(kern, dim3((uint32_t)std::min<uint64_t>(tickets_tp, resident)), dim3(threads), kargs, lds, st));
+        } else if (persistent) {
             const bool multi = d.n_seg > 1 || d.total_base_cols != d.base_cols;
             const bool small = threads <= 256;  // the multi-segment variants without the 128-VGPR cap (2^22 x 64: last pass -3 %)
             const void *kern =

@@ -162,6 +162,8 @@ struct SegArgs {
     uint32_t *chunk_cvs;       // k_seg_last_hash<.., CHUNKED>: [LDE row][n_chunks][8] chunk chaining values (rows > 1024 bytes)
     uint32_t n_chunks;         //   ceil(n_seg / 16): a BLAKE3 chunk is 16 blocks = 16 segments of a row
     uint32_t *tile_counters;   // k_seg_last_hash: 8 ticket + 8 exit counters, one per XCD, zero between launches (self-resetting)
+    const T *src_tail;         // k_seg_last_hash_tp: the coset-packed tail segment's work buffer [coset pair][N][S]
+    uint32_t tail_cols;        //   base columns in the tail segment (<= S / 2)
 #ifdef WF_EXP_STAMPS
     unsigned long long *stamps;  // diagnostic build only: per work-group phase cycle sums of k_seg_last_hash (8 words each)
 #endif
@@ -926,8 +928,6 @@ __global__ void __launch_bounds__(1024) k_seg_strided_wide(SegArgs<F> a) {
         for (uint32_t q = 0; q < 16; q++) {
 #ifdef WF_EXP_SKIP_LOAD
             vr[q] = src[l16];
-#elif defined(WF_TMP_WIDE_NT)
-            vr[q] = __builtin_nontemporal_load(pr);
 #else
             vr[q] = *pr;
 #endif
@@ -974,14 +974,7 @@ __global__ void __launch_bounds__(1024) k_seg_strided_wide(SegArgs<F> a) {
 #ifdef WF_EXP_SKIP_STORE
         if (*reinterpret_cast<const uint32_t *>(&v.a) == a.logN + 77777u)
 #endif
-#ifdef WF_TMP_WIDE_NT
-        {
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(&v), reinterpret_cast<u32x4 *>(dst_lane + ((uint64_t)k << k_shift)));
-        }
-#else
         store_pair(dst_lane + ((uint64_t)k << k_shift), v);
-#endif
     }
 }
 
@@ -1693,6 +1686,265 @@ __global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : 1024) k_seg_last_hash(SegArgs
 
 #undef WF_TILE_LOAD
 #undef WF_STAMP
+
+// ---------------------------------------------------------------------------------------------------------------
+// The fused persistent last pass for ONE trace whose last segment is at most half full (f128: 9, 10, 13, 14 .. columns; f64:
+// 9 .. 12, 17 .. 20 ..): the tail segment's lanes would be transformed half empty in every coset.  Instead the tail is
+// COSET-PACKED -- a tile row of the tail holds the tail columns of two cosets, lane = (local coset j, column) with S / 2 lanes
+// per coset, as the PACKED kernels lay narrow matrices out -- and a ticket is (coset pair, row block): the work-group walks the
+// full segments of coset 2 cg, then those of coset 2 cg + 1 (a BLAKE3 block each, chaining values in registers; the first
+// coset's wait in their rows' leaf slots, written and read back by the same thread), then ONE tail tile that finishes the rows
+// of both cosets.  10 f128 columns: 2 * 2 + 1 = 5 tiles per coset pair instead of 6; 10 f64 columns: 3 instead of 4.
+// Same arithmetic and outputs as k_seg_last_hash<F, true>: row (k, c) = segments 0 .. nf - 1 of coset c, then the tail's lanes
+// of local coset c & 1, then zeros up to the row width (the tail tile writes those too).
+template <class F, bool SMALL = false, int LOGD = 0>
+__global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : 1024) k_seg_last_hash_tp(SegArgs<F> a) {
+    typedef typename F::T T;
+    typedef Pair<T> P2;
+    const uint32_t logD_ = LOGD ? (uint32_t)LOGD : a.logD;
+    const uint32_t NT = tile_threads<LOGD>();
+    constexpr uint32_t S = SegCfg<F>::S, HP = SegCfg<F>::HP, LGT = ilog2_const(S / 2);  // S / 2 lanes per coset in a tail row
+    constexpr uint32_t hp_shift = HP == 4 ? 2 : 1;
+    constexpr uint32_t WPE = F::BYTES / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const uint32_t D = 1u << logD_;
+    T *x = reinterpret_cast<T *>(smem_raw);
+    T *twd = x + (size_t)D * S;
+    const uint32_t nf = a.n_seg - 1;                       // full segments
+    const uint32_t n_pairs = a.n_cosets >> 1;
+    const uint64_t total = (uint64_t)n_pairs * a.O;        // tickets: (coset pair, row block); a multiple of 8
+    const uint64_t seg_elems = ((uint64_t)1 << a.logN) * S;
+    const uint32_t step = NT;
+    const uint32_t out_shift = a.logN - logD_;
+    const uint32_t k_stride = a.rows_per_k * (uint32_t)a.row_width;
+    const uint32_t hash_bytes = a.hash_epr * F::BYTES;
+    const uint32_t n_tiles = 2 * nf + 1;                   // per ticket
+
+    for (uint32_t e = threadIdx.x; e < D - 1; e += step) twd[e] = a.digit_tw[e];  // (twd[D - 1] holds the ticket words: k_seg_last_hash)
+
+    auto decode = [&](uint64_t t, uint32_t &cg, uint64_t &o, uint64_t &rev_o) {
+        const uint64_t bid = xcd_group_index(t, total);  // coset pair fastest, 8 consecutive tickets on one XCD
+        const uint32_t b32 = (uint32_t)bid, q32 = b32 / n_pairs;
+        cg = b32 - q32 * n_pairs;
+        o = q32;
+        rev_o = 0;
+        uint32_t bits = 0;
+        for (uint32_t q = 0; q < a.n_prev; q++) bits += a.prev_log[q];
+        uint32_t hi = bits, sh = 0;
+        for (uint32_t q = 0; q < a.n_prev; q++) {
+            hi -= a.prev_log[q];
+            rev_o |= ((o >> hi) & (((uint64_t)1 << a.prev_log[q]) - 1)) << sh;
+            sh += a.prev_log[q];
+        }
+    };
+    // tile s of ticket (cg, o): s < 2 nf: segment s % nf of coset 2 cg + s / nf; s == 2 nf: the tail tile of the pair
+    auto tile_src = [&](uint32_t cg, uint64_t o, uint32_t s) -> const T * {
+        if (s == 2 * nf) return a.src_tail + (uint64_t)cg * seg_elems + (o << logD_) * S;
+        const uint32_t j = s >= nf ? 1u : 0u, g = s - j * nf;
+        return a.src + ((uint64_t)(2 * cg + j) * nf + g) * seg_elems + (o << logD_) * S;
+    };
+
+    uint32_t *ticket_sh = reinterpret_cast<uint32_t *>(twd + (D - 1));
+    const uint32_t xcd = blockIdx.x & 7;
+    const uint64_t per_xcd = total >> 3;
+    auto next_ticket = [&](uint32_t slot) -> uint64_t {
+        if (threadIdx.x == 0) ticket_sh[slot] = atomicAdd(a.tile_counters + xcd, 1u);
+        __syncthreads();
+        return ticket_sh[slot];
+    };
+    auto sign_off = [&]() {
+        if (threadIdx.x == 0) {
+            const uint32_t mine = (gridDim.x + 7 - xcd) >> 3;
+            if (atomicAdd(a.tile_counters + 8 + xcd, 1u) == mine - 1) {
+                atomicExch(a.tile_counters + xcd, 0u);
+                atomicExch(a.tile_counters + 8 + xcd, 0u);
+            }
+        }
+    };
+    uint64_t ticket = next_ticket(0);
+    if (ticket >= per_xcd) {
+        sign_off();
+        return;
+    }
+    uint32_t cg, s = 0;
+    uint64_t o, rev_o;
+    decode(ticket * 8 + xcd, cg, o, rev_o);
+    uint4 q0, q1, q2, q3, q4, q5, q6, q7;
+    uint4 cva0 = make_uint4(0, 0, 0, 0), cva1 = cva0, cvb0 = cva0, cvb1 = cva0;  // chaining values of this lane's two rows
+#define WF_TILE_LOAD(SRC, TID)                                          \
+    do {                                                                \
+        const uint4 *s_ = reinterpret_cast<const uint4 *>(SRC) + (TID); \
+        q0 = s_[0];                                                     \
+        q1 = s_[step];                                                  \
+        q2 = s_[2 * step];                                              \
+        q3 = s_[3 * step];                                              \
+        q4 = s_[4 * step];                                              \
+        q5 = s_[5 * step];                                              \
+        q6 = s_[6 * step];                                              \
+        q7 = s_[7 * step];                                              \
+    } while (0)
+    WF_TILE_LOAD(tile_src(cg, o, 0), threadIdx.x);
+
+    while (true) {
+        {
+            uint4 *d_ = reinterpret_cast<uint4 *>(x);
+            const uint32_t t_ = opaque_tid();
+            d_[t_] = q0;
+            d_[t_ + step] = q1;
+            d_[t_ + 2 * step] = q2;
+            d_[t_ + 3 * step] = q3;
+            d_[t_ + 4 * step] = q4;
+            d_[t_ + 5 * step] = q5;
+            d_[t_ + 6 * step] = q6;
+            d_[t_ + 7 * step] = q7;
+            q0 = q1 = q2 = q3 = q4 = q5 = q6 = q7 = make_uint4(0, 0, 0, 0);  // (ends their live ranges: see k_seg_last_hash)
+        }
+        __syncthreads();
+        seg_lds_ntt<F, 1, (LOGD ? (1u << LOGD) : SMALL ? (FIX7 | FIX9) : FIX_BIG)>(x, twd, logD_, NT, nullptr, false, true);
+
+        const bool tail = s == 2 * nf;
+        const uint32_t j = s >= nf ? 1u : 0u, g = tail ? nf : s - j * nf, c = 2 * cg + j;  // (tail: j, c of the SECOND coset; unused)
+        uint4 pka0 = make_uint4(0, 0, 0, 0), pka1 = pka0, pkb0 = pka0, pkb1 = pka0;  // the first coset's chaining values, on their way back (tail tile)
+        // ---- row stores
+        if (!tail) {
+            const uint32_t tid = opaque_tid();
+            if (F::BYTES == 16) {  // one element per thread: whole 64-byte runs per store instruction
+                store_rows_by_element<F>(x, a, g, c, rev_o, out_shift, k_stride, tid, NT, false, false);
+            } else {
+                const uint32_t pstride = step >> hp_shift, pos0 = tid >> hp_shift, lane_a = 2 * (tid & (HP - 1));
+                T *pa = a.dst + (uint64_t)c * a.row_width + g * S + lane_a;
+                const uint32_t k0 = seg_digit_reverse<F>(pos0, logD_);
+                for (uint32_t pj = 0; pj < D; pj += pstride) {
+                    const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, logD_)) << out_shift);
+                    store_pair(pa + (uint64_t)(uint32_t)k * k_stride, *reinterpret_cast<P2 *>(x + (pos0 + pj) * S + lane_a));
+                }
+            }
+        } else {
+            // the rest of both cosets' rows from column nf * S on: the tail columns, then the zero padding -- one thread per
+            // 16-byte unit, the two local rows of a position next to each other.  The remainder of a row is 4 or 8 units (rows are
+            // multiples of 8 elements, full segments of S): this thread keeps its unit and local coset and walks over positions
+            // pos0 + it * pstride, whose digit reversal splits as in the loops above.
+            const uint32_t tid = opaque_tid();
+            constexpr uint32_t EPU = 16 / F::BYTES;
+            const uint32_t rest = (uint32_t)a.row_width - nf * S, lupr = ilog2_pow2(rest / EPU);
+            const uint32_t u = tid & ((1u << lupr) - 1), jj = (tid >> lupr) & 1u, pos0 = tid >> (lupr + 1), pstride = NT >> (lupr + 1);
+            // the first coset's chaining values come back from their leaf slots while the rows are stored
+            {
+                const uint64_t ka = rev_o + ((uint64_t)seg_digit_reverse<F>(tid, logD_) << out_shift);
+                const uint64_t kb = rev_o + ((uint64_t)seg_digit_reverse<F>(tid + step, logD_) << out_shift);
+                const uint4 *la = reinterpret_cast<const uint4 *>(a.leaves + ((uint64_t)(uint32_t)ka * a.rows_per_k + 2 * cg) * 8);
+                const uint4 *lb = reinterpret_cast<const uint4 *>(a.leaves + ((uint64_t)(uint32_t)kb * a.rows_per_k + 2 * cg) * 8);
+                pka0 = la[0];
+                pka1 = la[1];
+                pkb0 = lb[0];
+                pkb1 = lb[1];
+            }
+            const uint32_t k0 = seg_digit_reverse<F>(pos0, logD_);
+            T *row0p = a.dst + (uint64_t)(2 * cg + jj) * a.row_width + nf * S + EPU * u;
+            const T *xs0 = x + (jj << LGT);
+            const bool live_a = EPU * u < a.tail_cols, live_b = EPU * u + 1 < a.tail_cols;
+            for (uint32_t pj = 0; pj < D; pj += pstride) {
+                const uint64_t k = rev_o + ((uint64_t)(k0 | seg_digit_reverse<F>(pj, logD_)) << out_shift);
+                T *row = row0p + (uint64_t)(uint32_t)k * k_stride;
+                const T *xs = xs0 + (pos0 + pj) * S;
+                if (EPU == 2) {
+                    P2 v{F::zero(), F::zero()};
+                    if (live_a) v.a = xs[2 * u];
+                    if (live_b) v.b = xs[2 * u + 1];
+                    store_pair(row, v);
+                } else {
+                    row[0] = live_a ? xs[u] : F::zero();
+                }
+            }
+        }
+        // ---- the next tile starts its way into registers
+        bool more = true;
+        uint32_t cgn = cg, sn = s + 1;
+        uint64_t on = o, rev_on = rev_o;
+        if (sn == n_tiles) {
+            ticket = next_ticket(1);
+            more = ticket < per_xcd;
+            if (more) decode(ticket * 8 + xcd, cgn, on, rev_on);
+            sn = 0;
+        }
+        if (more) WF_TILE_LOAD(tile_src(cgn, on, sn), opaque_tid());
+        // ---- hashing: block g of the rows of coset c (full tile), or the last block of the rows of both cosets (tail tile)
+        {
+            const uint32_t tid = opaque_tid();
+#pragma unroll 1
+            for (uint32_t r = 0; r < 2; r++) {
+                const uint32_t pos = tid + r * step;
+                const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, logD_) << out_shift);
+                if (!tail) {
+                    T ev[S];
+                    uint4 *evq = reinterpret_cast<uint4 *>(ev);
+                    const uint4 *q = reinterpret_cast<const uint4 *>(x + (size_t)pos * S);
+#pragma unroll
+                    for (uint32_t w = 0; w < 4; w++) evq[w] = q[w];
+                    uint32_t m[16], cv[8];
+#pragma unroll
+                    for (uint32_t e = 0; e < S; e++) elem_words<F>(ev[e], &m[e * WPE]);
+                    if (g == 0) {
+                        b3::set_iv(cv);
+                    } else {
+                        const uint4 lo = r == 0 ? cva0 : cvb0, hi = r == 0 ? cva1 : cvb1;
+                        cv[0] = lo.x; cv[1] = lo.y; cv[2] = lo.z; cv[3] = lo.w;
+                        cv[4] = hi.x; cv[5] = hi.y; cv[6] = hi.z; cv[7] = hi.w;
+                    }
+                    b3::compress(cv, m, 0, 0, 64, g == 0 ? (uint32_t)b3::CHUNK_START : 0u);
+                    const uint4 lo = make_uint4(cv[0], cv[1], cv[2], cv[3]), hi = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+                    if (j == 0 && g + 1 == nf) {
+                        // the first coset's chaining values wait in their rows' leaf slots (this thread reads them back at the tail tile)
+                        uint4 *dl = reinterpret_cast<uint4 *>(a.leaves + ((uint64_t)(uint32_t)k * a.rows_per_k + c) * 8);
+                        dl[0] = lo;
+                        dl[1] = hi;
+                    } else if (r == 0) {
+                        cva0 = lo;
+                        cva1 = hi;
+                    } else {
+                        cvb0 = lo;
+                        cvb1 = hi;
+                    }
+                } else {
+                    const uint32_t blen = hash_bytes - 64u * nf;
+#pragma unroll 1
+                    for (uint32_t jj = 0; jj < 2; jj++) {
+                        uint4 *dl = reinterpret_cast<uint4 *>(a.leaves + ((uint64_t)(uint32_t)k * a.rows_per_k + 2 * cg + jj) * 8);
+                        uint32_t m[16], cv[8];
+#pragma unroll
+                        for (uint32_t w = 0; w < 16; w++) m[w] = 0;
+                        const T *e = x + (size_t)pos * S + (jj << LGT);
+#pragma unroll
+                        for (uint32_t q = 0; q < S / 2; q++) elem_words<F>(e[q], &m[q * WPE]);  // (lanes past the last column are zero)
+                        uint4 lo, hi;
+                        if (jj == 0) {
+                            lo = r == 0 ? pka0 : pkb0;
+                            hi = r == 0 ? pka1 : pkb1;
+                        } else {
+                            lo = r == 0 ? cva0 : cvb0;
+                            hi = r == 0 ? cva1 : cvb1;
+                        }
+                        cv[0] = lo.x; cv[1] = lo.y; cv[2] = lo.z; cv[3] = lo.w;
+                        cv[4] = hi.x; cv[5] = hi.y; cv[6] = hi.z; cv[7] = hi.w;
+                        b3::compress(cv, m, 0, 0, blen, (uint32_t)(b3::CHUNK_END | b3::ROOT));
+                        dl[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+                        dl[1] = digest_hi(cv[4], cv[5], cv[6], cv[7], a.digest_words);
+                    }
+                }
+            }
+        }
+        if (!more) {
+            sign_off();
+            break;
+        }
+        __syncthreads();  // x is rewritten by the next tile
+        cg = cgn;
+        s = sn;
+        o = on;
+        rev_o = rev_on;
+    }
+}
+#undef WF_TILE_LOAD
 
 // ---------------------------------------------------------------------------------------------------------------
 // Layout changes between the caller's columns ([col][row][ext coordinate]) and segments.
