@@ -311,8 +311,13 @@ def cpu_baseline(model, wl, traces_host, gpu_root=None, runs=5, warmups=2):
     # published single-thread 2-to-1 hash latency -- the tree phase is exactly N - 1 such hashes
     ns_tree = phases[3] * 1e6 * threads / (N - 1)
     ns_leaf = phases[2] * 1e6 * threads / leaf_comp
+    # against the threads started, and against the CPUs the cgroup really grants (32 threads on a 16-CPU quota can reach 0.5 at best)
+    granted = max(1, min(threads, usable))
     eff = {"merkle": round(ns_single / ns_tree, 3) if ns_tree > 0 else None,
-           "hash_rows": round(ns_single / ns_leaf, 3) if ns_leaf > 0 else None}
+           "hash_rows": round(ns_single / ns_leaf, 3) if ns_leaf > 0 else None,
+           "merkle_vs_cpus_granted": round(ns_single / ns_tree * threads / granted, 3) if ns_tree > 0 else None,
+           "hash_rows_vs_cpus_granted": round(ns_single / ns_leaf * threads / granted, 3) if ns_leaf > 0 else None,
+           "cpus_granted": granted}
     return dict(value=model["field_ops"] / (median * 1e-3), unit="field-ops/s", cores=threads, kind="port",
                 label="C restatement of the reference's concurrent CPU path (oracle/, OpenMP; BLAKE3 compression vectorised as in the "
                       "blake3 crate's single-compression SSE form; Merkle tree by sub-trees per thread as merkle/concurrent.rs) -- not the "

@@ -162,6 +162,13 @@ extern "C" {
     ) -> c_int;
     pub fn wf_commitment_wait(c: *mut WfCommitment) -> c_int;
     pub fn wf_comm_barrier(comm: *mut WfComm) -> c_int;
+    /// One f64 of every rank on every rank (`all_out`: world values, rank-major): per-rank step times of a benchmark record.
+    pub fn wf_comm_gather_f64(comm: *mut WfComm, value: f64, all_out: *mut f64) -> c_int;
+    /// What the transport reports about the communicator: transport (0 = RCCL, 1 = caller-supplied) and, for RCCL,
+    /// ncclCommCount / ncclCommUserRank / ncclCommCuDevice of the ncclComm_t in use.  Any output may be null.
+    pub fn wf_comm_info(
+        comm: *const WfComm, transport: *mut c_int, nccl_count: *mut c_int, nccl_user_rank: *mut c_int, nccl_device: *mut c_int,
+    ) -> c_int;
     /// Blocking wait on `stream` under the communicator's watchdog (WF_COMM_TIMEOUT_S): WF_ERR_COMM instead of a hang.
     pub fn wf_comm_stream_wait(comm: *mut WfComm, stream: *mut c_void) -> c_int;
     /// The file the RCCL symbols were resolved from (NUL-terminated, static storage).

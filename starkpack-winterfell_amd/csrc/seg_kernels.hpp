@@ -1394,7 +1394,11 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
 // SMALL: tiles of at most 2^9 rows (<= 256 threads): compiled without the 128-VGPR cap that 1024-thread work-groups impose
 // (the multi-segment variants spill a few registers under it)
 template <class F, bool MULTI, bool PADT = false, bool CHUNKED = false, bool SMALL = false, int LOGD = 0>  // PADT: SegArgs::pad_traces (kept out of the other instantiations' registers)
-__global__ void WF_TILE_BOUNDS(LOGD, SMALL ? 256 : 1024) k_seg_last_hash(SegArgs<F> a) {
+// (minimum waves per SIMD: 4 for the tile-size-specialised forms and for the small-tile chunk-by-chunk form of padded packed traces,
+// whose 130 registers otherwise cost it a wave: 13 traces x 20 columns at 2^18 last pass 4.28 -> 4.09 ms; the same cap on the
+// one-chunk small-tile padded form spills and loses 2-7 %: profiles/r04_attribution.txt)
+__global__ void __launch_bounds__((LOGD) ? (1 << ((LOGD) ? (LOGD) - 1 : 0)) : (SMALL ? 256 : 1024), ((LOGD) || (SMALL && PADT && CHUNKED)) ? 4 : 1)
+k_seg_last_hash(SegArgs<F> a) {
     typedef typename F::T T;
     const uint32_t logD_ = LOGD ? (uint32_t)LOGD : a.logD;  // (a local, not a.logD = LOGD: a modified copy of the arguments would live in scratch, where decode() indexes prev_log[])
     const uint32_t NT = tile_threads<LOGD>();
