@@ -5,11 +5,10 @@ passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes).
 (config: cfg2 -> profiles/traffic.json, else profiles/traffic_<config>.json -- the files bench.py --config reads)
 
 gfx950 corrections (guide, section HBM): WRITE_SIZE is exact for 16-byte-per-lane streaming stores.  FETCH_SIZE
-tallies 128-byte requests at 64 bytes, so it is doubled for kernels whose wave-instructions read >= 128 contiguous
-bytes (last passes, hashing, Merkle levels, layout changes); the strided passes gather isolated 64-byte rows
-(64-byte requests, counted exactly) and are not doubled, and neither is k_merkle_level2 (128 bytes per lane at a
-128-byte lane stride: its raw counter already equals the 340 MiB of children it must read).  Calibration:
-evaluate.last_pass must read the 512 MiB intermediate exactly once (raw counter: 256 MiB).
+tallies 128-byte requests at 64 bytes, so it is doubled -- for every kernel but k_merkle_level2 (128 bytes per lane at a
+128-byte lane stride; kept as rounds 1-3 had it).  Calibrations: evaluate.last_pass must read the 512 MiB intermediate of
+cfg 2 exactly once (raw counter: 256 MiB); the second strided pass of cfg 3 must read its 17.18 GB exactly once (raw: 8.59 GB;
+see NO_DOUBLE below for what that says about rounds 1-3).
 When the leaves are hashed inside the last evaluation pass (one segment, one trace) there is no k_hash_rows launch: its
 entry is zero and the evaluate entry carries the 256 MiB of leaf writes."""
 import collections
@@ -32,13 +31,19 @@ def csrc_sha():
 
 LOGICAL = [
     ("interpolate", ["k_cols_to_seg", "k_seg_strided<wf::F64, 0,", "k_seg_last<wf::F64, 0,", "k_seg_strided<wf::F128, 0,",
-                     "k_seg_last<wf::F128, 0,", "k_seg_to_cols"]),
+                     "k_seg_last<wf::F128, 0,", "k_seg_to_cols", "k_seg_strided_wide<wf::F64, 0,"]),
     ("evaluate", ["k_seg_strided<wf::F64, 1,", "k_seg_last<wf::F64, 1,", "k_seg_last_hash<wf::F64,", "k_seg_strided<wf::F128, 1,",
-                  "k_seg_last<wf::F128, 1,", "k_seg_last_hash<wf::F128,"]),
+                  "k_seg_last<wf::F128, 1,", "k_seg_last_hash<wf::F128,", "k_seg_strided_wide<wf::F64, 1,",
+                  "k_seg_last_hash_tp<wf::F64,", "k_seg_last_hash_tp<wf::F128,"]),
     ("hash_rows", ["k_hash_rows", "k_hash_chunks", "k_hash_merge_chunks"]),
     ("merkle", ["k_merkle_level", "k_merkle_subtree"])  # k_merkle_level also matches k_merkle_level2,
 ]
-NO_DOUBLE = ("k_seg_strided", "k_merkle_level2")
+# Round 4 calibration: the SECOND strided evaluation pass of cfg 3 must read the 17.18 GB intermediate exactly once (nothing can
+# absorb 16 GiB); its raw counter is 8.59 GB -- with 64-byte tile rows (round 3's kernel, same raw figure) as with 128-byte rows.
+# So the strided passes are doubled like every other kernel; rounds 1-3 took their 64-byte gathers as "counted exactly" and
+# UNDERCOUNTED them by half (cfg 3 evaluate: 87.5 GB then = 104.7 GB by this rule; cfg 2: 2.37 -> 2.64 GB).  The first strided
+# pass re-reads the polynomials once per coset at the fabric (cfg 2: 8 x 67 MB) -- Infinity-Cache hits are counted, as the guide says.
+NO_DOUBLE = ("k_merkle_level2",)
 
 
 def per_kernel(path, counter):
@@ -67,6 +72,9 @@ def main():
                 wr += write.get(k, 0.0) * 1024 / steps
         out[name] = {"read_bytes_per_step": rd, "write_bytes_per_step": wr, "hbm_bytes_per_step": rd + wr}
     out["path_total"] = sum(v["hbm_bytes_per_step"] for k, v in out.items() if not k.startswith("_"))
+    # raw counters per kernel and launch (KiB as rocprofv3 reports them), for the calibration notes
+    out["_raw_per_launch_kib"] = {k.split("(")[0][:90]: {"fetch": round(fetch[k] / max(1, fcalls[k]), 1), "write": round(write.get(k, 0.0) / max(1, fcalls[k]), 1),
+                                                          "launches_per_step": fcalls[k] / steps} for k in fetch}
     json.dump(out, open("profiles/traffic.json" if config == "cfg2" else f"profiles/traffic_{config}.json", "w"), indent=1)
     print(json.dumps(out, indent=1))
 
