@@ -335,7 +335,9 @@ def cpu_baseline(model, wl, traces_host, gpu_root=None, runs=5, warmups=2):
                                     "parallel_efficiency": eff,
                                     "reference_published_2_to_1_ns": "62-106 (single thread; /root/reference/crypto/README.md:69-75)",
                                     "note": "phase wall clock x threads / compressions: an upper bound on the per-thread cost (includes "
-                                            "imbalance and memory stalls); efficiency = single-thread ns measured in this run / that"},
+                                            "imbalance and memory stalls); efficiency = single-thread ns measured in this run / that; *_vs_cpus_granted rescales "
+                                            "by threads / min(threads, quota) -- the quota is enforced per 100 ms period, so a phase shorter "
+                                            "than that can burst above it (values > 1)"},
                 cpu_model=cpu_model(), threads_pinned=os.environ.get("OMP_PROC_BIND") == "close",
                 omp_places=os.environ.get("OMP_PLACES"), root=res["root"].hex(),
                 root_matches_gpu=(None if gpu_root is None else res["root"].hex() == gpu_root),

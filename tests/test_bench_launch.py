@@ -33,6 +33,36 @@ def test_plain_multi_gpu_command_starts_ranks_and_fails_loudly_without_gpus(capi
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]  # no number without a GPU
 
 
+def test_thread_route_fails_loudly_without_gpus(capi):
+    """`--ranks threads` on a box without a HIP device: no line, a non-zero exit code, the reason on stderr."""
+    if capi.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    out = run_bench("--gpus", "2", "--ranks", "threads", "--steps", "1", "--warmup", "0", timeout=300)
+    assert out.returncode == 1, out.stderr[-2000:]
+    assert "no HIP device" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_cpu_budget_reads_the_cgroup_quota(tmp_path, monkeypatch):
+    """bench.cpu_budget(): the thread count the CPU baseline may use = affinity capped by the cgroup's CPU quota."""
+    sys.path.insert(0, ROOT)
+    import bench
+    usable, det = bench.cpu_budget()
+    assert usable >= 1 and det["affinity"] >= usable and "os_cpu_count" in det
+    real_open = open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            f = tmp_path / "cpu.max"
+            f.write_text("300000 100000\n")
+            return real_open(f, *a, **k)
+        return real_open(path, *a, **k)
+
+    monkeypatch.setattr("builtins.open", fake_open)
+    usable, det = bench.cpu_budget()
+    assert det["quota_cpus"] == 3.0 and usable == min(3, det["affinity"])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["proofs", "packed"])
 def test_two_ranks_on_one_device_gloo_rehearsal(capi, mode):
