@@ -40,6 +40,12 @@ struct SegCfg {
     // radix-16 rounds keep 16 values (+ 8 constants) in registers: 2 VGPRs per value for f64; for f128 (4 per value)
     // that costs half the occupancy and runs slower than radix-4 rounds
     static constexpr bool RADIX16 = F::BYTES == 8;
+    // f128: radix-8 rounds with the 8 values of one lane in registers (32 VGPRs, what a radix-4 round on lane pairs holds too):
+    // three bits per LDS round trip instead of two -- a 2^9-row tile takes 3 rounds instead of 5, a 2^10-row tile 4 instead of 5.
+    // The multiplication count is the same (no root of unity of this field is a shift: 0.5 products per element and bit either way).
+    // Measured (profiles/r04_tail_pack.txt): cfg 5 1.21 -> 1.15 ms (every pass -5 %), f128 2^20 x 10 -1.6 %, the shapes with
+    // 2^10-row tiles (rounds 8, 8, 8, 2 against five radix-4 / radix-2 rounds) within 1 % either way; 8, 8, 4, 4 no better.
+    static constexpr bool RADIX8 = F::BYTES == 16;
     static constexpr uint32_t LOAD_BATCH = F::BYTES == 8 ? 8 : 4;  // 16- / 32-byte loads kept in flight per thread
 };
 
@@ -177,6 +183,11 @@ __device__ __forceinline__ uint32_t seg_digit_reverse(uint32_t pos, uint32_t log
         k |= ((pos >> (cur - 4)) & 15u) << sh;
         sh += 4;
         cur -= 4;
+    }
+    while (SegCfg<F>::RADIX8 && cur >= 3) {
+        k |= ((pos >> (cur - 3)) & 7u) << sh;
+        sh += 3;
+        cur -= 3;
     }
     while (cur >= 2) {
         k |= ((pos >> (cur - 2)) & 3u) << sh;
@@ -396,6 +407,61 @@ __device__ __forceinline__ void seg_round16(typename F::T *x, const typename F::
     }
 }
 
+// One radix-8 round (fields without shift twiddles: f128) at `cur` remaining bits: work item wk = lane wk % LANES of the 8 rows
+// row0 + a * 2^(cur-3); 8-point DIF in registers (w8[j] = w_8^j, j = 1..3), then the inter-round twiddles w_(2^cur)^(jp k).
+__host__ __device__ constexpr uint32_t bitrev3(uint32_t v) { return ((v & 1) << 2) | (v & 2) | ((v & 4) >> 2); }
+template <class F, uint32_t LANES = SegCfg<F>::S>
+__device__ __forceinline__ void seg_round8(typename F::T *x, const typename F::T *twd, const typename F::T (&w8)[4], uint32_t logD,
+                                           uint32_t cur, uint32_t nthr, uint32_t tid) {
+    typedef typename F::T T;
+    constexpr uint32_t l_shift = ilog2_const(LANES);
+    const uint32_t D = 1u << logD;
+    const uint32_t mlog = cur - 3, m = 1u << mlog;
+    const uint32_t nwork = (D >> 3) * LANES;
+    const uint32_t tshift = logD - cur;
+    const uint32_t st = m * LANES;
+    for (uint32_t wk = tid; wk < nwork; wk += nthr) {
+        const uint32_t l = wk & (LANES - 1), u = wk >> l_shift;
+        const uint32_t jp = u & (m - 1), p = u >> mlog;
+        const uint32_t base = ((p << cur) + jp) * LANES + l;
+        T v[8];
+#pragma unroll
+        for (int a = 0; a < 8; a++) v[a] = x[base + a * st];
+        // stage 1: (v[i], v[i + 4]) -> (sum, difference * w_8^i)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const T a0 = v[i], a1 = v[i + 4];
+            v[i] = F::add(a0, a1);
+            v[i + 4] = i == 0 ? F::sub(a0, a1) : F::mul(F::sub(a0, a1), w8[i]);
+        }
+        // stage 2: within each half, (v[q + i], v[q + i + 2]) with w_4^i = w_8^(2 i)
+#pragma unroll
+        for (int q = 0; q < 8; q += 4) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const T a0 = v[q + i], a1 = v[q + i + 2];
+                v[q + i] = F::add(a0, a1);
+                v[q + i + 2] = i == 0 ? F::sub(a0, a1) : F::mul(F::sub(a0, a1), w8[2]);
+            }
+        }
+        // stage 3
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+            const T a0 = v[q], a1 = v[q + 1];
+            v[q] = F::add(a0, a1);
+            v[q + 1] = F::sub(a0, a1);
+        }
+        // v[bitrev3(k)] = X_k; inter-round twiddles w^(jp k)
+        if (jp != 0) {
+            const uint32_t e = jp << tshift;
+#pragma unroll
+            for (int k = 1; k < 8; k++) v[bitrev3(k)] = F::mul(v[bitrev3(k)], twd[e * k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[base + k * st] = v[bitrev3(k)];
+    }
+}
+
 // (u - t) * w_4 of a transform of known direction over Goldilocks: w_4 = 2^48 forward, -2^48 inverse (2^96 = -1)
 template <class F, int DIR>
 __device__ __forceinline__ typename F::T mul_w4(typename F::T u, typename F::T t, typename F::T w4) {
@@ -580,6 +646,16 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
         while (cur >= 4) {
             seg_round16<F, DIR, false, LANES>(x, twd, w16, logD, cur, nthr, first, threadIdx.x, use_first && cur == logD);
             cur -= 4;
+            __syncthreads();
+        }
+    }
+    if (SegCfg<F>::RADIX8 && logD >= 3) {
+        T w8[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) w8[j] = twd[j * (D >> 3)];
+        while (cur >= 3) {
+            seg_round8<F, LANES>(x, twd, w8, logD, cur, nthr, threadIdx.x);
+            cur -= 3;
             __syncthreads();
         }
     }
