@@ -640,7 +640,11 @@ static int run_hash_rows(wf_ctx *ctx, hipStream_t st, const void *lde, uint64_t 
         int rc = ensure(ctx, ctx->hash_tmp, (size_t)n_rows * chunks * 32);
         if (rc) return rc;
         const uint64_t g2 = (n_rows * chunks + threads - 1) / threads;
-        hipLaunchKernelGGL(k_hash_chunks<F>, dim3((uint32_t)g2), dim3(threads), 0, st, h, (uint32_t)chunks,
+        // 40 KiB of (unused) dynamic LDS per work-group = three work-groups, 12 waves per CU: the lanes of this kernel gather
+        // 16-byte elements a row apart (256 bytes in the reference's example), and more resident waves only evict each other's
+        // lines from the 32 KiB L1 -- 512 x 2^10 x 10 f128: 0.387 -> 0.343 ms for the hashing launches, other shapes unchanged
+        // (profiles/r04_attribution.txt)
+        hipLaunchKernelGGL(k_hash_chunks<F>, dim3((uint32_t)g2), dim3(threads), 40 * 1024, st, h, (uint32_t)chunks,
                            (uint32_t *)ctx->hash_tmp.p);
         HIP_TRY(hipGetLastError());
         launch_merge_chunks(st, ctx->hash_tmp.p, (uint32_t)chunks, n_rows, leaves, dw);
