@@ -363,6 +363,13 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         if (rc) return rc;
         const uint64_t grid = (uint64_t)n_groups * run_cnt * a.O * a.I;
         if (grid > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "problem too large for one launch (%llu groups)", (unsigned long long)grid);
+        // first pass of a coset evaluation: the cosets of a tile back to back on one XCD (coset_inner_split, seg_kernels.hpp)
+        auto coset_inner = [&](uint32_t cosets, uint64_t tiles_per_coset) -> uint32_t {
+            if (!(d.rows_out && first) || ctx->tune.no_coset_inner || cosets < 2 || (cosets & (cosets - 1)) || (tiles_per_coset & 63)) return 0u;
+            uint32_t lc = 0;
+            while ((1u << lc) < cosets) lc++;
+            return lc + 1;
+        };
         prof_mark(ctx, st, tag_s);
         // f64 tiles of 2^10 and 2^9 rows (the digits of the 2^17 .. 2^21 plans) run the tile-size-specialised instantiations
         // (seg_kernels.hpp, WF_TILE_BOUNDS: strided pass of cfg 2 0.347 -> 0.324 ms); everything else the generic kernel
@@ -385,6 +392,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             while (ti > 1 && (ti > a.I || ((size_t)(ti * SegCfg<F>::S + 2 + ti) << a.logD) * sizeof(T) > 80 * 1024)) ti >>= 1;
             if (ti < 2 || ((1u << a.logD) * ti * SegCfg<F>::S) / 16 < 64) ti = 0;
         }
+        a.coset_inner = coset_inner(n_groups, ((uint64_t)run_cnt * a.O * a.I) / (ti ? ti : 1u));
         if (ti) {
             if constexpr (F::BYTES == 8) {
                 const void *kw = ti == 8 ? (d.rows_out ? (const void *)k_seg_strided_wide<F, 1, 8> : (const void *)k_seg_strided_wide<F, 0, 8>)
@@ -418,6 +426,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             b.lg_log = S_ == 8 ? 2 : 1;
             b.base_cols = b.total_base_cols = tail_cols;
             const uint64_t grid_b = (uint64_t)(d.n_cosets / 2) * a.O * a.I;
+            b.coset_inner = coset_inner(d.n_cosets / 2, a.O * a.I);
             hipLaunchKernelGGL((k_seg_strided<F, 1, true>), dim3((uint32_t)grid_b), dim3(threads), lds, st, b);
             HIP_TRY(hipGetLastError());
         }
@@ -425,6 +434,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
     }
     a.n_seg = d.n_seg;
     a.seg_stride = d.n_seg;
+    a.coset_inner = 0;
     if (d.phase == 1) return 0;
     {
         const int pi = plan.n_pass - 1;

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 
 PARITY_SWITCHES = ["WF_EXP_MAX_DIGIT=5", "WF_EXP_MAX_DIGIT=7", "WF_EXP_MAX_DIGIT=5 WF_EXP_WIDE_TI=8", "WF_EXP_MAX_DIGIT=7 WF_EXP_WIDE_TI=1", "WF_EXP_NO_FUSED_HASH=1",
-                   "WF_EXP_NO_PERSISTENT=1", "WF_EXP_NO_CHUNKED=1", "WF_EXP_PERSISTENT_ALWAYS=1", "WF_EXP_NO_SPECIALIZED=1"]
+                   "WF_EXP_NO_PERSISTENT=1", "WF_EXP_NO_CHUNKED=1", "WF_EXP_PERSISTENT_ALWAYS=1", "WF_EXP_NO_SPECIALIZED=1",
+                   "WF_EXP_NO_COSET_INNER=1 WF_EXP_MAX_DIGIT=7"]
 PARITY_FILES = ["test_gpu_coset_shard.py", "test_gpu_parity.py", "test_gpu_golden.py"]
 RESIDENT_SWITCHES = ["WF_EXP_PIPELINE_MIN_BYTES=0", "WF_EXP_PIPELINE_MIN_BYTES=0 WF_EXP_MAX_DIGIT=5", "WF_EXP_NO_PIPELINE=1"]
 RESIDENT_FILES = ["test_gpu_queries.py", "test_gpu_deep.py", "test_gpu_pipeline.py", "test_gpu_wide_resident.py"]
@@ -51,7 +52,9 @@ def test_parity_under_forced_plans(forced_runs, switch):
     WF_EXP_NO_CHUNKED: rows longer than one BLAKE3 chunk hashed by the separate chunk kernels instead of chunk by chunk
     inside the persistent pass.  WF_EXP_PERSISTENT_ALWAYS: the ticket kernel also on the small shapes that normally take
     one work-group per tile.  WF_EXP_NO_SPECIALIZED: every tile size on the generic kernels (the tile-size-specialised
-    instantiations are the default for 2^7 .. 2^10-row tiles, so without this run the generic code would see few shapes)."""
+    instantiations are the default for 2^7 .. 2^10-row tiles, so without this run the generic code would see few shapes).
+    WF_EXP_NO_COSET_INNER: the first strided evaluation pass with the coset as the outermost tile index (the default walks the
+    cosets of 64 neighbouring tiles back to back on one XCD whenever the tile count allows)."""
     out = forced_runs[switch]
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
 
