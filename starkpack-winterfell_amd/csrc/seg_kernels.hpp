@@ -189,6 +189,19 @@ struct SegArgs {
 #endif
 };
 
+// radix-8 fields: the number of remaining bits that is NOT taken as a radix-8 round (seg_lds_ntt); the diagnostic build can put
+// the round sequence of the first radix-8 version back (8, 8, 8, 2 for 2^10 rows) for a same-box comparison
+#if defined(WF_EXPERIMENTS) && defined(WF_EXP_R8_NO_SPLIT)
+constexpr uint32_t R8_SPLIT = 0;
+#else
+constexpr uint32_t R8_SPLIT = 4;
+#endif
+// radix-8 rounds of a 2^logD-row tile: all of them when 3 divides logD or leaves 2 bits (one radix-4 round follows); when it
+// leaves 1 bit, one round fewer and two radix-4 rounds (8, 8, 4, 4 for 2^10 rows, not 8, 8, 8, 2: see seg_lds_ntt)
+__host__ __device__ constexpr uint32_t radix8_rounds(uint32_t logD) {
+    return (R8_SPLIT == 4 && logD >= 4 && logD % 3 == 1) ? logD / 3 - 1 : logD / 3;
+}
+
 // LDS position -> output index of seg_lds_ntt: radix-16 digits while >= 4 bits remain, then radix-4, then radix-2
 template <class F>
 __device__ __forceinline__ uint32_t seg_digit_reverse(uint32_t pos, uint32_t logD) {
@@ -198,10 +211,12 @@ __device__ __forceinline__ uint32_t seg_digit_reverse(uint32_t pos, uint32_t log
         sh += 4;
         cur -= 4;
     }
-    while (SegCfg<F>::RADIX8 && cur >= 3) {
-        k |= ((pos >> (cur - 3)) & 7u) << sh;
-        sh += 3;
-        cur -= 3;
+    if (SegCfg<F>::RADIX8) {
+        for (uint32_t r = radix8_rounds(logD); r > 0; r--) {
+            k |= ((pos >> (cur - 3)) & 7u) << sh;
+            sh += 3;
+            cur -= 3;
+        }
     }
     while (cur >= 2) {
         k |= ((pos >> (cur - 2)) & 3u) << sh;
@@ -667,7 +682,10 @@ __device__ __forceinline__ void seg_lds_ntt(typename F::T *x, const typename F::
         T w8[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) w8[j] = twd[j * (D >> 3)];
-        while (cur >= 3) {
+        // radix-8 rounds, except that 4 remaining bits go as 4 + 4 points (not 8 + 2): a round's general products are its inner
+        // constants plus the twiddles in front of the next round, and the LAST round has none of the latter -- 2^10 rows as
+        // 8, 8, 4, 4 take 4.25 products per element against 4.5 for 8, 8, 8, 2 (2^7: 2.75 against 3), with as many LDS round trips
+        for (uint32_t r = radix8_rounds(logD); r > 0; r--) {
             seg_round8<F, LANES>(x, twd, w8, logD, cur, nthr, threadIdx.x);
             cur -= 3;
             __syncthreads();
