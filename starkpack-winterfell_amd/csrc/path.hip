@@ -205,32 +205,11 @@ static int seg_launch_dims(uint32_t logD, uint32_t &threads, size_t &lds, bool l
 static void launch_merge_chunks(hipStream_t st, const void *cvs, uint32_t n_chunks, uint64_t n_rows, void *leaves, uint32_t dw);
 
 // per-XCD ticket / exit counters of the persistent kernels + their error word; zeroed once (the kernels leave them at zero)
-// ... followed by WF_GROUP_COUNTERS words, one per row block of a last pass that builds tree levels (k_seg_last_hash<.., TREE>).
-// That form relies on work-groups with equal blockIdx % 8 sharing an XCD (they exchange leaves through its L2): the first use
-// checks it on this device with a probe launch (XCC_ID of 1024 work-groups); the kernel itself re-checks every row block and
-// raises the context's device error word if a block's tiles ever ran on different XCDs.
-constexpr size_t WF_GROUP_COUNTERS = 1u << 16;
-static __global__ void k_xcc_probe(uint32_t *out) {
-    if (threadIdx.x == 0) out[blockIdx.x] = xcc_id();
-}
 static int ensure_tickets(wf_ctx *ctx, hipStream_t st) {
     if (ctx->tickets.p) return 0;
-    int rc = ensure(ctx, ctx->tickets, 128 + WF_GROUP_COUNTERS * 4);
+    int rc = ensure(ctx, ctx->tickets, 128);
     if (rc) return rc;
-    uint32_t *gc = (uint32_t *)ctx->tickets.p + 32;
-    hipLaunchKernelGGL(k_xcc_probe, dim3(1024), dim3(64), 0, st, gc);
-    std::vector<uint32_t> ids(1024);
-    hipError_t e = hipMemcpyAsync(ids.data(), gc, 1024 * 4, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e == hipSuccess) e = hipMemsetAsync(ctx->tickets.p, 0, 128 + WF_GROUP_COUNTERS * 4, st);  // ordered on the launch stream (first use only)
-    if (e != hipSuccess) {
-        (void)hipFree(ctx->tickets.p);
-        ctx->tickets = DevBuf();
-        return fail(WF_ERR_HIP, "ticket counters: %s", hipGetErrorString(e));
-    }
-    bool same = true;
-    for (uint32_t b = 8; b < 1024; b++) same = same && ids[b] == ids[b & 7] && ids[b] < 8;
-    ctx->xcd_by_residue = same;
+    HIP_TRY(hipMemsetAsync(ctx->tickets.p, 0, 128, st));  // ordered on the launch stream (first use only)
     return 0;
 }
 
@@ -270,8 +249,6 @@ struct SegDesc {
     uint32_t hash_epr = 0;
     uint32_t digest_words = 8;  // 6: Blake3_192 leaves
     bool *fused = nullptr;
-    void *nodes = nullptr;              // rows_out + leaves: the tree's node array -- the last pass may build its first levels ...
-    uint32_t *tree_levels = nullptr;    // ... and says here how many (run_merkle starts above them)
     const TableSet *pre;
     bool pad_traces = false;     // rows_out, unpacked: the lane with a trace's last column zeroes the rest of that row
     bool pad_in_kernel = false;  // rows_out: the last pass also writes the zero padding lanes of the rows
@@ -571,20 +548,6 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             // ... and in 2^8-row tiles (2^17 x 32: last pass 0.278 -> 0.259 ms)
             if (F::BYTES == 8 && !chunked && multi && !a.pad_traces && a.logD == 8 && small && !ctx->tune.no_specialized)
                 kern = (const void *)k_seg_last_hash<F, true, false, false, true, F::BYTES == 8 ? 8 : 0>;
-            int rcq = ensure_tickets(ctx, st);
-            if (rcq) return rcq;
-            // one segment of one trace, 8 cosets: the three tree levels above the leaves built in the pass (cfg 2: the tree kernels
-            // 0.227 -> ... ms; seg_kernels.hpp, TREE)
-            const bool tree = !chunked && !multi && !a.pad_traces && d.nodes && d.tree_levels && d.n_cosets == 8 && d.coset0 == 0 &&
-                              a.digest_words == 8 && a.O <= WF_GROUP_COUNTERS && ctx->xcd_by_residue && !ctx->tune.no_tree_in_pass;
-            if (tree) {
-                kern = (F::BYTES == 8 && a.logD == 10 && !ctx->tune.no_specialized)
-                           ? (const void *)k_seg_last_hash<F, false, false, false, false, F::BYTES == 8 ? 10 : 0, 3>
-                           : (const void *)k_seg_last_hash<F, false, false, false, false, 0, 3>;
-                a.nodes = (uint32_t *)d.nodes;
-                a.group_counters = (uint32_t *)ctx->tickets.p + 32;
-                *d.tree_levels = 3;
-            }
             if (chunked) {
                 int rcc = ensure(ctx, ctx->hash_tmp, (size_t)launch_rows * n_chunks * 32);
                 if (rcc) return rcc;
@@ -594,6 +557,8 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             const size_t lds_p = lds;  // (the two ticket words live in the unused last twiddle slot)
             const uint64_t resident = (uint64_t)ctx->num_cus * std::max<size_t>(1, (160 * 1024) / lds_p);
+            int rcq = ensure_tickets(ctx, st);
+            if (rcq) return rcq;
             a.tile_counters = (uint32_t *)ctx->tickets.p;
 #if defined(WF_EXPERIMENTS) && defined(WF_EXP_STAMPS)
             a.stamps = exp_stamps_buffer();
@@ -698,12 +663,11 @@ static int run_hash_rows(wf_ctx *ctx, hipStream_t st, const void *lde, uint64_t 
     return 0;
 }
 
-// skip: levels above the leaves that are already in `nodes` (built by the last evaluation pass)
 template <int DW>
-static int run_merkle_dw(wf_ctx *ctx, hipStream_t st, const void *leaves, uint64_t n_leaves, void *nodes, uint32_t skip) {
+static int run_merkle_dw(wf_ctx *ctx, hipStream_t st, const void *leaves, uint64_t n_leaves, void *nodes) {
     // (nodes[0] = Digest::default(), merkle/mod.rs:355, is written by the launch that produces the root)
-    const uint32_t *children = skip ? (const uint32_t *)nodes + (n_leaves >> skip) * 8 : (const uint32_t *)leaves;
-    uint64_t n_children = n_leaves >> skip;
+    const uint32_t *children = (const uint32_t *)leaves;
+    uint64_t n_children = n_leaves;
     while (n_children > 1) {
         const uint64_t n_par = n_children >> 1;
         const uint32_t threads = 256;
@@ -738,8 +702,8 @@ static int run_merkle_dw(wf_ctx *ctx, hipStream_t st, const void *leaves, uint64
 }
 
 // dw: digest words -- 8 = Blake3_256, 6 = Blake3_192 (48-byte merge inputs; the slots' last two words are zeros)
-static int run_merkle(wf_ctx *ctx, hipStream_t st, const void *leaves, uint64_t n_leaves, void *nodes, uint32_t dw = 8, uint32_t skip = 0) {
-    return dw == 6 ? run_merkle_dw<6>(ctx, st, leaves, n_leaves, nodes, skip) : run_merkle_dw<8>(ctx, st, leaves, n_leaves, nodes, skip);
+static int run_merkle(wf_ctx *ctx, hipStream_t st, const void *leaves, uint64_t n_leaves, void *nodes, uint32_t dw = 8) {
+    return dw == 6 ? run_merkle_dw<6>(ctx, st, leaves, n_leaves, nodes) : run_merkle_dw<8>(ctx, st, leaves, n_leaves, nodes);
 }
 
 // ------------------------------------------------------------------------------------------------- the path (device)
@@ -831,11 +795,6 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
     d.hash_epr = b.total_base_cols;  // the combined row of all traces (= base_cols for one trace)
     d.digest_words = p->digest_bytes / 4;
     d.fused = &hashed;
-    uint32_t tree_levels = 0;  // levels of the tree the last pass built itself
-    if (d_nodes && coset0 == 0 && n_cosets == (1u << logB)) {
-        d.nodes = d_nodes;
-        d.tree_levels = &tree_levels;
-    }
     d.phase = phase;
     d.seg0 = seg0;
     d.seg_cnt = seg_cnt;
@@ -851,7 +810,7 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
         }
         if (d_nodes) {
             prof_mark(ctx, st, "merkle");
-            rc = run_merkle(ctx, st, d_leaves, Nrows, d_nodes, p->digest_bytes / 4, tree_levels);
+            rc = run_merkle(ctx, st, d_leaves, Nrows, d_nodes, p->digest_bytes / 4);
             if (rc) return rc;
         }
     }
@@ -1523,9 +1482,6 @@ int path_device_error(wf_ctx *ctx) {
     HIP_TRY(hipMemcpy(&err, (const char *)ctx->tickets.p + 64, 4, hipMemcpyDeviceToHost));
     if (!err) return 0;
     (void)hipMemset((char *)ctx->tickets.p + 64, 0, 4);
-    if (err == 2)
-        return fail(WF_ERR_HIP, "the tiles of one row block ran on different XCDs: the tree levels built in the last pass are not to be trusted "
-                                "(work-groups with equal blockIdx %% 8 did not share an XCD on this device)");
     return fail(WF_ERR_HIP, "a persistent kernel gave up waiting for the chaining values of a preceding block (internal error)");
 }
 

@@ -128,9 +128,6 @@ __device__ __forceinline__ uint64_t coset_inner_split(uint64_t bid, uint32_t lc,
     return ((hi >> lc) << 6) | (bid & 63);
 }
 
-// The XCD this wave runs on (hardware register XCC_ID, bits 3:0)
-__device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u; }
-
 // Tile indices are decoded with shifts where a factor is a power of two (I and O always are) and with 32-bit divisions
 // otherwise (grids are below 2^31): a 64-bit division by a run-time value costs ~80 VALU instructions on this target,
 // and the prologue of a tile is paid by every thread.
@@ -185,8 +182,6 @@ struct SegArgs {
     uint32_t *chunk_cvs;       // k_seg_last_hash<.., CHUNKED>: [LDE row][n_chunks][8] chunk chaining values (rows > 1024 bytes)
     uint32_t n_chunks;         //   ceil(n_seg / 16): a BLAKE3 chunk is 16 blocks = 16 segments of a row
     uint32_t *tile_counters;   // k_seg_last_hash: 8 ticket + 8 exit counters, one per XCD, zero between launches (self-resetting)
-    uint32_t *nodes;           // k_seg_last_hash<.., TREE>: the Merkle tree's node array (32-byte slots; level of n nodes at [n, 2n))
-    uint32_t *group_counters;  //   one word per row block: cosets of the block whose leaves are out; zero between launches (self-resetting)
     const T *src_tail;         // k_seg_last_hash_tp: the coset-packed tail segment's work buffer [coset pair][N][S]
     uint32_t tail_cols;        //   base columns in the tail segment (<= S / 2)
 #ifdef WF_EXP_STAMPS
@@ -1510,12 +1505,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
 // 16 segments of that chunk and writes the rows' chunk chaining values; k_hash_merge_chunks folds them into the leaves.
 // SMALL: tiles of at most 2^9 rows (<= 256 threads): compiled without the 128-VGPR cap that 1024-thread work-groups impose
 // (the multi-segment variants spill a few registers under it)
-// TREE (one segment of one trace, 8 cosets, 32-byte digests): the leaves of a row block's eight cosets are the eight CONSECUTIVE
-// leaves 8 k .. 8 k + 7 of every row index k of the block, i.e. complete sub-trees of three levels.  The eight tiles of a block
-// run on ONE XCD (consecutive tickets of its queue); each counts itself in on the block's counter once its leaves are out, and the
-// work-group that arrives last builds those three levels (7 compressions per k, two k per lane) from that XCD's L2 -- the leaves
-// are not read back from memory by the tree kernels, which start three levels up (run_merkle, path.hip).
-template <class F, bool MULTI, bool PADT = false, bool CHUNKED = false, bool SMALL = false, int LOGD = 0, int TREE = 0>  // PADT: SegArgs::pad_traces (kept out of the other instantiations' registers)
+template <class F, bool MULTI, bool PADT = false, bool CHUNKED = false, bool SMALL = false, int LOGD = 0>  // PADT: SegArgs::pad_traces (kept out of the other instantiations' registers)
 // (minimum waves per SIMD: 4 for the tile-size-specialised forms and for the small-tile chunk-by-chunk form of padded packed traces,
 // whose 130 registers otherwise cost it a wave: 13 traces x 20 columns at 2^18 last pass 4.28 -> 4.09 ms; the same cap on the
 // one-chunk small-tile padded form spills and loses 2-7 %: profiles/r04_attribution.txt)
@@ -1792,61 +1782,6 @@ k_seg_last_hash(SegArgs<F> a) {
 #ifdef WF_EXP_STAMPS
         st_acc[6]++;
 #endif
-        if constexpr (TREE != 0) {
-            static_assert(TREE == 3 && !MULTI && !CHUNKED && !PADT, "three levels above the leaves of 8 cosets, one segment");
-            // this tile's leaf stores have reached L2 (stores are acknowledged from there; the wait also covers the rows of the next
-            // tile, which the loop needs next anyway); then one arrival per work-group on the row block's counter
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-            __syncthreads();
-            // (the word also tallies the arrivals per XCD, three bits each from bit 8: the tiles of a row block are consecutive tickets
-            // of ONE XCD's queue, and the leaves are exchanged through that XCD's L2)
-            const uint32_t my_xcc = xcc_id() & 7u;
-            if (threadIdx.x == 0) ticket_sh[0] = atomicAdd(a.group_counters + o, 1u + (1u << (8 + 3 * my_xcc)));
-            __syncthreads();
-            const uint32_t before = ticket_sh[0];
-            if ((before & 0xFFu) == 7u) {  // uniform: the other seven cosets of this row block are out -- all from this XCD, all in its L2
-                if (threadIdx.x == 0) {
-                    atomicExch(a.group_counters + o, 0u);  // (the next launch finds zeros)
-                    if (before != 7u + (7u << (8 + 3 * my_xcc))) atomicExch(a.tile_counters + 16, 2u);  // device error word: path_device_error
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");           // no stale line of this CU's vector L1 is read below
-                const uint32_t tid = opaque_tid();
-                const uint64_t n_top = (uint64_t)1 << a.logN;  // nodes of the highest level built here; leaves = 8 n_top
-#pragma unroll 1
-                for (uint32_t r = 0; r < 2; r++) {
-                    const uint32_t pos = tid + r * step;
-                    const uint64_t k = rev_o + ((uint64_t)seg_digit_reverse<F>(pos, logD_) << out_shift);
-                    const uint4 *lf = reinterpret_cast<const uint4 *>(a.leaves + k * 64);  // 8 leaves = 16 x 16 bytes
-                    uint32_t par[16], gp[16], m[16], cv[8];
-#pragma unroll
-                    for (uint32_t h = 0; h < 4; h++) {  // leaves 2h, 2h + 1 -> node 4 n_top + 4 k + h
-                        const uint4 q0 = lf[4 * h], q1 = lf[4 * h + 1], q2 = lf[4 * h + 2], q3 = lf[4 * h + 3];
-                        m[0] = q0.x; m[1] = q0.y; m[2] = q0.z; m[3] = q0.w;
-                        m[4] = q1.x; m[5] = q1.y; m[6] = q1.z; m[7] = q1.w;
-                        m[8] = q2.x; m[9] = q2.y; m[10] = q2.z; m[11] = q2.w;
-                        m[12] = q3.x; m[13] = q3.y; m[14] = q3.z; m[15] = q3.w;
-                        b3::merge_slots<8>(m, cv);
-                        uint4 *dn = reinterpret_cast<uint4 *>(a.nodes + (4 * n_top + 4 * k + h) * 8);
-                        dn[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
-                        dn[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
-#pragma unroll
-                        for (uint32_t w = 0; w < 8; w++) par[8 * (h & 1) + w] = cv[w];
-                        if (h & 1) {  // parents 2j, 2j + 1 -> node 2 n_top + 2 k + j
-                            b3::merge_slots<8>(par, cv);
-                            uint4 *dg = reinterpret_cast<uint4 *>(a.nodes + (2 * n_top + 2 * k + (h >> 1)) * 8);
-                            dg[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
-                            dg[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
-#pragma unroll
-                            for (uint32_t w = 0; w < 8; w++) gp[8 * (h >> 1) + w] = cv[w];
-                        }
-                    }
-                    b3::merge_slots<8>(gp, cv);
-                    uint4 *dt = reinterpret_cast<uint4 *>(a.nodes + (n_top + k) * 8);
-                    dt[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
-                    dt[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
-                }
-            }
-        }
         if (!more) {
             sign_off();
             break;

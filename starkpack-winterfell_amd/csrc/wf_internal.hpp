@@ -68,7 +68,6 @@ struct wf_tuning {
     size_t pipeline_min_bytes = (size_t)1 << 20;  // WF_EXP_PIPELINE_MIN_BYTES
     bool no_tail_pack = false;        // WF_EXP_NO_TAIL_PACK: a half-empty last segment evaluated like the others (not coset-packed)
     bool no_coset_inner = false;      // WF_EXP_NO_COSET_INNER: first strided evaluation pass with the coset as the outermost tile index
-    bool no_tree_in_pass = false;     // WF_EXP_NO_TREE_IN_PASS: the fused last pass leaves every tree level to the tree kernels
     uint32_t wide_ti = 0;             // WF_EXP_WIDE_TI: inner positions per tile of the wide strided pass of 3+-pass plans (2, 4, 8); 1 = never; 0 = planner's own (2)
     int fail_after_segment = -1;      // WF_EXP_FAIL_AFTER_SEGMENT: the pipelined upload fails after that many segments (error-path test)
 };
@@ -96,7 +95,6 @@ struct wf_ctx {
     DevBuf io[5];     // staging for the host-buffer API: trace, polys, lde, leaves, nodes
     DevBuf hash_tmp;  // chunk chaining values of rows longer than one BLAKE3 chunk
     DevBuf tickets;   // per-XCD tile counters of the persistent last passes (+ word 16: their error flag)
-    bool xcd_by_residue = false;  // probed with the ticket buffer: work-groups with equal blockIdx % 8 share an XCD (ensure_tickets, path.hip)
     // Buffers of destroyed resident commitments, kept for the next commitment of the same shape (four hipFree + four
     // hipMalloc of 64..512 MiB cost about as much as the commitment itself); released by wf_ctx_release_cached / destroy.
     // Guarded by pool_mutex: a handle may be destroyed by another thread (a finaliser, Rust's Drop) while a call runs.
