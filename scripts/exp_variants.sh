@@ -1,7 +1,7 @@
 #!/bin/bash
 # Tuning aid: build variants of libwf_lde.so into build/exp_<name>/ -- any flags (a kernel change behind a macro of its own), or
 # the diagnostic switches of the experiment build (-DWF_EXPERIMENTS -DWF_EXP_SKIP_LOAD / _SKIP_NTT / _SKIP_STORE / _LOCAL_STORE=1|2 /
-# _STAMPS; the product build ignores them) -- and time cfg 2 with each
+# _STAMPS, -DWF_EXP_R8_NO_SPLIT = the f128 round order 8, 8, 8, 2; the product build ignores them) -- and time cfg 2 with each
 # (run the timing part on the GPU box:  WF_LDE_LIB=build/exp_<name>/libwf_lde.so python scripts/time_config.py 1 1 20 3 8 1).
 #   scripts/exp_variants.sh [name "flags"]...   (default: the time-attribution set of DESIGN.md §4)
 set -e
