@@ -393,25 +393,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             if (ti < 2 || ((1u << a.logD) * ti * SegCfg<F>::S) / 16 < 64) ti = 0;
         }
         a.coset_inner = coset_inner(n_groups, ((uint64_t)run_cnt * a.O * a.I) / (ti ? ti : 1u));
-        // ... and the later ones of those passes (outer count >= 8: tiles that share their tables follow each other) as runs of tiles per
-        // work-group with the next tile arriving by LDS-DMA (k_seg_strided_run)
-        const uint32_t threads_run = ti ? ((1u << a.logD) * ti * SegCfg<F>::S) / 16 : 0;
-        const bool dma_run = ti && !first && a.O >= 8 && threads_run <= 256 && !ctx->tune.no_dma_run;
-        if (dma_run) {
-            if constexpr (F::BYTES == 8) {
-                uint32_t run = ctx->tune.run_tiles ? ctx->tune.run_tiles : 32u;
-                while (run > a.O) run >>= 1;
-                a.run_log = 0;
-                while ((1u << a.run_log) < run) a.run_log++;
-                const void *kr = ti == 8 ? (d.rows_out ? (const void *)k_seg_strided_run<F, 1, 8> : (const void *)k_seg_strided_run<F, 0, 8>)
-                               : ti == 4 ? (d.rows_out ? (const void *)k_seg_strided_run<F, 1, 4> : (const void *)k_seg_strided_run<F, 0, 4>)
-                                         : (d.rows_out ? (const void *)k_seg_strided_run<F, 1, 2> : (const void *)k_seg_strided_run<F, 0, 2>);
-                const size_t lds_r = ((size_t)(2 * ti * SegCfg<F>::S + 1 + ti) << a.logD) * sizeof(T);
-                if (lds_r > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                void *kargs[] = {&a};
-                HIP_TRY(hipLaunchKernel(kr, dim3((uint32_t)((grid / ti) >> a.run_log)), dim3(threads_run), kargs, lds_r, st));
-            }
-        } else if (ti) {
+        if (ti) {
             if constexpr (F::BYTES == 8) {
                 const void *kw = ti == 8 ? (d.rows_out ? (const void *)k_seg_strided_wide<F, 1, 8> : (const void *)k_seg_strided_wide<F, 0, 8>)
                                : ti == 4 ? (d.rows_out ? (const void *)k_seg_strided_wide<F, 1, 4> : (const void *)k_seg_strided_wide<F, 0, 4>)

@@ -144,7 +144,6 @@ struct SegArgs {
     uint32_t n_seg;         // segments per coset
     uint32_t n_cosets;
     uint32_t src_shared;    // source indexed by segment only (first pass of an evaluation reads the polys)
-    uint32_t run_log;       // k_seg_strided_run: log2 of the tiles (consecutive outer indices) per work-group
     uint32_t coset_inner;   // strided pass, src_shared: 1 + log2(n_cosets) -- the cosets of 64 neighbouring tiles follow each other on one
                             // XCD (coset_inner_split), so that the source tile they share is fetched once and found in that L2; 0: coset outermost
     Pow2L<F> tw;            // powers of the N-th root of this transform
@@ -1088,103 +1087,6 @@ __global__ void __launch_bounds__(1024) k_seg_strided_wide(SegArgs<F> a) {
         if (*reinterpret_cast<const uint32_t *>(&v.a) == a.logN + 77777u)
 #endif
         store_pair(dst_lane + ((uint64_t)k << k_shift), v);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// EXPERIMENT (measured slower): the wide strided pass as a RUN of tiles per work-group, the next tile
-// arriving by LDS-DMA (later passes of plans of three and more passes: the tiles of one (coset, segment, inner block) for consecutive
-// outer indices o share every table of the pass).  The rows of tile t + 2 are requested with global_load_lds_dwordx4 (gfx950: 16
-// bytes per lane straight into LDS, no VGPR destination; 64 lanes x 16 bytes = 8 tile rows of 128 bytes, lane-linear in LDS, which
-// IS the tile layout) into the buffer tile t has just been stored from, and land while tile t + 1 is transformed.  The requests
-// are inline asm, so hipcc's s_waitcnt bookkeeping does not know them: the kernel waits for them itself (vmcnt(0) AFTER a
-// transform and before the stores of that tile are issued, so that the wait never sits behind fresh stores), and the compiler's
-// own waits can only be stricter than it thinks.  Digit twiddles and output factors are built once per work-group.
-// grid.x = n_cosets * n_seg * (O / run) * (I / TI); blockDim = D * TI * S / 16; LDS = two tiles + the two tables.
-__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {  // lds_dst: wave-uniform LDS byte address
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-}
-
-template <class F, int EVAL, int TI>
-__global__ void __launch_bounds__(256) k_seg_strided_run(SegArgs<F> a) {
-    static_assert(SegCfg<F>::RADIX16 && TI >= 2 && (TI & (TI - 1)) == 0 && TI <= 8, "f64 tiles of 2, 4 or 8 inner positions");
-    typedef typename F::T T;
-    typedef Pair<T> P2;
-    constexpr uint32_t S = SegCfg<F>::S, LANES = TI * S, HPW = LANES / 2;  // HPW: 16-byte pieces per tile row
-    constexpr uint32_t LOGS = ilog2_const(S), LOGTI = ilog2_const(TI), LOGHPW = ilog2_const(HPW);
-    constexpr uint32_t RPI = 64 / HPW;  // tile rows per DMA instruction (64 lanes x 16 bytes)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const uint32_t D = 1u << a.logD, NT = blockDim.x;
-    T *xb0 = reinterpret_cast<T *>(smem_raw);
-    T *xb1 = xb0 + (size_t)D * LANES;
-    T *twd = xb1 + (size_t)D * LANES;
-    T *fout = twd + D;  // [TI][D]: factors of the output rows
-
-    const uint64_t bid = xcd_group_index(blockIdx.x, gridDim.x);  // 8 neighbouring inner blocks on one XCD
-    const uint32_t logI = ilog2_pow2(a.I), logO = ilog2_pow2(a.O), logIt = logI - LOGTI, logRun = a.run_log;
-    const uint32_t run = 1u << logRun;
-    const uint64_t i0 = (bid & ((a.I >> LOGTI) - 1)) << LOGTI;
-    const uint64_t o0 = ((bid >> logIt) & ((a.O >> logRun) - 1)) << logRun;
-    const uint32_t rest = (uint32_t)(bid >> (logIt + logO - logRun));
-    const uint32_t c = rest / a.n_seg, g = rest - c * a.n_seg;
-    const uint64_t seg_elems = ((uint64_t)1 << a.logN) * S;
-    const T *src = a.src + ((uint64_t)c * a.seg_stride + g) * seg_elems;
-    T *dst = a.dst + ((uint64_t)c * a.seg_stride + g) * seg_elems;
-    const uint32_t tw_shift = a.logN - a.logD - logI;
-    const uint32_t tid = threadIdx.x;
-
-    // this lane's part of a tile request: instruction q = wave + j * n_waves covers tile rows q * RPI ..; 8 instructions per wave
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u, n_waves = NT >> 6;
-    const uint32_t lrow = lane >> LOGHPW, piece = lane & (HPW - 1);
-    auto request = [&](uint64_t o, T *xb) {
-        const uint64_t row0 = ((o << a.logD) << logI) + i0;
-        const uint32_t lds0 = (uint32_t)(uintptr_t)xb;
-#pragma unroll
-        for (uint32_t j = 0; j < 8; j++) {
-            const uint32_t d0 = (wave + j * n_waves) * RPI;
-            const T *gp = src + (row0 + ((uint64_t)(d0 + lrow) << logI)) * S + 2 * piece;
-            glds16(gp, __builtin_amdgcn_readfirstlane(lds0 + d0 * (LANES * (uint32_t)sizeof(T))));
-        }
-    };
-    request(o0, xb0);
-    if (run > 1) request(o0 + 1, xb1);
-
-    // tables, once per work-group: entry e = ti * D + k of the output factors (TI * D = 2 NT entries), the digit twiddles
-#pragma unroll
-    for (uint32_t q = 0; q < 2; q++) {
-        const uint32_t e = tid + q * NT, k = e & (D - 1), ti = e >> a.logD;
-        T f = a.tw.get(((uint64_t)k * (i0 + ti)) << tw_shift);
-        if (a.scale_on) f = F::mul(f, a.scale);  // 1/n of an interpolation
-        fout[e] = f;
-    }
-    if (tid < D) twd[tid] = a.digit_tw[tid];  // (NT = D * TI / 2 >= D)
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): both requested tiles have landed
-    __syncthreads();
-
-    const uint32_t pstride = NT >> LOGHPW, pos0 = tid >> LOGHPW, prw = tid & (HPW - 1);
-    const uint32_t k0 = seg_digit_reverse<F>(pos0, a.logD);
-    const T *fo = fout + (((2 * prw) >> LOGS) << a.logD);
-    const uint32_t k_shift = logI + LOGS;  // output rows k are I apart
-    for (uint32_t t = 0; t < run; t++) {
-        T *x = (t & 1) ? xb1 : xb0;
-        seg_lds_ntt<F, EVAL ? 1 : -1, 0u, LANES>(x, twd, a.logD, NT);
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // the tile requested a transform ago has landed (nothing newer is in flight yet)
-        const uint64_t row0 = (((o0 + t) << a.logD) << logI) + i0;
-        T *dst_lane = dst + row0 * S + 2 * prw;
-        for (uint32_t pj = 0; pj < D; pj += pstride) {
-            const uint32_t k = k0 | seg_digit_reverse<F>(pj, a.logD);
-            P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * LANES + 2 * prw);
-            const T f = fo[k];
-            v.a = F::mul(v.a, f);
-            v.b = F::mul(v.b, f);
-            store_pair(dst_lane + ((uint64_t)k << k_shift), v);
-        }
-        __syncthreads();  // every wave has read tile t out of x, and every wave's part of tile t + 1 has landed
-        if (t + 2 < run) request(o0 + t + 2, x);
     }
 }
 

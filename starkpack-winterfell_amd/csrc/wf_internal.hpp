@@ -68,8 +68,6 @@ struct wf_tuning {
     size_t pipeline_min_bytes = (size_t)1 << 20;  // WF_EXP_PIPELINE_MIN_BYTES
     bool no_tail_pack = false;        // WF_EXP_NO_TAIL_PACK: a half-empty last segment evaluated like the others (not coset-packed)
     bool no_coset_inner = false;      // WF_EXP_NO_COSET_INNER: first strided evaluation pass with the coset as the outermost tile index
-    bool no_dma_run = false;          // WF_EXP_NO_DMA_RUN: the later strided passes of 3+-pass plans one tile per work-group (k_seg_strided_wide)
-    uint32_t run_tiles = 0;           // WF_EXP_RUN_TILES=<1..128, power of two>: tiles per work-group of k_seg_strided_run (0: 32)
     uint32_t wide_ti = 0;             // WF_EXP_WIDE_TI: inner positions per tile of the wide strided pass of 3+-pass plans (2, 4, 8); 1 = never; 0 = planner's own (2)
     int fail_after_segment = -1;      // WF_EXP_FAIL_AFTER_SEGMENT: the pipelined upload fails after that many segments (error-path test)
 };
