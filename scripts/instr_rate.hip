@@ -47,6 +47,38 @@ KERNEL(k_pk_add16, asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a) : "v"(b)); a
 KERNEL(k_bfi, asm volatile("v_bfi_b32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(d)); asm volatile("v_bfi_b32 %0, %0, %1, %2" : "+v"(c) : "v"(d), "v"(b));)
 KERNEL(k_mad64_const0, asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p) : "v"(b), "v"(d) : "vcc"); asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(q) : "v"(d), "v"(b) : "vcc");)
 
+// round 4: the conditional move with its mask in an SGPR pair that nothing in the loop writes (the round-3 line above clobbers VCC in
+// every statement, so hipcc puts an s_nop between the statements and the figure is not the instruction's); compare + select as the
+// field code issues them; carry-in additions alone; and the double-precision pipe (a 104-bit product from two FMAs is the candidate
+// for a cheaper f128 product: DESIGN.md section 7c)
+__global__ void k_cndmask_sgpr(uint32_t *out, int iters) {
+    uint32_t a = threadIdx.x, b = a * 3 + 1, c = a ^ 0x55, d = a + 7;
+    const uint64_t mask = __builtin_amdgcn_read_exec() ^ (0x5555555555555555ull * (uint64_t)(iters & 1));
+    for (int i = 0; i < iters; i++) {
+        REP64(asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a) : "v"(b), "s"(mask)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(c) : "v"(d), "s"(mask));)
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d;
+}
+KERNEL(k_cmp_cnd, asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(b) : "vcc");)
+KERNEL(k_addc_only, asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a) : "v"(b) : "vcc"); asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(c) : "v"(d) : "vcc");)
+#define KERNEL_F64(name, body)                                                    \
+    __global__ void name(uint32_t *out, int iters) {                              \
+        double x = threadIdx.x + 1.5, y = 1.0000001, z = 0.75, w = 1.25;           \
+        for (int i = 0; i < iters; i++) { REP64(body) }                           \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(x + z);           \
+    }
+KERNEL_F64(k_fma64, asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(x) : "v"(y), "v"(w)); asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(z) : "v"(w), "v"(y));)
+KERNEL_F64(k_mul64f, asm volatile("v_mul_f64 %0, %0, %1" : "+v"(x) : "v"(y)); asm volatile("v_mul_f64 %0, %0, %1" : "+v"(z) : "v"(w));)
+KERNEL_F64(k_add64f, asm volatile("v_add_f64 %0, %0, %1" : "+v"(x) : "v"(y)); asm volatile("v_add_f64 %0, %0, %1" : "+v"(z) : "v"(w));)
+__global__ void k_cvt(uint32_t *out, int iters) {
+    uint32_t a = threadIdx.x + 3, c = threadIdx.x ^ 0x55;
+    double x, z;
+    for (int i = 0; i < iters; i++) {
+        REP64(asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(x) : "v"(a)); asm volatile("v_cvt_u32_f64 %0, %1" : "=v"(a) : "v"(x)); asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(z) : "v"(c)); asm volatile("v_cvt_u32_f64 %0, %1" : "=v"(c) : "v"(z));)
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ c;
+}
+
 template <class K>
 static void run(const char *name, K kern, uint32_t *out) {
     const int blocks = 256 * 8, threads = 256, iters = 200;  // 8 waves per SIMD
@@ -99,5 +131,12 @@ int main() {
     run("v_pk_add_u16", k_pk_add16, out);
     run("v_bfi_b32", k_bfi, out);
     run("mad64 (+0)", k_mad64_const0, out);
+    run("cndmask sgpr", k_cndmask_sgpr, out);
+    run("cmp+cndmask/2", k_cmp_cnd, out);  // (one statement of two instructions per REP body: halve the cycles for the pair... the line is per instruction of a 2-instruction body)
+    run("v_addc_co only", k_addc_only, out);
+    run("v_fma_f64", k_fma64, out);
+    run("v_mul_f64", k_mul64f, out);
+    run("v_add_f64", k_add64f, out);
+    run("cvt u32<->f64 x2", k_cvt, out);  // (four instructions per REP body: double the cycles)
     return 0;
 }
