@@ -144,6 +144,7 @@ struct SegArgs {
     uint32_t n_seg;         // segments per coset
     uint32_t n_cosets;
     uint32_t src_shared;    // source indexed by segment only (first pass of an evaluation reads the polys)
+    const T *fout_tab;      // k_seg_strided_wide<.., GTAB>: [I][D] output factors w_N^(k i N / (D I)) of this pass (global, built once per context)
     uint32_t coset_inner;   // strided pass, src_shared: 1 + log2(n_cosets) -- the cosets of 64 neighbouring tiles follow each other on one
                             // XCD (coset_inner_split), so that the source tile they share is fetched once and found in that L2; 0: coset outermost
     Pow2L<F> tw;            // powers of the N-th root of this transform
@@ -980,7 +981,11 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_strided(SegArgs<F> a) {
 // the two strided evaluation passes 9.28 -> 8.71 ms each and the commitment 35.5 -> 33.9 ms; TI = 4 and 8 (64 KiB tiles,
 // two work-groups per CU) give 9.0-9.2 and 9.1 ms.
 // grid.x = n_cosets * n_seg * O * (I / TI); blockDim = D * TI * S / 16 (one radix-16 work item per thread).
-template <class F, int EVAL, int TI>
+// GTAB: the output factors come from a table in global memory (SegArgs::fout_tab, [inner position][k]: passes after the first, whose
+// factors w_N^(k i N / (D I)) depend on neither coset nor segment nor outer index -- D x I entries, 256 KiB for cfg 3's second pass, built
+// once per context and served from L2) instead of being rebuilt in LDS by every tile.  What that buys is LDS: 17 KiB per work-group
+// instead of 20, i.e. nine work-groups per CU instead of eight for the pass whose waves per CU are what it lives on.
+template <class F, int EVAL, int TI, bool GTAB = false>
 __global__ void __launch_bounds__(1024) k_seg_strided_wide(SegArgs<F> a) {
     static_assert(SegCfg<F>::RADIX16 && TI >= 2 && (TI & (TI - 1)) == 0, "f64 tiles of 2, 4 or 8 inner positions");
     typedef typename F::T T;
@@ -1018,18 +1023,20 @@ __global__ void __launch_bounds__(1024) k_seg_strided_wide(SegArgs<F> a) {
     // prologue: every global read of the tile's setup is issued before the first one is used (as in k_seg_strided)
     const Pow2L<F> pst = scale_in ? pre : a.tw;  // (without input scaling these reads go to the root table and are dropped)
     T fo_a[2], fo_b[2], st_a[2], st_b[2];
+    if constexpr (!GTAB) {
 #pragma unroll
-    for (uint32_t q = 0; q < 2; q++) {  // TI * D = 2 NT table entries: entry e = ti * D + k
-        const uint32_t e = tid + q * NT, k = e & (D - 1), ti = e >> a.logD;
-        const uint64_t i = i0 + ti;
-        a.tw.fetch(((uint64_t)k * i) << tw_shift, fo_a[q], fo_b[q]);
-        pst.fetch(i, st_a[q], st_b[q]);
+        for (uint32_t q = 0; q < 2; q++) {  // TI * D = 2 NT table entries: entry e = ti * D + k
+            const uint32_t e = tid + q * NT, k = e & (D - 1), ti = e >> a.logD;
+            const uint64_t i = i0 + ti;
+            a.tw.fetch(((uint64_t)k * i) << tw_shift, fo_a[q], fo_b[q]);
+            pst.fetch(i, st_a[q], st_b[q]);
+        }
     }
     const bool has_d = tid < D;  // (NT = D * TI / 2 >= D)
     const uint32_t kd = has_d ? tid : 0;
     const T twv = a.digit_tw[kd];
     T fi_a, fi_b;
-    pst.fetch((uint64_t)kd << logI, fi_a, fi_b);
+    if constexpr (!GTAB) pst.fetch((uint64_t)kd << logI, fi_a, fi_b);
     // the thread's radix-16 work item straight from global memory: lane tid % LANES of rows a * D/16 + tid / LANES
     const uint32_t m16 = D >> 4, l16 = tid & (LANES - 1), j16 = tid >> LOGL;
     T vr[16];
@@ -1046,23 +1053,28 @@ __global__ void __launch_bounds__(1024) k_seg_strided_wide(SegArgs<F> a) {
             pr += rstep;
         }
     }
+    if constexpr (!GTAB) {
 #pragma unroll
-    for (uint32_t q = 0; q < 2; q++) {
-        T f = F::mul(fo_a[q], fo_b[q]);
-        if (scale_in)
-            f = F::mul(f, F::mul(st_a[q], st_b[q]));  // h_c^i rides on the output factors
-        else if (a.scale_on)
-            f = F::mul(f, a.scale);                    // 1/n of an interpolation
-        fout[tid + q * NT] = f;
+        for (uint32_t q = 0; q < 2; q++) {
+            T f = F::mul(fo_a[q], fo_b[q]);
+            if (scale_in)
+                f = F::mul(f, F::mul(st_a[q], st_b[q]));  // h_c^i rides on the output factors
+            else if (a.scale_on)
+                f = F::mul(f, a.scale);                    // 1/n of an interpolation
+            fout[tid + q * NT] = f;
+        }
     }
     if (has_d) {
         twd[kd] = twv;
-        if (scale_in) fin[kd] = F::mul(fi_a, fi_b);
+        if constexpr (!GTAB)
+            if (scale_in) fin[kd] = F::mul(fi_a, fi_b);
     }
     __syncthreads();
-    if (scale_in) {
+    if constexpr (!GTAB) {
+        if (scale_in) {
 #pragma unroll
-        for (uint32_t q = 0; q < 16; q++) vr[q] = F::mul(vr[q], fin[q * m16 + j16]);
+            for (uint32_t q = 0; q < 16; q++) vr[q] = F::mul(vr[q], fin[q * m16 + j16]);
+        }
     }
 #ifndef WF_EXP_SKIP_NTT
     seg_lds_ntt<F, EVAL ? 1 : -1, 0u, LANES>(x, twd, a.logD, NT, vr, true);
@@ -1074,9 +1086,26 @@ __global__ void __launch_bounds__(1024) k_seg_strided_wide(SegArgs<F> a) {
     // store: this thread's lane pair of row positions pos0 + j * pstride (rev(pos) = rev(pos0) | rev(j * pstride))
     const uint32_t pstride = NT >> LOGHPW, pos0 = tid >> LOGHPW, prw = tid & (HPW - 1);
     const uint32_t k0 = seg_digit_reverse<F>(pos0, a.logD);
-    const T *fo = fout + (((2 * prw) >> LOGS) << a.logD);
+    const T *fo = GTAB ? a.fout_tab + ((i0 + ((2 * prw) >> LOGS)) << a.logD) : fout + (((2 * prw) >> LOGS) << a.logD);
     T *dst_lane = dst + row0 * S + 2 * prw;
     const uint32_t k_shift = logI + LOGS;  // output rows k are I apart
+    if constexpr (GTAB) {  // pstride = D / 8: eight rows per thread, their factors requested together
+        uint32_t kk[8];
+        T ff[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            kk[j] = k0 | seg_digit_reverse<F>(j * pstride, a.logD);
+            ff[j] = fo[kk[j]];
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            P2 v = *reinterpret_cast<P2 *>(x + (pos0 + j * pstride) * LANES + 2 * prw);
+            v.a = F::mul(v.a, ff[j]);
+            v.b = F::mul(v.b, ff[j]);
+            store_pair(dst_lane + ((uint64_t)kk[j] << k_shift), v);
+        }
+        return;
+    }
     for (uint32_t pj = 0; pj < D; pj += pstride) {
         const uint32_t k = k0 | seg_digit_reverse<F>(pj, a.logD);
         P2 v = *reinterpret_cast<P2 *>(x + (pos0 + pj) * LANES + 2 * prw);

@@ -155,6 +155,37 @@ static int digit_table(wf_ctx *ctx, uint32_t logD, bool inverse, const typename 
     return 0;
 }
 
+// Output factors of a strided pass after the first (k_seg_strided_wide<.., GTAB>): entry [i][k] = w^((k i) << shift), w the 2^logN-th
+// root of the transform (or its inverse), k < 2^logD, i < 2^logI, shift = logN - logD - logI
+template <class F>
+static int pass_factor_table(wf_ctx *ctx, uint32_t logN, uint32_t logD, uint32_t logI, bool inverse, const typename F::T **out) {
+    auto key = std::make_tuple((int)F::FIELD_ID, (int)logN, inverse ? 7 : 6, (int)(logD | (logI << 8)), (uint64_t)0, (uint64_t)0);
+    auto it = ctx->tables.find(key);
+    if (it == ctx->tables.end()) {
+        typedef typename F::T T;
+        T w = f_root_of_unity<F>(logN ? logN : 1);
+        if (inverse) w = f_inv<F>(w);
+        const uint64_t D = (uint64_t)1 << logD, I = (uint64_t)1 << logI;
+        const T base = f_pow<F>(w, (u128)1 << (logN - logD - logI));  // w_(D I)
+        std::vector<T> tab(D * I);
+        T step = F::one();  // base^i
+        for (uint64_t i = 0; i < I; i++) {
+            T acc = F::one();
+            for (uint64_t k = 0; k < D; k++) {
+                tab[i * D + k] = acc;
+                acc = F::mul(acc, step);
+            }
+            step = F::mul(step, base);
+        }
+        TableSet ts;
+        HIP_TRY(hipMalloc(&ts.lo, tab.size() * sizeof(T)));
+        HIP_TRY(hipMemcpy(ts.lo, tab.data(), tab.size() * sizeof(T), hipMemcpyHostToDevice));
+        it = ctx->tables.emplace(key, ts).first;
+    }
+    *out = (const typename F::T *)it->second.lo;
+    return 0;
+}
+
 template <class F>
 static typename F::T offset_elem(const wf_params *p, uint64_t &lo, uint64_t &hi) {
     u128 off;
