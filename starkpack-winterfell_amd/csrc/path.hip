@@ -403,10 +403,12 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
                 // (<= 4 MiB, built once per context) instead of one rebuilt in LDS per tile: a work-group less LDS, a work-group more per CU
                 const uint32_t logI_ = (uint32_t)(d.logN - done_bits - a.logD);
                 a.fout_tab = nullptr;
-                if (!first && !a.scale_on && !a.pre_on && ti == 2 && a.logD + logI_ <= 19 && !ctx->tune.no_gtab) {
+                if (!first && !a.scale_on && !a.pre_on && a.logD + logI_ <= 19 && !ctx->tune.no_gtab) {
                     rc = pass_factor_table<F>(ctx, d.logN, a.logD, logI_, inverse, &a.fout_tab);
                     if (rc) return rc;
-                    kw = d.rows_out ? (const void *)k_seg_strided_wide<F, 1, 2, true> : (const void *)k_seg_strided_wide<F, 0, 2, true>;
+                    kw = ti == 8 ? (d.rows_out ? (const void *)k_seg_strided_wide<F, 1, 8, true> : (const void *)k_seg_strided_wide<F, 0, 8, true>)
+                       : ti == 4 ? (d.rows_out ? (const void *)k_seg_strided_wide<F, 1, 4, true> : (const void *)k_seg_strided_wide<F, 0, 4, true>)
+                                 : (d.rows_out ? (const void *)k_seg_strided_wide<F, 1, 2, true> : (const void *)k_seg_strided_wide<F, 0, 2, true>);
                     lds_w = ((size_t)(ti * SegCfg<F>::S + 1) << a.logD) * sizeof(T);
                 }
                 const uint32_t threads_w = ((1u << a.logD) * ti * SegCfg<F>::S) / 16;

@@ -995,7 +995,7 @@ __global__ void __launch_bounds__(1024) k_seg_strided_wide(SegArgs<F> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const uint32_t D = 1u << a.logD, NT = blockDim.x;
     T *x = reinterpret_cast<T *>(smem_raw);
-    T *twd = x + (size_t)D * LANES;
+    T *twd = x + (size_t)D * LANES;  // (stays in LDS also with GTAB: read from global memory inside the rounds the pass measured 3 % slower)
     T *fin = twd + D;    // h_c^(d I): factors of the input rows (first pass of a coset evaluation)
     T *fout = fin + D;   // [TI][D]: factors of the output rows
 

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 PARITY_SWITCHES = ["WF_EXP_MAX_DIGIT=5", "WF_EXP_MAX_DIGIT=7", "WF_EXP_MAX_DIGIT=5 WF_EXP_WIDE_TI=8", "WF_EXP_MAX_DIGIT=7 WF_EXP_WIDE_TI=1", "WF_EXP_NO_FUSED_HASH=1",
                    "WF_EXP_NO_PERSISTENT=1", "WF_EXP_NO_CHUNKED=1", "WF_EXP_PERSISTENT_ALWAYS=1", "WF_EXP_NO_SPECIALIZED=1",
-                   "WF_EXP_NO_COSET_INNER=1 WF_EXP_MAX_DIGIT=7"]
+                   "WF_EXP_NO_COSET_INNER=1 WF_EXP_MAX_DIGIT=7", "WF_EXP_NO_GTAB=1 WF_EXP_MAX_DIGIT=5 WF_EXP_WIDE_TI=8"]
 PARITY_FILES = ["test_gpu_coset_shard.py", "test_gpu_parity.py", "test_gpu_golden.py"]
 RESIDENT_SWITCHES = ["WF_EXP_PIPELINE_MIN_BYTES=0", "WF_EXP_PIPELINE_MIN_BYTES=0 WF_EXP_MAX_DIGIT=5", "WF_EXP_NO_PIPELINE=1"]
 RESIDENT_FILES = ["test_gpu_queries.py", "test_gpu_deep.py", "test_gpu_pipeline.py", "test_gpu_wide_resident.py"]
@@ -54,7 +54,9 @@ def test_parity_under_forced_plans(forced_runs, switch):
     one work-group per tile.  WF_EXP_NO_SPECIALIZED: every tile size on the generic kernels (the tile-size-specialised
     instantiations are the default for 2^7 .. 2^10-row tiles, so without this run the generic code would see few shapes).
     WF_EXP_NO_COSET_INNER: the first strided evaluation pass with the coset as the outermost tile index (the default walks the
-    cosets of 64 neighbouring tiles back to back on one XCD whenever the tile count allows)."""
+    cosets of 64 neighbouring tiles back to back on one XCD whenever the tile count allows).  WF_EXP_NO_GTAB: the later wide strided
+    passes rebuild their output factors in LDS per tile (the default reads them from a per-context table in global memory; the
+    WF_EXP_MAX_DIGIT=5 WF_EXP_WIDE_TI=8 run above takes that default on the small shapes of the parity suites)."""
     out = forced_runs[switch]
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
 
