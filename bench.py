@@ -459,6 +459,8 @@ def with_transfers(ctx, capi, params, trace_host, gpu_root):
         a = sorted(wide_commit() for _ in range(3))[1]
         # the same with the upload in front of the kernels: a second context created with WF_EXP_NO_PIPELINE set (the
         # library reads its tuning switches once, when a context is created)
+        # (process environment: safe here because with_transfers runs on single-rank records only -- rank_main calls it under
+        # `world == 1`, so no peer rank thread can be creating a context in this window)
         os.environ["WF_EXP_NO_PIPELINE"] = os.environ["WF_EXP_ENABLE"] = "1"
         try:
             serial_ctx = capi.Context(ctx.device)
@@ -521,23 +523,30 @@ def free_port():
     return p
 
 
-def launch_ranks(n):
-    """`python bench.py --gpus N` as a plain command: start one rank per GPU and get out of the way.  This process has
-    not imported torch or touched the GPU; the ranks are children, not an exec of this process.  The children run in
-    their own process group under a wall-clock limit (WF_BENCH_LAUNCH_TIMEOUT_S, default 900 s): on expiry exactly that
-    group is ended and this process exits non-zero -- a rank stuck in a collective cannot hang the caller."""
+def _run_limited(cmd, env, limit, what):
+    """Run `cmd` as a child in its own process group under a wall-clock limit, passing its stdout through line by line while
+    keeping a copy.  Returns (exit code, captured stdout, captured stderr tail); 124 when the limit ended the group."""
     import signal
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this host driver
-    env.setdefault("OMP_NUM_THREADS", "8")
-    limit = float(os.environ.get("WF_BENCH_LAUNCH_TIMEOUT_S", "900"))
-    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    import threading
+    child = subprocess.Popen(cmd, env=env, start_new_session=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                             errors="replace")
+    out_lines, err_lines = [], []
+
+    def tee(src, dst, keep):
+        for line in src:
+            keep.append(line)
+            dst.write(line)
+            dst.flush()
+
+    pumps = [threading.Thread(target=tee, args=(child.stdout, sys.stdout, out_lines), daemon=True),
+             threading.Thread(target=tee, args=(child.stderr, sys.stderr, err_lines), daemon=True)]
+    for t in pumps:
+        t.start()
+    rc = None
     try:
-        return child.wait(timeout=limit)
+        rc = child.wait(timeout=limit)
     except subprocess.TimeoutExpired:
-        print(f"bench.py: the {n} ranks did not finish within {limit:.0f} s; ending their process group", file=sys.stderr, flush=True)
+        print(f"bench.py: {what} did not finish within {limit:.0f} s; ending the process group", file=sys.stderr, flush=True)
         for sig, grace in ((signal.SIGTERM, 10), (signal.SIGKILL, 10)):
             try:
                 os.killpg(child.pid, sig)  # the group this call created (start_new_session): the launcher and its ranks
@@ -548,7 +557,51 @@ def launch_ranks(n):
                 break
             except subprocess.TimeoutExpired:
                 continue
-        return 124
+        rc = 124
+    for t in pumps:
+        t.join(timeout=5)
+    return rc, "".join(out_lines), "".join(err_lines[-200:])
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` as a plain command: start one rank per GPU and get out of the way.  This process has
+    not imported torch or touched the GPU; the ranks are children, not an exec of this process.  The children run in
+    their own process group under a wall-clock limit (WF_BENCH_LAUNCH_TIMEOUT_S, default 900 s): on expiry exactly that
+    group is ended and this process exits non-zero -- a rank stuck in a collective cannot hang the caller.
+
+    Fallback (round 5): if the process launcher fails WITHOUT a benchmark line -- and not through a parity gate and not at the
+    limit: e.g. a box that allows fewer processes on a card than the launcher needs -- a FRESH child runs the same command
+    with `--ranks threads` (one process, one host thread per GPU, the same RCCL communicator, steps and gates).  The child's
+    record says in `collective.ranks` that the fallback ran and why.  WF_BENCH_NO_FALLBACK=1 turns it off."""
+    launcher = os.environ.get("WF_BENCH_LAUNCHER")  # test hook: a stand-in for `python -m torch.distributed.run`
+    head = launcher.split() if launcher else [sys.executable, "-m", "torch.distributed.run"]
+    cmd = head + ["--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+                  os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    limit = float(os.environ.get("WF_BENCH_LAUNCH_TIMEOUT_S", "900"))
+    t0 = time.monotonic()
+    rc, out, err = _run_limited(cmd, env, limit, f"the {n} ranks")
+    has_line = any(l.startswith("{") for l in out.splitlines())
+    parity = "PARITY FAILURE" in out or "PARITY FAILURE" in err
+    if rc == 0 or has_line or parity or rc == 124 or os.environ.get("WF_BENCH_NO_FALLBACK") == "1":
+        return rc
+    left = limit - (time.monotonic() - t0)
+    if left < 30:
+        return rc
+    last = [l.strip() for l in err.splitlines() if l.strip()]
+    reason = f"process launcher exited {rc} without a benchmark line" + (f" (last stderr line: {last[-1][:160]})" if last else "")
+    print(f"bench.py: {reason}; starting a fresh child with --ranks threads", file=sys.stderr, flush=True)
+    argv = [a for a in sys.argv[1:]]
+    if "--ranks" in argv:  # (only reached when --ranks processes was given explicitly)
+        i = argv.index("--ranks")
+        del argv[i:i + 2]
+    env2 = dict(env)
+    env2["WF_BENCH_FALLBACK_REASON"] = reason
+    rc2, _, _ = _run_limited([sys.executable, os.path.abspath(__file__)] + argv + ["--ranks", "threads"], env2, left,
+                             f"the {n} rank threads (fallback)")
+    return rc2
 
 
 def verify_multi_rank(torch, capi, shard, ctx, comm, args, packed, params, rank, world, device, stream, trace, roots, all_roots, top,
@@ -626,8 +679,16 @@ class ThreadRanks:
         self.world, self.backend = world, backend
         self.uid = shard.unique_id() if backend == "rccl" else None
         self.loopback = shard.Loopback(world, timeout=float(os.environ.get("WF_COMM_TIMEOUT_S", "300"))) if backend == "loopback" else None
-        self.host_barrier = threading.Barrier(world)
+        self.failed = threading.Event()  # a rank failed: its peers are released (loopback) or given a short grace (RCCL)
         self.rc = [None] * world
+
+    def abort(self):
+        self.failed.set()
+        if self.loopback is not None:
+            try:
+                self.loopback.barrier.abort()  # peers waiting in a rehearsal collective raise BrokenBarrierError
+            except Exception:  # noqa: BLE001
+                pass
 
 
 def run_threads(args):
@@ -660,22 +721,30 @@ def run_threads(args):
         except SystemExit as e:
             if e.code not in (None, 0):
                 print(f"rank {r}: {e.code}", file=sys.stderr, flush=True)
+                shared.abort()  # (a parity gate exits this way: the peers must not sit in their next collective)
             shared.rc[r] = 0 if e.code in (None, 0) else 1
         except BaseException:  # noqa: BLE001 -- a rank's failure is the run's failure
             traceback.print_exc()
             shared.rc[r] = 1
-            try:
-                shared.host_barrier.abort()
-            except Exception:  # noqa: BLE001
-                pass
+            shared.abort()
 
     threads = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(n)]
     for t in threads:
         t.start()
     limit = float(os.environ.get("WF_BENCH_LAUNCH_TIMEOUT_S", "900"))
     deadline = time.monotonic() + limit
-    for t in threads:
-        t.join(timeout=max(0.0, deadline - time.monotonic()))
+    grace = float(os.environ.get("WF_BENCH_PEER_GRACE_S", "20"))
+    while any(t.is_alive() for t in threads) and time.monotonic() < deadline:
+        threads[0].join(timeout=0.2) if threads[0].is_alive() else time.sleep(0.2)
+        if shared.failed.is_set():  # a rank failed: peers inside an RCCL collective get a short grace, not the whole limit
+            end = time.monotonic() + grace
+            while any(t.is_alive() for t in threads) and time.monotonic() < end:
+                time.sleep(0.2)
+            if any(t.is_alive() for t in threads):
+                print(f"bench.py: a rank failed and its peers did not return within {grace:.0f} s; ending the process", file=sys.stderr, flush=True)
+                sys.stdout.flush()
+                os._exit(1)
+            break
     if any(t.is_alive() for t in threads):
         print(f"bench.py: the {n} rank threads did not finish within {limit:.0f} s; ending the process", file=sys.stderr, flush=True)
         sys.stdout.flush()
@@ -962,7 +1031,8 @@ def rank_main(args, rank, world, local_rank, route, shared):
                             else ("FALLBACK: torch.distributed nccl (= RCCL), wf_comm failed: " + comm.reason) if comm.transport == "torch"
                             else "wf_transport through host memory between the threads of one process (rehearsal)" if route == "threads"
                             else "wf_transport over torch.distributed gloo (rehearsal)",
-                            "ranks": ("one host thread per GPU in one process" if route == "threads" else "one process per GPU (torch.distributed.run)"),
+                            "ranks": (("one host thread per GPU in one process" if route == "threads" else "one process per GPU (torch.distributed.run)") +
+                                      (" -- FALLBACK: " + os.environ["WF_BENCH_FALLBACK_REASON"] if os.environ.get("WF_BENCH_FALLBACK_REASON") else "")),
                             # ncclCommCount / ncclCommUserRank / ncclCommCuDevice as every rank's communicator reports them
                             # (wf_comm_info): RCCL itself saying that it spans `world` ranks on `world` distinct devices
                             "nccl_comm_count": comm_info["count"] if comm_info else None,

@@ -93,3 +93,42 @@ def test_packed_mode_single_gpu_root_matches_sharded(capi):
     r1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])["root"]
     r2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])["root"]
     assert r1 == r2
+
+
+# ---- the fallback of the plain multi-GPU command (round 5): process launcher fails without a line -> fresh --ranks threads child
+def _fake_launcher(tmp_path, body):
+    f = tmp_path / "fake_launcher.py"
+    f.write_text("import sys\n" + body)
+    return f"{sys.executable} {f}"
+
+
+def test_failed_process_launcher_falls_back_to_a_fresh_thread_child(capi, tmp_path):
+    """A process launcher that dies without a benchmark line (a per-card process limit, say) must not lose the N > 1 record:
+    the parent starts `bench.py --gpus N --ranks threads` as a NEW child.  Without a GPU that child fails loudly in turn --
+    what this test sees is that it was started, with the reason handed over."""
+    if capi.device_count() > 0:
+        pytest.skip("a HIP device is present (the GPU form of this test is in test_gpu_multi_device.py)")
+    launcher = _fake_launcher(tmp_path, "sys.stderr.write('process guard: too many processes on the card\\n'); sys.exit(7)\n")
+    out = run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", env_extra={"WF_BENCH_LAUNCHER": launcher}, timeout=300)
+    assert out.returncode == 1, out.stderr[-2000:]
+    assert "process launcher exited 7 without a benchmark line" in out.stderr
+    assert "starting a fresh child with --ranks threads" in out.stderr
+    assert "no HIP device" in out.stderr                                  # the thread child ran (and refused: no GPU here)
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.parametrize("body,rc", [
+    ("sys.stderr.write('PARITY FAILURE: root mismatch\\n'); sys.exit(1)\n", 1),         # a parity gate is a result, not a launch failure
+    ("print('{\"metric\": \"x\"}'); sys.exit(3)\n", 3),                                    # a line was printed
+    ("sys.exit(0)\n", 0),
+])
+def test_no_fallback_after_a_parity_failure_a_line_or_success(capi, tmp_path, body, rc):
+    out = run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", env_extra={"WF_BENCH_LAUNCHER": _fake_launcher(tmp_path, body)}, timeout=120)
+    assert out.returncode == rc
+    assert "--ranks threads" not in out.stderr
+
+
+def test_fallback_can_be_switched_off(capi, tmp_path):
+    launcher = _fake_launcher(tmp_path, "sys.exit(7)\n")
+    out = run_bench("--gpus", "2", env_extra={"WF_BENCH_LAUNCHER": launcher, "WF_BENCH_NO_FALLBACK": "1"}, timeout=120)
+    assert out.returncode == 7 and "--ranks threads" not in out.stderr

@@ -3,7 +3,7 @@
   * On a box with >= 2 GPUs (skipped cleanly otherwise): RCCL inside libwf_lde.so across processes, one rank per GPU --
     `bench.py --gpus W` in both sharding modes (its root-parity gates must pass and the line must say so) and the
     collective query service against the oracle (tests/ranks_sharded_query.py).  W = the largest power of two <= the
-    device count, capped by WF_TEST_RANKS (default 4: the GPU boxes of this pool allow few processes per card).
+    device count, capped by WF_TEST_RANKS (default 4 -- the GPU boxes of this pool allow few processes per card -- and 8 on a box with >= 8 devices).
   * On any GPU box: the very same rank script and the same bench gates over the gloo rehearsal transport, the ranks
     sharing the device(s) -- so the code the multi-GPU run executes is exercised by every `pytest -m gpu`.
   * The gates themselves: a corrupted root must take the run down with a non-zero exit code and no benchmark line.
@@ -45,8 +45,11 @@ def real_world(capi):
     n = capi.device_count()
     if n < 2:
         pytest.skip(f"{n} HIP device(s): RCCL needs one device per rank (the same ranks run over gloo below)")
+    # WF_TEST_RANKS caps the world (default: 4 processes -- the one-GPU boxes of this pool allow few processes per card; a
+    # whole node, >= 8 devices, runs all eight: one process per card is within every limit there)
+    cap = int(os.environ.get("WF_TEST_RANKS", "8" if n >= 8 else "4"))
     w = 1
-    while 2 * w <= min(n, int(os.environ.get("WF_TEST_RANKS", "4"))):
+    while 2 * w <= min(n, cap):
         w *= 2
     return w
 
@@ -143,6 +146,21 @@ def test_thread_route_gives_up_on_a_rank_that_hangs(capi):
                     env_extra={"WF_BENCH_BACKEND": "loopback", "WF_BENCH_LAUNCH_TIMEOUT_S": "25", "WF_COMM_TIMEOUT_S": "60"}, timeout=300)
     assert out.returncode == 124, out.stdout[-2000:] + out.stderr[-2000:]
     assert "did not finish within" in out.stderr
+
+
+def test_failed_process_launcher_falls_back_to_the_thread_route_and_says_so(capi, tmp_path):
+    """`python bench.py --gpus N` whose process launcher dies without a line (stand-in launcher: exit 7) must still print a
+    verified line -- from a fresh `--ranks threads` child -- and the line must say that the fallback ran and why."""
+    capi.load()
+    f = tmp_path / "fake_launcher.py"
+    f.write_text("import sys\nsys.stderr.write('process guard: too many processes on the card\\n')\nsys.exit(7)\n")
+    out = run_bench("--gpus", "2", "--steps", "2", "--warmup", "1",
+                    env_extra={"WF_BENCH_BACKEND": "loopback", "WF_BENCH_LAUNCHER": f"{sys.executable} {f}"})
+    j = bench_line(out)
+    c = j["collective"]
+    assert j["n_gpus"] == 2 and c["verified"]["ok"] is True
+    assert "thread" in c["ranks"] and "FALLBACK" in c["ranks"] and "exited 7" in c["ranks"]
+    assert "starting a fresh child with --ranks threads" in out.stderr
 
 
 def test_thread_route_refuses_rccl_with_fewer_devices_than_ranks(capi):
