@@ -44,6 +44,7 @@ wf_tuning tuning_from_env() {
     t.no_tail_pack = getenv("WF_EXP_NO_TAIL_PACK") != nullptr;
     t.no_coset_inner = getenv("WF_EXP_NO_COSET_INNER") != nullptr;
     t.no_gtab = getenv("WF_EXP_NO_GTAB") != nullptr;
+    t.no_r32 = getenv("WF_EXP_NO_R32") != nullptr;
     if (const char *e = getenv("WF_EXP_WIDE_TI")) {
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8) t.wide_ti = (uint32_t)v;

@@ -68,6 +68,7 @@ struct wf_tuning {
     size_t pipeline_min_bytes = (size_t)1 << 20;  // WF_EXP_PIPELINE_MIN_BYTES
     bool no_tail_pack = false;        // WF_EXP_NO_TAIL_PACK: a half-empty last segment evaluated like the others (not coset-packed)
     bool no_coset_inner = false;      // WF_EXP_NO_COSET_INNER: first strided evaluation pass with the coset as the outermost tile index
+    bool no_r32 = false;              // WF_EXP_NO_R32: 2^10-row f64 tiles through LDS round by round (seg_kernels.hpp) instead of register-resident (seg_r32.hpp)
     bool no_gtab = false;             // WF_EXP_NO_GTAB: later wide strided passes rebuild their output factors in LDS per tile
     uint32_t wide_ti = 0;             // WF_EXP_WIDE_TI: inner positions per tile of the wide strided pass of 3+-pass plans (2, 4, 8); 1 = never; 0 = planner's own (2)
     int fail_after_segment = -1;      // WF_EXP_FAIL_AFTER_SEGMENT: the pipelined upload fails after that many segments (error-path test)
