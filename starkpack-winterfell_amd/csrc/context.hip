@@ -3,6 +3,8 @@
 // There is deliberately no CPU fallback: every compute entry point needs a HIP device.
 #include "wf_internal.hpp"
 
+#include <atomic>
+
 #include "field.hpp"
 
 using namespace wf;
@@ -10,7 +12,14 @@ using namespace wf;
 // ------------------------------------------------------------------------------------------------- errors
 static thread_local char g_err[512] = "";
 
+// Every reported failure advances this epoch.  The per-XCD ticket counters of the persistent last passes reset themselves only when
+// every work-group of a launch signs off; a context whose call failed anywhere in between (a launch error after the counters were
+// handed out, a HIP error of a later launch) clears them before their next use instead of trusting them: ensure_tickets compares.
+std::atomic<uint64_t> g_fail_epoch{0};
+uint64_t fail_epoch() { return g_fail_epoch.load(std::memory_order_relaxed); }
+
 int fail(int code, const char *fmt, ...) {
+    g_fail_epoch.fetch_add(1, std::memory_order_relaxed);
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
@@ -44,7 +53,8 @@ wf_tuning tuning_from_env() {
     t.no_tail_pack = getenv("WF_EXP_NO_TAIL_PACK") != nullptr;
     t.no_coset_inner = getenv("WF_EXP_NO_COSET_INNER") != nullptr;
     t.no_gtab = getenv("WF_EXP_NO_GTAB") != nullptr;
-    t.no_r32 = getenv("WF_EXP_NO_R32") != nullptr;
+    t.r32 = getenv("WF_EXP_R32") != nullptr;
+    t.no_staged_chunks = getenv("WF_EXP_NO_STAGED_CHUNKS") != nullptr;
     if (const char *e = getenv("WF_EXP_WIDE_TI")) {
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8) t.wide_ti = (uint32_t)v;
@@ -382,7 +392,7 @@ int wf_ctx_release_cached(wf_ctx *ctx) {
 int wf_ctx_synchronize(wf_ctx *ctx) {
     if (!ctx) return fail(WF_ERR_ARG, "ctx is null");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return path_device_error(ctx);
+    return 0;
 }
 
 void *wf_ctx_stream(wf_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }

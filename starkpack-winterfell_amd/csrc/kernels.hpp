@@ -243,6 +243,122 @@ __global__ void __launch_bounds__(256) k_hash_chunks(HashArgs<F> a, uint32_t chu
     dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
 }
 
+// The same chunk chaining values with every global access a whole 64-byte piece (round 5).  In k_hash_chunks a lane walks its own
+// row: consecutive lanes are a matrix row apart (256 bytes in the reference's example: 512 traces x 10 f128 columns, rows padded
+// to 16 elements), so each load instruction touches 64 lines for 16 bytes each and the kernel lives on the L1 keeping those lines
+// until the lane comes back for the next element -- which it does not with more than a few waves per CU (measured: 1.63 GB
+// fetched for 0.67 GB hashed).  Here a wave owns 16 consecutive rows x 4 chunks (item n: row n & 15, chunk slot n >> 4) and moves
+// one 64-byte block per item and step: FOUR lanes load the block of one item (16 bytes each: a 64-byte piece per quad, sixteen
+// quads = sixteen consecutive rows of one trace's matrix, i.e. one 4 KiB window per load instruction), the pieces cross a
+// wave-private 4 KiB LDS region (units XORed with (n >> 2) & 3: one lane per item reading 64 bytes at a 64-byte stride would
+// otherwise hit four banks sixteen times over), and every lane compresses the block of its own item.  Each element is fetched
+// once, whatever the L1 does.  Elements are loaded in 16-byte units: epr must be a multiple of 16 / sizeof(element) (always true
+// for f128; f64 matrices with an odd number of columns keep k_hash_chunks).
+// grid.x * 4 waves >= ceil(n_rows / 16) * ceil(chunks_per_row / 4); consecutive waves take consecutive row groups.
+template <class F>
+__global__ void __launch_bounds__(256) k_hash_chunks_staged(HashArgs<F> a, uint32_t chunks_per_row, uint32_t *cvs) {
+    typedef typename F::T T;
+    constexpr uint32_t EPB = 64 / F::BYTES, WPE = F::BYTES / 4, EPC = 1024 / F::BYTES, EPL = 16 / F::BYTES;
+    __shared__ uint4 stage[4][256];  // 4 KiB per wave
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint4 *sh = stage[wave];
+    const uint64_t row_groups = (a.n_rows + 15) >> 4;
+    const uint64_t gw = (uint64_t)blockIdx.x * 4 + wave;
+    const uint64_t rg = gw % row_groups, cg = gw / row_groups;
+    if (cg * 4 >= chunks_per_row) return;  // (whole wave: no work-group barrier below)
+    const uint64_t total_elems = (uint64_t)a.n_traces * a.epr;
+
+    // loader role: quad q = row within the group, unit i of the item's block; one stream per chunk slot k
+    const uint32_t q = lane >> 2, i = lane & 3u;
+    const uint64_t lrow = rg * 16 + q;
+    const T *lp[4];
+    uint32_t lcol[4];
+    uint64_t lleft[4];  // elements from this lane's next unit to the end of its chunk (0: nothing more to load)
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint64_t c = cg * 4 + k;
+        const uint64_t e0 = c * EPC + (uint64_t)i * EPL;  // first element of this lane's unit in block 0
+        const bool live = lrow < a.n_rows && c < chunks_per_row && e0 < total_elems;
+        const uint64_t cend = (c + 1) * EPC < total_elems ? (c + 1) * EPC : total_elems;
+        const uint32_t t = live ? (uint32_t)(e0 / a.epr) : 0u;
+        lcol[k] = live ? (uint32_t)(e0 - (uint64_t)t * a.epr) : 0u;
+        lp[k] = a.lde + (uint64_t)t * a.trace_elems + (live ? lrow : 0) * a.row_width;
+        lleft[k] = live ? cend - e0 : 0;
+    }
+    auto fetch = [&](uint32_t k) -> uint4 {  // this lane's 16 bytes of the current block of slot k, then on to the next block
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (lleft[k]) {
+            v = *reinterpret_cast<const uint4 *>(lp[k] + lcol[k]);
+            if (EPL == 2 && lleft[k] == 1) v.z = v.w = 0u;  // (f64: the chunk ends on the first element of the unit)
+        }
+        lleft[k] = lleft[k] > EPB ? lleft[k] - EPB : 0;
+        lcol[k] += EPB;
+        while (lcol[k] >= a.epr) {  // into the next trace's matrix (same row)
+            lcol[k] -= a.epr;
+            lp[k] += a.trace_elems;
+        }
+        return v;
+    };
+    // hasher role: item = lane
+    const uint64_t hrow = rg * 16 + (lane & 15u), hc = cg * 4 + (lane >> 4);
+    const bool hlive = hrow < a.n_rows && hc < chunks_per_row;
+    const uint64_t he0 = hc * EPC;
+    const uint32_t celems = hlive ? (uint32_t)(total_elems - he0 < EPC ? total_elems - he0 : EPC) : 0u;
+    const uint32_t clen = celems * F::BYTES, nblocks = (clen + 63) >> 6;
+    uint32_t wave_blocks = nblocks;  // the wave steps until its longest item is done
+#pragma unroll
+    for (uint32_t o = 32; o > 0; o >>= 1) wave_blocks = max(wave_blocks, (uint32_t)__shfl_xor((int)wave_blocks, (int)o));
+    const uint32_t swz = (lane >> 2) & 3u;  // of the item this lane hashes
+    uint32_t cv[8];
+    b3::set_iv(cv);
+    uint4 r0 = fetch(0), r1 = fetch(1), r2 = fetch(2), r3 = fetch(3);
+    for (uint32_t b = 0; b < wave_blocks; b++) {
+        // pieces of item n = q + 16 k: unit i goes to n * 4 + (i ^ ((n >> 2) & 3)); (q + 16 k) >> 2 = (q >> 2) + 4 k: same low bits for every k
+        {
+            const uint32_t u = i ^ ((q >> 2) & 3u);
+            sh[(q + 0) * 4 + u] = r0;
+            sh[(q + 16) * 4 + u] = r1;
+            sh[(q + 32) * 4 + u] = r2;
+            sh[(q + 48) * 4 + u] = r3;
+        }
+        if (b + 1 < wave_blocks) {  // the next block is on its way while this one is compressed
+            r0 = fetch(0);
+            r1 = fetch(1);
+            r2 = fetch(2);
+            r3 = fetch(3);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        T ev[EPB];
+        uint4 *evq = reinterpret_cast<uint4 *>(ev);
+#pragma unroll
+        for (uint32_t w = 0; w < 4; w++) evq[w] = sh[lane * 4 + (w ^ swz)];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // (the region is rewritten by the next step)
+        if (b < nblocks) {
+            uint32_t m[16];
+#pragma unroll
+            for (uint32_t e = 0; e < EPB; e++) {
+                if (b * EPB + e < celems) {
+                    elem_words<F>(ev[e], &m[e * WPE]);
+                } else {
+#pragma unroll
+                    for (uint32_t w = 0; w < WPE; w++) m[e * WPE + w] = 0;
+                }
+            }
+            const uint32_t blen = clen - b * 64 < 64 ? clen - b * 64 : 64;
+            const uint32_t flags = (b == 0 ? (uint32_t)b3::CHUNK_START : 0u) | (b == nblocks - 1 ? (uint32_t)b3::CHUNK_END : 0u);
+            b3::compress(cv, m, (uint32_t)hc, (uint32_t)(hc >> 32), blen, flags);
+        }
+    }
+    if (hlive) {
+        uint4 *dst = reinterpret_cast<uint4 *>(cvs + (hrow * chunks_per_row + hc) * 8);
+        dst[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+        dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+    }
+}
+
 static __global__ void __launch_bounds__(256) k_hash_merge_chunks(const uint32_t *__restrict__ cvs, uint32_t chunks_per_row,
                                                            uint64_t n_rows, uint32_t *__restrict__ leaves, uint32_t digest_words) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

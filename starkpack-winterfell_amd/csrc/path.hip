@@ -205,12 +205,18 @@ static int seg_launch_dims(uint32_t logD, uint32_t &threads, size_t &lds, bool l
 
 static void launch_merge_chunks(hipStream_t st, const void *cvs, uint32_t n_chunks, uint64_t n_rows, void *leaves, uint32_t dw);
 
-// per-XCD ticket / exit counters of the persistent kernels + their error word; zeroed once (the kernels leave them at zero)
+// per-XCD ticket / exit counters of the persistent kernels: zeroed at first use (the kernels leave them at zero: the last work-group
+// to sign off resets them) and again whenever any call of the library has reported a failure since -- a launch that did not run
+// to its sign-off (a failed launch behind it, a fault) must not leave its counters to the next commitment
 static int ensure_tickets(wf_ctx *ctx, hipStream_t st) {
-    if (ctx->tickets.p) return 0;
-    int rc = ensure(ctx, ctx->tickets, 128);
-    if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(ctx->tickets.p, 0, 128, st));  // ordered on the launch stream (first use only)
+    const uint64_t epoch = fail_epoch();
+    if (ctx->tickets.p && ctx->tickets_epoch == epoch) return 0;
+    if (!ctx->tickets.p) {
+        int rc = ensure(ctx, ctx->tickets, 128);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemsetAsync(ctx->tickets.p, 0, 128, st));  // ordered on the launch stream, behind whatever used the counters before
+    ctx->tickets_epoch = epoch;
     return 0;
 }
 
@@ -396,7 +402,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         a.coset_inner = coset_inner(n_groups, ((uint64_t)run_cnt * a.O * a.I) / (ti ? ti : 1u));
         // f64 tiles of 2^10 rows: register-resident tiles, two radix-32 rounds, LDS as the exchange buffer only (seg_r32.hpp)
         bool r32 = false;
-        if constexpr (F::BYTES == 8) r32 = spec_ok && a.logD == 10 && !ctx->tune.no_r32;
+        if constexpr (F::BYTES == 8) r32 = spec_ok && a.logD == 10 && ctx->tune.r32;
         if (r32) {
             if constexpr (F::BYTES == 8) {
                 const void *kr = d.rows_out ? (const void *)k_seg_strided_r32<1> : (const void *)k_seg_strided_r32<0>;
@@ -575,7 +581,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             // ... or, for that shape, the register-resident form (seg_r32.hpp): 256 threads, 72 KiB
             bool r32_last = false;
             if constexpr (F::BYTES == 8) {
-                if (!chunked && !multi && !a.pad_traces && a.logD == 10 && !ctx->tune.no_specialized && !ctx->tune.no_r32) {
+                if (!chunked && !multi && !a.pad_traces && a.logD == 10 && !ctx->tune.no_specialized && ctx->tune.r32) {
                     kern = (const void *)k_seg_last_hash_r32;
                     r32_last = true;
                     threads = R32_NT;
@@ -689,6 +695,15 @@ static int run_hash_rows(wf_ctx *ctx, hipStream_t st, const void *lde, uint64_t 
         // 16-byte elements a row apart (256 bytes in the reference's example), and more resident waves only evict each other's
         // lines from the 32 KiB L1 -- 512 x 2^10 x 10 f128: 0.387 -> 0.343 ms for the hashing launches, other shapes unchanged
         // (profiles/r04_attribution.txt)
+        // (round 5) 16-byte units that never straddle two traces' rows: the staged form -- a wave takes 16 rows x 4 chunks, quads of
+        // lanes load 64-byte pieces, one lane per (row, chunk) hashes from a wave-private LDS region (kernels.hpp)
+        constexpr uint32_t EPL = 16 / F::BYTES;
+        if (epr % EPL == 0 && !ctx->tune.no_staged_chunks) {
+            const uint64_t waves = ((n_rows + 15) / 16) * ((chunks + 3) / 4);
+            if ((waves + 3) / 4 > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "rows too long for one launch");
+            hipLaunchKernelGGL(k_hash_chunks_staged<F>, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, st, h, (uint32_t)chunks,
+                               (uint32_t *)ctx->hash_tmp.p);
+        } else
         hipLaunchKernelGGL(k_hash_chunks<F>, dim3((uint32_t)g2), dim3(threads), 40 * 1024, st, h, (uint32_t)chunks,
                            (uint32_t *)ctx->hash_tmp.p);
         HIP_TRY(hipGetLastError());
@@ -1509,15 +1524,6 @@ int path_digests_from_host(wf_ctx *ctx, hipStream_t st, const void *host, void *
     hipLaunchKernelGGL(k_digests_unpack24, dim3((uint32_t)((4 * n + 255) / 256)), dim3(256), 0, st, (const uint2 *)ctx->pack_tmp.p, (uint2 *)d_slots, (uint64_t)n);
     HIP_TRY(hipGetLastError());
     return 0;
-}
-
-int path_device_error(wf_ctx *ctx) {
-    if (!ctx->tickets.p) return 0;
-    uint32_t err = 0;
-    HIP_TRY(hipMemcpy(&err, (const char *)ctx->tickets.p + 64, 4, hipMemcpyDeviceToHost));
-    if (!err) return 0;
-    (void)hipMemset((char *)ctx->tickets.p + 64, 0, 4);
-    return fail(WF_ERR_HIP, "a persistent kernel gave up waiting for the chaining values of a preceding block (internal error)");
 }
 
 int path_trace_commit_sharded(wf_comm *c, const wf_params *p, const void *d_trace, void *d_polys, void *d_lde_shard,

@@ -9,8 +9,7 @@
 
 using namespace wf;
 
-// completes an asynchronous commitment: waits for its kernels, fetches the root and the device error word that travelled
-// with it, gives the pinned slot back.  May run on a thread that holds no call on the context (a finaliser destroying a
+// completes an asynchronous commitment: waits for its kernels, fetches the root from its pinned slot, gives the slot back.  May run on a thread that holds no call on the context (a finaliser destroying a
 // pending handle): the context is touched only under the registry's lock (CtxPin), its slot table under pool_mutex.
 static int commitment_wait(wf_commitment *c) {
     if (!c->pending) return 0;
@@ -20,25 +19,15 @@ static int commitment_wait(wf_commitment *c) {
         const hipError_t e = hipEventSynchronize(c->done);  // (the event is the handle's own: no context needed to wait for it)
         if (e != hipSuccess) rc = fail(WF_ERR_HIP, "the commitment's kernels failed: %s", hipGetErrorString(e));
     }
-    bool device_error = false;
     {
         CtxPin pin(c->ctx, c->ctx_generation);
         if (pin.alive && c->root_slot1) {
             const uint8_t *slot = c->ctx->root_pin + (size_t)(c->root_slot1 - 1) * WF_ROOT_SLOT_BYTES;
-            if (rc == 0) {
-                memcpy(c->root, slot, 32);
-                uint32_t err;
-                memcpy(&err, slot + 32, 4);
-                device_error = err != 0;
-            }
+            if (rc == 0) memcpy(c->root, slot, 32);
             std::lock_guard<std::mutex> lock(c->ctx->pool_mutex);
             c->ctx->root_used[c->root_slot1 - 1] = 0;
         }
     }
-    // a persistent kernel of this commitment flagged a chaining time-out: the leaves are wrong (path_device_error also
-    // clears the flag, so that it is not blamed on the context's next commitment)
-    if (device_error && ctx_alive(c->ctx, c->ctx_generation)) rc = path_device_error(c->ctx);
-    if (device_error && rc == 0) rc = fail(WF_ERR_HIP, "a persistent kernel of this commitment reported an internal error");
     if (c->done) (void)hipEventDestroy(c->done);
     c->done = nullptr;
     c->root_slot1 = 0;
@@ -151,10 +140,6 @@ static int commit_resident(wf_ctx *ctx, const wf_params *p, bool constraint, con
         free_commitment(c);
         return fail(WF_ERR_HIP, "commitment failed: %s", hipGetErrorString(e));
     }
-    if ((rc = path_device_error(ctx))) {
-        free_commitment(c);
-        return rc;
-    }
     *out = c;
     return 0;
 }
@@ -239,11 +224,6 @@ static int commit_resident_async(wf_ctx *ctx, const wf_params *p, const void *co
         rc = path_trace_commit(ctx, p, ctx->stage[sb].p, c->polys, c->lde, c->leaves, c->nodes, st, ctx->stage_free[sb]);
     uint8_t *slot = ctx->root_pin + (size_t)(slot1 - 1) * WF_ROOT_SLOT_BYTES;
     if (rc == 0 && e == hipSuccess) e = hipMemcpyAsync(slot, (char *)c->nodes + 32, 32, hipMemcpyDeviceToHost, st);
-    // the persistent kernels' error word (word 16 of the ticket block) travels with the root: wf_commitment_wait reports a
-    // chaining time-out of THIS commitment without another round trip
-    memset(slot + 32, 0, 4);
-    if (rc == 0 && e == hipSuccess && ctx->tickets.p)
-        e = hipMemcpyAsync(slot + 32, (const char *)ctx->tickets.p + 64, 4, hipMemcpyDeviceToHost, st);
     if (rc == 0 && e == hipSuccess) e = hipEventRecord(c->done, st);
     if (rc || e != hipSuccess) {
         // whatever was queued from the caller's columns or into this handle's buffers must have drained before either goes away
@@ -853,7 +833,6 @@ int wf_trace_commit_sharded_resident(wf_comm *comm, const wf_params *p, const vo
     if (rc == 0 && hipMemcpyAsync(top_pin, ctx->io[4].p, c->top.size(), hipMemcpyDeviceToHost, st) != hipSuccess)
         rc = fail(WF_ERR_HIP, "commitment failed: %s", hipGetErrorString(hipGetLastError()));
     if (rc == 0) rc = comm_wait(comm, st);  // (with the watchdog: a peer that failed inside the exchanges never arrives)
-    if (rc == 0) rc = path_device_error(ctx);
     if (rc) {
         // (after a time-out the kernels behind the dead exchange may still hold these buffers: they go back to the driver
         // through hipFree, which waits for the device, not into the pool)

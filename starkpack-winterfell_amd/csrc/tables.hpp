@@ -8,6 +8,21 @@
 
 using namespace wf;
 
+// One table to the device: allocated through dev_malloc (which gives the context's parked buffers back to the driver and retries
+// when the device is full), filled synchronously, and freed again if the copy fails -- a cached table is either complete or absent.
+static int table_upload(wf_ctx *ctx, void **dst, const void *src, size_t bytes) {
+    *dst = nullptr;
+    hipError_t e = dev_malloc(ctx, dst, bytes);
+    if (e != hipSuccess) return fail(WF_ERR_HIP, "table allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(*dst);
+        *dst = nullptr;
+        return fail(WF_ERR_HIP, "table upload failed: %s", hipGetErrorString(e));
+    }
+    return 0;
+}
+
 template <class F>
 static int upload_pow2l(wf_ctx *ctx, const std::vector<typename F::T> &bases, uint32_t logN, TableSet &ts) {
     // for each base g: lo[e] = g^e (e < 2^s), hi[h] = g^(h * 2^s) (h < 2^(logN - s))
@@ -28,11 +43,13 @@ static int upload_pow2l(wf_ctx *ctx, const std::vector<typename F::T> &bases, ui
             acc = F::mul(acc, gs);
         }
     }
-    HIP_TRY(hipMalloc(&ts.lo, lo.size() * sizeof(T)));
-    HIP_TRY(hipMalloc(&ts.hi, hi.size() * sizeof(T)));
-    HIP_TRY(hipMemcpyAsync(ts.lo, lo.data(), lo.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ts.hi, hi.data(), hi.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));  // host vectors die at return
+    int rc = table_upload(ctx, &ts.lo, lo.data(), lo.size() * sizeof(T));
+    if (rc) return rc;
+    if ((rc = table_upload(ctx, &ts.hi, hi.data(), hi.size() * sizeof(T)))) {
+        (void)hipFree(ts.lo);
+        ts.lo = nullptr;
+        return rc;
+    }
     ts.s = s;
     ts.mask = (uint32_t)(nlo - 1);
     ts.lo_stride = nlo;
@@ -118,10 +135,12 @@ static int series_tables(wf_ctx *ctx, uint32_t logN, typename F::T offset, uint6
             acc = F::mul(acc, gs);
         }
         TableSet ts;
-        HIP_TRY(hipMalloc(&ts.lo, nlo * sizeof(T)));
-        HIP_TRY(hipMalloc(&ts.hi, nhi * sizeof(T)));
-        HIP_TRY(hipMemcpy(ts.lo, lo.data(), nlo * sizeof(T), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(ts.hi, hi.data(), nhi * sizeof(T), hipMemcpyHostToDevice));
+        int rcu = table_upload(ctx, &ts.lo, lo.data(), nlo * sizeof(T));
+        if (rcu) return rcu;
+        if ((rcu = table_upload(ctx, &ts.hi, hi.data(), nhi * sizeof(T)))) {
+            (void)hipFree(ts.lo);
+            return rcu;
+        }
         ts.s = s;
         ts.mask = (uint32_t)(nlo - 1);
         it = ctx->tables.emplace(key, ts).first;
@@ -147,8 +166,8 @@ static int digit_table(wf_ctx *ctx, uint32_t logD, bool inverse, const typename 
             acc = F::mul(acc, w);
         }
         TableSet ts;
-        HIP_TRY(hipMalloc(&ts.lo, tab.size() * sizeof(T)));
-        HIP_TRY(hipMemcpy(ts.lo, tab.data(), tab.size() * sizeof(T), hipMemcpyHostToDevice));
+        const int rcu = table_upload(ctx, &ts.lo, tab.data(), tab.size() * sizeof(T));
+        if (rcu) return rcu;
         it = ctx->tables.emplace(key, ts).first;
     }
     *out = (const typename F::T *)it->second.lo;
@@ -178,8 +197,8 @@ static int pass_factor_table(wf_ctx *ctx, uint32_t logN, uint32_t logD, uint32_t
             step = F::mul(step, base);
         }
         TableSet ts;
-        HIP_TRY(hipMalloc(&ts.lo, tab.size() * sizeof(T)));
-        HIP_TRY(hipMemcpy(ts.lo, tab.data(), tab.size() * sizeof(T), hipMemcpyHostToDevice));
+        const int rcu = table_upload(ctx, &ts.lo, tab.data(), tab.size() * sizeof(T));
+        if (rcu) return rcu;
         it = ctx->tables.emplace(key, ts).first;
     }
     *out = (const typename F::T *)it->second.lo;

@@ -31,6 +31,7 @@
 // ------------------------------------------------------------------------------------------------- errors (context.hip)
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 const char *last_error_text();
+uint64_t fail_epoch();  // advanced by every fail(): see ensure_tickets (path.hip)
 
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
@@ -68,7 +69,8 @@ struct wf_tuning {
     size_t pipeline_min_bytes = (size_t)1 << 20;  // WF_EXP_PIPELINE_MIN_BYTES
     bool no_tail_pack = false;        // WF_EXP_NO_TAIL_PACK: a half-empty last segment evaluated like the others (not coset-packed)
     bool no_coset_inner = false;      // WF_EXP_NO_COSET_INNER: first strided evaluation pass with the coset as the outermost tile index
-    bool no_r32 = false;              // WF_EXP_NO_R32: 2^10-row f64 tiles through LDS round by round (seg_kernels.hpp) instead of register-resident (seg_r32.hpp)
+    bool no_staged_chunks = false;    // WF_EXP_NO_STAGED_CHUNKS: rows longer than a BLAKE3 chunk hashed by k_hash_chunks (a lane walks its own row) instead of k_hash_chunks_staged
+    bool r32 = false;                 // WF_EXP_R32: 2^10-row f64 tiles register-resident in two radix-32 rounds (seg_r32.hpp; measured slower: DESIGN.md section 9)
     bool no_gtab = false;             // WF_EXP_NO_GTAB: later wide strided passes rebuild their output factors in LDS per tile
     uint32_t wide_ti = 0;             // WF_EXP_WIDE_TI: inner positions per tile of the wide strided pass of 3+-pass plans (2, 4, 8); 1 = never; 0 = planner's own (2)
     int fail_after_segment = -1;      // WF_EXP_FAIL_AFTER_SEGMENT: the pipelined upload fails after that many segments (error-path test)
@@ -96,7 +98,8 @@ struct wf_ctx {
     DevBuf scratch;   // evaluation intermediate [cosets][columns][R]
     DevBuf io[5];     // staging for the host-buffer API: trace, polys, lde, leaves, nodes
     DevBuf hash_tmp;  // chunk chaining values of rows longer than one BLAKE3 chunk
-    DevBuf tickets;   // per-XCD tile counters of the persistent last passes (+ word 16: their error flag)
+    DevBuf tickets;   // per-XCD ticket + exit counters of the persistent last passes (self-resetting; cleared again after any reported failure)
+    uint64_t tickets_epoch = 0;  // fail_epoch() when the counters were last cleared
     // Buffers of destroyed resident commitments, kept for the next commitment of the same shape (four hipFree + four
     // hipMalloc of 64..512 MiB cost about as much as the commitment itself); released by wf_ctx_release_cached / destroy.
     // Guarded by pool_mutex: a handle may be destroyed by another thread (a finaliser, Rust's Drop) while a call runs.
@@ -257,7 +260,6 @@ static inline void copy_digests_out(void *dst, const void *slots, size_t n, uint
 }
 // after a synchronisation: WF_ERR_HIP if a persistent kernel of this context flagged a chaining time-out (cannot happen
 // while the whole grid is resident; the flag exists so that a wrong assumption shows up as an error, not as wrong leaves)
-int path_device_error(wf_ctx *ctx);
 // one packed commitment sharded over the ranks of a communicator (segment-sharded interpolation, coset-sharded evaluation)
 int path_trace_commit_sharded(wf_comm *c, const wf_params *p, const void *d_trace, void *d_polys, void *d_lde_shard,
                               void *d_leaves, void *d_nodes, void *d_top, hipStream_t st);

@@ -111,3 +111,36 @@ def test_tail_packed_2_9_row_tiles_and_blake3_192(forced9, orc, capi):
         assert np.array_equal(lde.reshape(-1), np.ascontiguousarray(want["lde"][0]).reshape(-1))
         assert np.array_equal(leaves[:, :24], want["leaves"]) and not leaves[:, 24:].any()
         assert np.array_equal(nodes[1:, :24], want["nodes"][1:])
+
+
+@pytest.mark.parametrize("field,logR,n_cols,world", [(F128, 14, 10, 2), (F64, 14, 10, 4), (F128, 14, 6, 4)])
+def test_tail_packed_coset_shards_match_the_oracle(forced, orc, capi, field, logR, n_cols, world):
+    """The tail-packed route through wf_trace_commit_shard_dev with coset0 != 0 (a rank of a coset-sharded commitment evaluates
+    blowup / W cosets: the tail work region sits behind n_cosets * (n_seg - 1) segments of the SHARD's work buffer and the leaf
+    slots that park the first coset's chaining values are the shard's own rows).  Every shard's LDE rows (padding written into
+    poisoned buffers) and leaves against the oracle's unsharded commitment."""
+    import torch
+    from starkpack_winterfell_amd import shard
+    logB = 3
+    rng = np.random.default_rng(field * 1000 + n_cols * 10 + world)
+    R, blowup = 1 << logR, 1 << logB
+    cols = rand_cols(rng, field, n_cols, R)
+    want = orc.build_trace_commitment(field, [cols], 1, logR, logB, 7 if field == F64 else 3)
+    params = capi.make_params(field, 1, logR, logB, n_cols, 1)
+    w = 1 if field == F64 else 2
+    rw = 8 * ((n_cols + 7) // 8)
+    dev = torch.device("cuda", 0)
+    d_trace = torch.from_numpy(np.concatenate([c.reshape(-1) for c in cols]).view(np.int64)).to(dev)
+    full = want["lde"][0].reshape((R, blowup, rw) + ((2,) if w == 2 else ()))
+    leaves_full = want["leaves"].reshape(R, blowup, 32)
+    for rank in range(world):
+        c0, nc = shard.cosets_of_rank(blowup, rank, world)
+        d_polys = torch.empty_like(d_trace)
+        d_lde = torch.full((R * nc * rw * w,), -1, dtype=torch.int64, device=dev)
+        d_leaves = torch.full((R * nc, 32), 0xEE, dtype=torch.uint8, device=dev)
+        for _ in range(2):
+            forced.trace_commit_shard_dev(params, c0, nc, d_trace.data_ptr(), d_polys.data_ptr(), d_lde.data_ptr(), d_leaves.data_ptr())
+            forced.synchronize()
+        lde = d_lde.cpu().numpy().view(np.uint64).reshape((R, nc, rw) + ((2,) if w == 2 else ()))
+        assert np.array_equal(lde, full[:, c0:c0 + nc]), f"rank {rank}"
+        assert np.array_equal(d_leaves.cpu().numpy().reshape(R, nc, 32), leaves_full[:, c0:c0 + nc]), f"rank {rank}"
