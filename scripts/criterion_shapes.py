@@ -85,14 +85,19 @@ for name, field, ext in (("f64", capi.F64, 1), ("f64_quad", capi.F64, 2), ("f128
         small = rng.integers(0, 2**62, size=(size // 8) * ext * w, dtype=np.uint64)
         full = np.zeros(size * ext * w, dtype=np.uint64)
         full[:small.size] = small
-        ms = host_time(lambda: ctx.fft_evaluate_poly(field, ext, full))
+        # in place on a reused buffer, as the reference's `&mut [E]` entry points work (round 5: the Python wrapper's default of copying
+        # into a FRESH array per call put ~3 ms of page faults into the 32 MiB shapes -- glibc mmaps allocations from 32 MiB up --
+        # which round 4's table showed as a "5 x for 2 x the size" jump; the library's own transfers are linear in size)
+        work = full.copy()
+        ms = host_time(lambda: ctx.fft_evaluate_poly(field, ext, work, inplace=True))
         say(f"{name}/fft_evaluate_poly/simple/{size}: {ms:.3f} ms")
-        ms = host_time(lambda: ctx.fft_evaluate_poly_with_offset(field, ext, small, 7 if field == capi.F64 else 3, 8))
+        res = np.empty(size * ext * w, dtype=np.uint64).reshape((-1, w) if w > 1 else (-1,))
+        ms = host_time(lambda: ctx.fft_evaluate_poly_with_offset(field, ext, small, 7 if field == capi.F64 else 3, 8, out=res))
         say(f"{name}/fft_evaluate_poly/with_offset/{size}: {ms:.3f} ms")
         ev = rng.integers(0, 2**62, size=size * ext * w, dtype=np.uint64)
-        ms = host_time(lambda: ctx.fft_interpolate_poly(field, ext, ev))
+        ms = host_time(lambda: ctx.fft_interpolate_poly(field, ext, ev, inplace=True))
         say(f"{name}/fft_interpolate_poly/simple/{size}: {ms:.3f} ms")
-        ms = host_time(lambda: ctx.fft_interpolate_poly_with_offset(field, ext, ev, 7 if field == capi.F64 else 3))
+        ms = host_time(lambda: ctx.fft_interpolate_poly_with_offset(field, ext, ev, 7 if field == capi.F64 else 3, inplace=True))
         say(f"{name}/fft_interpolate_poly/with_offset/{size}: {ms:.3f} ms")
 
 say("# crypto/benches/merkle.rs merkle tree construction (Blake3_256), device-resident")

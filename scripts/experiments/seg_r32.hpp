@@ -1,3 +1,10 @@
+// EXPERIMENT, NOT PART OF THE PRODUCT BUILD (round 5; docs/EXPERIMENTS.md "register-resident radix-32 tiles").  Bit-exact (the cfg 2
+// oracle comparison and the parity suites passed with it), measured SLOWER than the LDS-resident pair it would replace: strided pass
+// 358.7 -> 375.1 us with 3.8 % FEWER vector instructions, fused last pass 541 -> 587 us with 9 % more (profiles/r05_r32.txt) -- at two
+// waves per SIMD a wave's own issue rate (one instruction per ~4-5 cycles, ~20 % of them hazard s_nops behind carry chains) no
+// longer covers the SIMD.  Commit af968a6 has it wired into path.hip (WF_EXP_NO_R32 selected the old kernels); to try it again:
+// put this file back into csrc/, #include it after seg_kernels.hpp and restore that commit's two launcher hunks.
+//
 // Register-resident 2^10-row f64 tiles: two radix-32 rounds, LDS as the exchange buffer only (round 5).
 //
 // The segment kernels of seg_kernels.hpp keep a tile in LDS and walk it round by round (radix 16, 16, 4 for 2^10 rows: the tile

@@ -50,7 +50,7 @@ KERNEL(k_mad64_const0, asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p)
 // round 4: the conditional move with its mask in an SGPR pair that nothing in the loop writes (the round-3 line above clobbers VCC in
 // every statement, so hipcc puts an s_nop between the statements and the figure is not the instruction's); compare + select as the
 // field code issues them; carry-in additions alone; and the double-precision pipe (a 104-bit product from two FMAs is the candidate
-// for a cheaper f128 product: DESIGN.md section 7c)
+// for a cheaper f128 product: docs/STATUS.md section 7c)
 __global__ void k_cndmask_sgpr(uint32_t *out, int iters) {
     uint32_t a = threadIdx.x, b = a * 3 + 1, c = a ^ 0x55, d = a + 7;
     const uint64_t mask = __builtin_amdgcn_read_exec() ^ (0x5555555555555555ull * (uint64_t)(iters & 1));

@@ -505,29 +505,40 @@ class Context:
         return out
 
     # -- building blocks -----------------------------------------------------------------------------------------
-    def fft_evaluate_poly(self, field, ext, poly: np.ndarray) -> np.ndarray:
-        a = np.ascontiguousarray(poly, dtype=np.uint64).copy()
+    def fft_evaluate_poly(self, field, ext, poly: np.ndarray, inplace: bool = False) -> np.ndarray:
+        """inplace=True: transform the caller's (contiguous uint64) array where it lies, as the reference's `&mut [E]` entry point
+        does -- no fresh array per call (a fresh 32 MiB numpy allocation alone costs ~3 ms of page faults: glibc mmaps it)."""
+        a = np.ascontiguousarray(poly, dtype=np.uint64)
+        if not inplace or a is not poly:
+            a = a.copy()
         n = a.size // (ELEM_WORDS[field] * ext)
         _check(load().wf_fft_evaluate_poly(self._h, field, ext, _p(a), n))
         return a
 
-    def fft_interpolate_poly(self, field, ext, evals: np.ndarray) -> np.ndarray:
-        a = np.ascontiguousarray(evals, dtype=np.uint64).copy()
+    def fft_interpolate_poly(self, field, ext, evals: np.ndarray, inplace: bool = False) -> np.ndarray:
+        """inplace=True: transform the caller's (contiguous uint64) array where it lies, as the reference's `&mut [E]` entry point
+        does -- no fresh array per call (a fresh 32 MiB numpy allocation alone costs ~3 ms of page faults: glibc mmaps it)."""
+        a = np.ascontiguousarray(evals, dtype=np.uint64)
+        if not inplace or a is not evals:
+            a = a.copy()
         n = a.size // (ELEM_WORDS[field] * ext)
         _check(load().wf_fft_interpolate_poly(self._h, field, ext, _p(a), n))
         return a
 
-    def fft_interpolate_poly_with_offset(self, field, ext, evals: np.ndarray, offset: int) -> np.ndarray:
-        a = np.ascontiguousarray(evals, dtype=np.uint64).copy()
+    def fft_interpolate_poly_with_offset(self, field, ext, evals: np.ndarray, offset: int, inplace: bool = False) -> np.ndarray:
+        a = np.ascontiguousarray(evals, dtype=np.uint64)
+        if not inplace or a is not evals:
+            a = a.copy()
         n = a.size // (ELEM_WORDS[field] * ext)
         _check(load().wf_fft_interpolate_poly_with_offset(self._h, field, ext, _p(a), n, _off16(offset)))
         return a
 
-    def fft_evaluate_poly_with_offset(self, field, ext, poly: np.ndarray, offset: int, blowup: int) -> np.ndarray:
+    def fft_evaluate_poly_with_offset(self, field, ext, poly: np.ndarray, offset: int, blowup: int, out: np.ndarray = None) -> np.ndarray:
         a = np.ascontiguousarray(poly, dtype=np.uint64)
         w = ELEM_WORDS[field]
         n = a.size // (w * ext)
-        out = np.empty((n * blowup * ext, w) if w > 1 else (n * blowup * ext,), dtype=np.uint64)
+        if out is None:  # (callers that time the call pass a preallocated result)
+            out = np.empty((n * blowup * ext, w) if w > 1 else (n * blowup * ext,), dtype=np.uint64)
         _check(load().wf_fft_evaluate_poly_with_offset(self._h, field, ext, _p(a), n, _off16(offset), blowup, _p(out)))
         return out
 

@@ -53,7 +53,6 @@ wf_tuning tuning_from_env() {
     t.no_tail_pack = getenv("WF_EXP_NO_TAIL_PACK") != nullptr;
     t.no_coset_inner = getenv("WF_EXP_NO_COSET_INNER") != nullptr;
     t.no_gtab = getenv("WF_EXP_NO_GTAB") != nullptr;
-    t.r32 = getenv("WF_EXP_R32") != nullptr;
     t.no_staged_chunks = getenv("WF_EXP_NO_STAGED_CHUNKS") != nullptr;
     if (const char *e = getenv("WF_EXP_WIDE_TI")) {
         const int v = atoi(e);

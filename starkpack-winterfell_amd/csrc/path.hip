@@ -5,7 +5,6 @@
 
 #include "kernels.hpp"
 #include "seg_kernels.hpp"
-#include "seg_r32.hpp"
 #include "col_kernels.hpp"
 #include "fri_kernels.hpp"
 #include "tables.hpp"
@@ -380,7 +379,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         prof_mark(ctx, st, tag_s);
         // f64 tiles of 2^10 and 2^9 rows (the digits of the 2^17 .. 2^21 plans) run the tile-size-specialised instantiations
         // (seg_kernels.hpp, WF_TILE_BOUNDS: strided pass of cfg 2 0.347 -> 0.324 ms); everything else the generic kernel
-        // (2^7 / 2^8-row tiles and the f128 tiles measured slower or the same specialised: DESIGN.md section 9).
+        // (2^7 / 2^8-row tiles and the f128 tiles measured slower or the same specialised: docs/EXPERIMENTS.md).
         const bool spec_ok = F::BYTES == 8 && !packed && threads * 2 == (1u << a.logD) && !ctx->tune.no_specialized;
         const void *kern = nullptr;
         if (spec_ok) {
@@ -400,18 +399,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             if (ti < 2 || ((1u << a.logD) * ti * SegCfg<F>::S) / 16 < 64) ti = 0;
         }
         a.coset_inner = coset_inner(n_groups, ((uint64_t)run_cnt * a.O * a.I) / (ti ? ti : 1u));
-        // f64 tiles of 2^10 rows: register-resident tiles, two radix-32 rounds, LDS as the exchange buffer only (seg_r32.hpp)
-        bool r32 = false;
-        if constexpr (F::BYTES == 8) r32 = spec_ok && a.logD == 10 && ctx->tune.r32;
-        if (r32) {
-            if constexpr (F::BYTES == 8) {
-                const void *kr = d.rows_out ? (const void *)k_seg_strided_r32<1> : (const void *)k_seg_strided_r32<0>;
-                const size_t lds_r = ((size_t)R32_D * SegCfg<F>::S + 2 * R32_D) * sizeof(T);
-                HIP_TRY(hipFuncSetAttribute(kr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                void *kargs[] = {&a};
-                HIP_TRY(hipLaunchKernel(kr, dim3((uint32_t)grid), dim3(R32_NT), kargs, lds_r, st));
-            }
-        } else if (ti) {
+        if (ti) {
             if constexpr (F::BYTES == 8) {
                 const void *kw = ti == 8 ? (d.rows_out ? (const void *)k_seg_strided_wide<F, 1, 8> : (const void *)k_seg_strided_wide<F, 0, 8>)
                                : ti == 4 ? (d.rows_out ? (const void *)k_seg_strided_wide<F, 1, 4> : (const void *)k_seg_strided_wide<F, 0, 4>)
@@ -578,17 +566,6 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             // ... and in 2^8-row tiles (2^17 x 32: last pass 0.278 -> 0.259 ms)
             if (F::BYTES == 8 && !chunked && multi && !a.pad_traces && a.logD == 8 && small && !ctx->tune.no_specialized)
                 kern = (const void *)k_seg_last_hash<F, true, false, false, true, F::BYTES == 8 ? 8 : 0>;
-            // ... or, for that shape, the register-resident form (seg_r32.hpp): 256 threads, 72 KiB
-            bool r32_last = false;
-            if constexpr (F::BYTES == 8) {
-                if (!chunked && !multi && !a.pad_traces && a.logD == 10 && !ctx->tune.no_specialized && ctx->tune.r32) {
-                    kern = (const void *)k_seg_last_hash_r32;
-                    r32_last = true;
-                    threads = R32_NT;
-                    lds = ((size_t)R32_D * SegCfg<F>::S + R32_D) * sizeof(T);
-                }
-            }
-            (void)r32_last;
             if (chunked) {
                 int rcc = ensure(ctx, ctx->hash_tmp, (size_t)launch_rows * n_chunks * 32);
                 if (rcc) return rcc;

@@ -886,6 +886,10 @@ int wf_sharded_commitment_query(wf_sharded_commitment *c, const uint64_t *positi
     for (auto &v : vec_ids) ids.insert(ids.end(), v.begin(), v.end());
 
     wf_comm *comm = c->comm;
+    // refused at once, BEFORE the local stage below: it synchronises with the stream, and on a communicator that died in a
+    // timed-out collective the stream may still sit behind the exchange that never completed (round 5: this call used to block there
+    // until the stream drained and only then report the dead communicator)
+    if (comm->dead) return fail(WF_ERR_COMM, "the communicator was aborted after a failed or timed-out collective");
     wf_ctx *ctx = comm->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     WF_ENTER(ctx, ctx->stream);

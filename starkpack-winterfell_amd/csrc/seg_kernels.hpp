@@ -11,7 +11,7 @@
 // (o, d, i), d = 0..D-1, of one inner position i; the last pass handles D contiguous rows and scatters to natural
 // order.  Inside LDS (x[D][S]): radix-16 rounds with the 16 values of one lane in registers (f64), then radix-4 /
 // radix-2 rounds on two lanes per thread (16-byte LDS accesses for f64); f128 uses the radix-4 / radix-2 rounds only.
-// Work-groups have D/2 threads (one work item of the widest round each).  DESIGN.md §4 describes the kernels, §9 the
+// Work-groups have D/2 threads (one work item of the widest round each).  DESIGN.md §4 describes the kernels, docs/EXPERIMENTS.md the
 // variants that were measured and dropped (their code is in the history, not here).  A -DWF_EXPERIMENTS build
 // (scripts/exp_variants.sh) adds the time-attribution switches WF_EXP_SKIP_LOAD / _SKIP_NTT / _SKIP_STORE, the
 // wrong-output store orders WF_EXP_LOCAL_STORE and the phase stamps WF_EXP_STAMPS; the product build has none of them.

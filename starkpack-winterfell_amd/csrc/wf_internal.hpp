@@ -70,7 +70,6 @@ struct wf_tuning {
     bool no_tail_pack = false;        // WF_EXP_NO_TAIL_PACK: a half-empty last segment evaluated like the others (not coset-packed)
     bool no_coset_inner = false;      // WF_EXP_NO_COSET_INNER: first strided evaluation pass with the coset as the outermost tile index
     bool no_staged_chunks = false;    // WF_EXP_NO_STAGED_CHUNKS: rows longer than a BLAKE3 chunk hashed by k_hash_chunks (a lane walks its own row) instead of k_hash_chunks_staged
-    bool r32 = false;                 // WF_EXP_R32: 2^10-row f64 tiles register-resident in two radix-32 rounds (seg_r32.hpp; measured slower: DESIGN.md section 9)
     bool no_gtab = false;             // WF_EXP_NO_GTAB: later wide strided passes rebuild their output factors in LDS per tile
     uint32_t wide_ti = 0;             // WF_EXP_WIDE_TI: inner positions per tile of the wide strided pass of 3+-pass plans (2, 4, 8); 1 = never; 0 = planner's own (2)
     int fail_after_segment = -1;      // WF_EXP_FAIL_AFTER_SEGMENT: the pipelined upload fails after that many segments (error-path test)

@@ -64,7 +64,7 @@ def test_product_does_not_import_the_oracle():
 
 def test_transform_plans(capi):
     """The pass plans of the commitment path (wf_plan_digits, no GPU needed) -- each of these splits was chosen by
-    measurement; a change here is a performance change and should be deliberate."""
+    measurement (docs/EXPERIMENTS.md); a change here is a performance change and should be deliberate."""
     F64, F128 = 1, 2
     plan = capi.plan_digits
     assert plan(F64, 10) == [10] and plan(F128, 10) == [10] and plan(F64, 3) == [3]

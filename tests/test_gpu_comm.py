@@ -348,10 +348,12 @@ def test_watchdog_covers_the_blocking_calls_when_a_peer_never_arrives(orc, capi,
                 com.query(np.array([5, 9], dtype=np.uint64))
             waited = time.perf_counter() - t0
             out["query"] = (e.value.code, waited)
+            t1 = time.perf_counter()
             for call in (comm.barrier, lambda: comm.max_f64(1.0), lambda: com.query(np.array([5], dtype=np.uint64))):
                 with pytest.raises(capi.WfError) as e2:   # a dead communicator refuses further collectives at once
                     call()
                 out.setdefault("after", []).append(e2.value.code)
+            out["after_s"] = time.perf_counter() - t1   # "at once": while the stream is STILL blocked behind the dead exchange
             release.set()       # the stream drains: the copies queued behind the dead exchange run now
             ctx.synchronize()
             done.set()
@@ -368,6 +370,7 @@ def test_watchdog_covers_the_blocking_calls_when_a_peer_never_arrives(orc, capi,
     code, waited = out["query"]
     assert code == -32 and 1.5 < waited < 30, out
     assert out["after"] == [-32, -32, -32]
+    assert out["after_s"] < 5.0, out   # (round 5: the query used to wait for the blocked stream -- a minute here -- before refusing)
 
 
 def test_comm_info_and_gather_f64(capi):

@@ -143,7 +143,7 @@ def test_thread_route_gate_fires_on_a_corrupted_root(capi, mode):
 def test_thread_route_gives_up_on_a_rank_that_hangs(capi):
     capi.load()
     out = run_bench("--gpus", "2", "--ranks", "threads", "--steps", "1", "--warmup", "0", "--inject-fault", "hang",
-                    env_extra={"WF_BENCH_BACKEND": "loopback", "WF_BENCH_LAUNCH_TIMEOUT_S": "25", "WF_COMM_TIMEOUT_S": "60"}, timeout=300)
+                    env_extra={"WF_BENCH_BACKEND": "loopback", "WF_BENCH_LAUNCH_TIMEOUT_S": "15", "WF_COMM_TIMEOUT_S": "60"}, timeout=300)
     assert out.returncode == 124, out.stdout[-2000:] + out.stderr[-2000:]
     assert "did not finish within" in out.stderr
 
@@ -204,6 +204,6 @@ def test_launcher_gives_up_on_ranks_that_hang(capi):
     """The parent of `bench.py --gpus N` ends its ranks' process group at its wall-clock limit and exits non-zero."""
     capi.load()
     out = run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--inject-fault", "hang",
-                    env_extra={"WF_BENCH_BACKEND": "gloo", "WF_BENCH_LAUNCH_TIMEOUT_S": "20"}, timeout=300)
+                    env_extra={"WF_BENCH_BACKEND": "gloo", "WF_BENCH_LAUNCH_TIMEOUT_S": "15"}, timeout=300)
     assert out.returncode == 124, out.stdout[-2000:] + out.stderr[-2000:]
     assert "did not finish within" in out.stderr

@@ -12,11 +12,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-PARITY_SWITCHES = ["WF_EXP_MAX_DIGIT=5", "WF_EXP_MAX_DIGIT=7", "WF_EXP_MAX_DIGIT=5 WF_EXP_WIDE_TI=8", "WF_EXP_MAX_DIGIT=7 WF_EXP_WIDE_TI=1", "WF_EXP_NO_FUSED_HASH=1",
-                   "WF_EXP_NO_PERSISTENT=1", "WF_EXP_NO_CHUNKED=1", "WF_EXP_PERSISTENT_ALWAYS=1", "WF_EXP_NO_SPECIALIZED=1",
-                   "WF_EXP_NO_COSET_INNER=1 WF_EXP_MAX_DIGIT=7", "WF_EXP_NO_GTAB=1 WF_EXP_MAX_DIGIT=5 WF_EXP_WIDE_TI=8"]
+# The forced-plan runs.  CORE runs on every invocation (the switches that reach the most code that default shapes never see);
+# of the ROTATING ones a subset of ROTATE_PICK runs per day -- chosen by the date, printed in the test ids, so that a failure
+# names the switch -- unless WF_TEST_ALL_PLANS=1 (every switch: what scripts/random_soak.py and the end-of-round soaks in
+# profiles/ run).  The suite had grown to 14 child suites and 95 s of a 900 s limit; the oracle comparisons of the BASELINE
+# configurations (tests/test_gpu_fullsize.py, test_gpu_production_size.py) are not part of the rotation and always run.
+PARITY_CORE = ["WF_EXP_MAX_DIGIT=5", "WF_EXP_NO_FUSED_HASH=1", "WF_EXP_PERSISTENT_ALWAYS=1", "WF_EXP_NO_SPECIALIZED=1"]
+PARITY_ROTATING = ["WF_EXP_MAX_DIGIT=7", "WF_EXP_MAX_DIGIT=5 WF_EXP_WIDE_TI=8", "WF_EXP_MAX_DIGIT=7 WF_EXP_WIDE_TI=1", "WF_EXP_NO_PERSISTENT=1",
+                   "WF_EXP_NO_CHUNKED=1", "WF_EXP_NO_CHUNKED=1 WF_EXP_NO_STAGED_CHUNKS=1", "WF_EXP_NO_COSET_INNER=1 WF_EXP_MAX_DIGIT=7",
+                   "WF_EXP_NO_GTAB=1 WF_EXP_MAX_DIGIT=5 WF_EXP_WIDE_TI=8"]
+RESIDENT_CORE = ["WF_EXP_PIPELINE_MIN_BYTES=0 WF_EXP_MAX_DIGIT=5"]
+RESIDENT_ROTATING = ["WF_EXP_PIPELINE_MIN_BYTES=0", "WF_EXP_NO_PIPELINE=1"]
+ROTATE_PICK = 3
+
+
+def _todays(rotating, pick):
+    if os.environ.get("WF_TEST_ALL_PLANS") == "1":
+        return list(rotating)
+    import datetime
+    day = int(os.environ.get("WF_TEST_PLAN_DAY", datetime.date.today().toordinal()))
+    return [rotating[(day * pick + k) % len(rotating)] for k in range(min(pick, len(rotating)))]
+
+
+PARITY_SWITCHES = PARITY_CORE + _todays(PARITY_ROTATING, ROTATE_PICK)
 PARITY_FILES = ["test_gpu_coset_shard.py", "test_gpu_parity.py", "test_gpu_golden.py"]
-RESIDENT_SWITCHES = ["WF_EXP_PIPELINE_MIN_BYTES=0", "WF_EXP_PIPELINE_MIN_BYTES=0 WF_EXP_MAX_DIGIT=5", "WF_EXP_NO_PIPELINE=1"]
+RESIDENT_SWITCHES = RESIDENT_CORE + _todays(RESIDENT_ROTATING, 1)
 RESIDENT_FILES = ["test_gpu_queries.py", "test_gpu_deep.py", "test_gpu_pipeline.py", "test_gpu_wide_resident.py"]
 
 

@@ -70,8 +70,10 @@ def test_bench_other_configs_print_the_same_line(capi, config):
     """bench.py --config: the f128 workloads print the contract's line with in-run `alu` rates and pass their CPU-oracle
     root gate (cfg3 -- 2^22 x 64 -- runs the same code at a size kept for the profiling scripts)."""
     capi.load()
+    env = dict(os.environ)
+    env["WF_BENCH_CPU_QUICK"] = "1"  # one CPU commitment (the root gate below needs no thread sweep: it took 47 s of the suite for dowork)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "2", "--warmup", "1"],
-                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert j["config"]["name"] == config and j["config"]["field"] == "f128"
