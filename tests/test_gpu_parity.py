@@ -108,6 +108,12 @@ CASES = [
     (F128, 1, 3, 1, 10, 206),  # 33 chunks: an unpaired chaining value is carried up at several levels
     (F128, 1, 4, 1, 10, 250),  # 40 chunks
     (F64, 1, 4, 1, 255, 17),   # 34 chunks of f64 rows
+    # single-pass plans with rows longer than a chunk and an EVEN number of f64 columns: k_hash_chunks_staged on 16-byte units of two
+    # f64 elements (odd widths -- 255 above -- keep k_hash_chunks); rows / chunk groups that do not fill a wave's 16 rows x 4 chunks
+    (F64, 1, 9, 1, 6, 40),     # 40 traces x 6 columns: 1920-byte rows, a short second chunk, blocks that straddle two traces' rows
+    (F64, 1, 3, 2, 8, 40),     # 32 LDE rows x 3 chunks (2560 bytes): fewer chunks than a wave's four slots
+    (F64, 2, 5, 1, 5, 13),     # quadratic extension: 10 base columns per trace, 1040-byte rows (one 16-byte unit in the second chunk)
+    (F128, 1, 5, 2, 3, 30),    # f128: 1440-byte rows, three columns per trace (blocks straddle up to three traces)
 ]
 
 
