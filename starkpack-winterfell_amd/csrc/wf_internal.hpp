@@ -128,7 +128,7 @@ struct wf_ctx {
     hipEvent_t stage_free[2] = {nullptr, nullptr}, upload_done[2] = {nullptr, nullptr};
     bool stage_busy[2] = {false, false};
     uint64_t async_seq = 0;
-    uint8_t *root_pin = nullptr;       // WF_ROOT_SLOTS slots of WF_ROOT_SLOT_BYTES: the root, then the device error word behind that commitment
+    uint8_t *root_pin = nullptr;       // WF_ROOT_SLOTS slots of WF_ROOT_SLOT_BYTES: the root of an asynchronous commitment (pinned: wf_commitment_wait reads it without a copy)
     std::vector<uint8_t> root_used;    // guarded by pool_mutex (slots are handed back by whatever thread completes a handle)
     uint64_t generation = 0;  // distinguishes this context from an earlier one at the same address (stale handles)
 };
@@ -257,8 +257,6 @@ static inline void copy_digests_out(void *dst, const void *slots, size_t n, uint
     }
     for (size_t i = 0; i < n; i++) memcpy((char *)dst + i * digest_bytes, (const char *)slots + i * 32, digest_bytes);
 }
-// after a synchronisation: WF_ERR_HIP if a persistent kernel of this context flagged a chaining time-out (cannot happen
-// while the whole grid is resident; the flag exists so that a wrong assumption shows up as an error, not as wrong leaves)
 // one packed commitment sharded over the ranks of a communicator (segment-sharded interpolation, coset-sharded evaluation)
 int path_trace_commit_sharded(wf_comm *c, const wf_params *p, const void *d_trace, void *d_polys, void *d_lde_shard,
                               void *d_leaves, void *d_nodes, void *d_top, hipStream_t st);
