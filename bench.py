@@ -416,7 +416,13 @@ def with_transfers(ctx, capi, params, trace_host, gpu_root):
     def streamed(columns, n=12, repeats=5):
         """Median and minimum ms per commitment over `repeats` batches of n (round 5: one batch was too thin a sample -- on a fresh
         box a single hiccup of ~30 ms inside the one timed batch read as 3.8 ms per commitment against 1.4 everywhere else)."""
-        warm = ctx.trace_commit_resident_batch(params, [columns] * 2)
+        # warm-up at the FULL depth of a batch: with pinned columns the asynchronous call returns in 0.1 ms, so the first batch is the first
+        # time ~300 operations (12 commitments x copies, kernels, events) are outstanding on the two streams together, and the runtime
+        # stalls once on it -- 55 ms to 1.3 s for one commitment's wait in scripts/stream_probe.py / the round-5 record
+        # (profiles/r05_stream_probe.txt); a warm-up of two commitments did not reach that depth.  Reported, not hidden: warmup_ms_per_commit.
+        t0 = time.perf_counter()
+        warm = ctx.trace_commit_resident_batch(params, [columns] * n)
+        warm_ms = (time.perf_counter() - t0) * 1e3 / n
         for c in warm:
             c.close()
         per, ok = [], True
@@ -428,7 +434,8 @@ def with_transfers(ctx, capi, params, trace_host, gpu_root):
             for c in coms:
                 c.close()
         per_sorted = sorted(per)
-        return per_sorted[len(per) // 2], ok, {"min": round(per_sorted[0], 4), "max": round(per_sorted[-1], 4), "batches_in_order": [round(x, 4) for x in per]}
+        return per_sorted[len(per) // 2], ok, {"min": round(per_sorted[0], 4), "max": round(per_sorted[-1], 4), "batches_in_order": [round(x, 4) for x in per],
+                                               "warmup_ms_per_commit": round(warm_ms, 4)}
 
     out["resident_stream_ms_per_commit"], out["resident_stream_roots_match"], out["resident_stream_batches"] = streamed(cols)
     # the same with the host columns in PINNED memory (what a host gets from hipHostMalloc): asynchronous DMA
