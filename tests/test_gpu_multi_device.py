@@ -116,7 +116,7 @@ def test_rccl_thread_route_verifies_itself_on_all_devices(capi, mode):
     assert j["roots_gathered"] == (3 * w if mode == "proofs" else 3)
 
 
-@pytest.mark.parametrize("mode,world", [("proofs", 2), ("packed", 2), ("proofs", 4), ("packed", 8)])
+@pytest.mark.parametrize("mode,world", [("proofs", 2), ("packed", 2), ("proofs", 4), ("packed", 8), ("proofs", 8)])  # (proofs, 8) = configs[3]'s rank count
 def test_thread_route_over_the_loopback_transport(capi, mode, world):
     """The same thread-per-rank control flow with the ranks sharing the device(s): gates pass, the record says what ran."""
     capi.load()
