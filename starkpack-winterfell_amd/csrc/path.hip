@@ -399,6 +399,17 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
             if (ti < 2 || ((1u << a.logD) * ti * SegCfg<F>::S) / 16 < 64) ti = 0;
         }
         a.coset_inner = coset_inner(n_groups, ((uint64_t)run_cnt * a.O * a.I) / (ti ? ti : 1u));
+        // first pass of a coset evaluation through k_seg_strided: output factors from a global table, the coset's h_c^i merged into
+        // the input factors (GTAB1, seg_kernels.hpp).  D x I <= 2^20 entries (4 MiB for cfg 5's [9, 9] plan).  f128 only: there the
+        // per-tile table arithmetic is two 78-instruction products per entry (cfg 5's strided pass 0.433 -> 0.423 ms, three
+        // interleaved rounds); for f64 the saved 3 % of the pass's instructions are paid back in the prologue's extra load latency
+        // (cfg 2: 1.374 against 1.365 ms over four rounds; WF_EXP_GTAB1_F64=1 to try again) -- profiles/r05_gtab1_ab.txt
+        a.fout_tab = nullptr;
+        if (!ti && d.rows_out && first && !packed && a.pre_on && !a.scale_on && d.logN <= 20 && !ctx->tune.no_gtab1 &&
+            (F::BYTES == 16 || ctx->tune.gtab1_f64)) {
+            rc = pass_factor_table<F>(ctx, d.logN, a.logD, (uint32_t)(d.logN - a.logD), inverse, &a.fout_tab);
+            if (rc) return rc;
+        }
         if (ti) {
             if constexpr (F::BYTES == 8) {
                 const void *kw = ti == 8 ? (d.rows_out ? (const void *)k_seg_strided_wide<F, 1, 8> : (const void *)k_seg_strided_wide<F, 0, 8>)
@@ -453,6 +464,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
     a.n_seg = d.n_seg;
     a.seg_stride = d.n_seg;
     a.coset_inner = 0;
+    a.fout_tab = nullptr;
     if (d.phase == 1) return 0;
     {
         const int pi = plan.n_pass - 1;
@@ -668,21 +680,22 @@ static int run_hash_rows(wf_ctx *ctx, hipStream_t st, const void *lde, uint64_t 
         int rc = ensure(ctx, ctx->hash_tmp, (size_t)n_rows * chunks * 32);
         if (rc) return rc;
         const uint64_t g2 = (n_rows * chunks + threads - 1) / threads;
-        // 40 KiB of (unused) dynamic LDS per work-group = three work-groups, 12 waves per CU: the lanes of this kernel gather
-        // 16-byte elements a row apart (256 bytes in the reference's example), and more resident waves only evict each other's
-        // lines from the 32 KiB L1 -- 512 x 2^10 x 10 f128: 0.387 -> 0.343 ms for the hashing launches, other shapes unchanged
-        // (profiles/r04_attribution.txt)
-        // (round 5) 16-byte units that never straddle two traces' rows: the staged form -- a wave takes 16 rows x 4 chunks, quads of
-        // lanes load 64-byte pieces, one lane per (row, chunk) hashes from a wave-private LDS region (kernels.hpp)
+        // 16-byte units that never straddle two traces' rows (always for f128; f64 with an even number of columns): the staged form
+        // (round 5, kernels.hpp) -- a wave takes 16 rows x 4 chunks, quads of lanes load 64-byte pieces, one lane per (row, chunk)
+        // hashes from a wave-private LDS region; every element is fetched once
         constexpr uint32_t EPL = 16 / F::BYTES;
         if (epr % EPL == 0 && !ctx->tune.no_staged_chunks) {
             const uint64_t waves = ((n_rows + 15) / 16) * ((chunks + 3) / 4);
             if ((waves + 3) / 4 > 0x7FFFFFFFull) return fail(WF_ERR_ARG, "rows too long for one launch");
             hipLaunchKernelGGL(k_hash_chunks_staged<F>, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, st, h, (uint32_t)chunks,
                                (uint32_t *)ctx->hash_tmp.p);
-        } else
-        hipLaunchKernelGGL(k_hash_chunks<F>, dim3((uint32_t)g2), dim3(threads), 40 * 1024, st, h, (uint32_t)chunks,
-                           (uint32_t *)ctx->hash_tmp.p);
+        } else {
+            // a lane walks its own row.  40 KiB of (unused) dynamic LDS per work-group = three work-groups, 12 waves per CU: the lanes
+            // gather 16-byte elements a row apart, and more resident waves only evict each other's lines from the 32 KiB L1 (round 4:
+            // 512 x 2^10 x 10 f128 0.387 -> 0.343 ms for the hashing launches, profiles/r04_attribution.txt)
+            hipLaunchKernelGGL(k_hash_chunks<F>, dim3((uint32_t)g2), dim3(threads), 40 * 1024, st, h, (uint32_t)chunks,
+                               (uint32_t *)ctx->hash_tmp.p);
+        }
         HIP_TRY(hipGetLastError());
         launch_merge_chunks(st, ctx->hash_tmp.p, (uint32_t)chunks, n_rows, leaves, dw);
     }

@@ -144,7 +144,8 @@ struct SegArgs {
     uint32_t n_seg;         // segments per coset
     uint32_t n_cosets;
     uint32_t src_shared;    // source indexed by segment only (first pass of an evaluation reads the polys)
-    const T *fout_tab;      // k_seg_strided_wide<.., GTAB>: [I][D] output factors w_N^(k i N / (D I)) of this pass (global, built once per context)
+    const T *fout_tab;      // k_seg_strided_wide<.., GTAB> (later passes) and k_seg_strided (first pass of an evaluation, GTAB1): [I][D] output factors
+                            // w_N^(k i N / (D I)) of this pass (global, built once per context); nullptr: rebuilt per tile
     uint32_t coset_inner;   // strided pass, src_shared: 1 + log2(n_cosets) -- the cosets of 64 neighbouring tiles follow each other on one
                             // XCD (coset_inner_split), so that the source tile they share is fetched once and found in that L2; 0: coset outermost
     Pow2L<F> tw;            // powers of the N-th root of this transform
@@ -775,15 +776,23 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_strided(SegArgs<F> a) {
     const uint32_t tw_shift = a.logN - a.logD - logI;
     const bool scale_in = !PACKED && a.pre_on;
     const Pow2L<F> pin = scale_in ? pre : a.tw;  // without input scaling the reads go to the root table and are dropped
+    // GTAB1 (round 5; first pass of a coset evaluation, SegArgs::fout_tab set): the output factors w_N^(k i) come from a table in
+    // global memory ([i][k], built once per context, D x I entries) and the coset's h_c^i moves from the output factors into the
+    // INPUT factors -- h_c^(d I) * h_c^i = h_c^(d I + i), the coset factor of the row itself, at the same two table reads and one
+    // product per entry -- so the per-tile arithmetic of the output table (two reads, two products per entry) is gone
+    const bool gtab = !PACKED && a.fout_tab != nullptr;  // (uniform)
     uint32_t kq[2];
     T fo_a[2], fo_b[2], tw_q[2], fi_a[2], fi_b[2];
 #pragma unroll
     for (uint32_t q = 0; q < 2; q++) {
         const uint32_t k = threadIdx.x + q * NT;
         kq[q] = k < D ? k : D - 1;
-        a.tw.fetch(((uint64_t)kq[q] * i) << tw_shift, fo_a[q], fo_b[q]);
+        if (gtab)
+            fo_a[q] = fo_b[q] = a.fout_tab[(i << a.logD) + kq[q]];
+        else
+            a.tw.fetch(((uint64_t)kq[q] * i) << tw_shift, fo_a[q], fo_b[q]);
         tw_q[q] = a.digit_tw[kq[q]];
-        pin.fetch((uint64_t)kq[q] << logI, fi_a[q], fi_b[q]);
+        pin.fetch(((uint64_t)kq[q] << logI) + (gtab ? i : 0), fi_a[q], fi_b[q]);
     }
     // `direct`: the 16 inputs of this thread's first radix-16 work item come straight from global memory into registers
     // (lane threadIdx % S of rows a * D/16 + threadIdx / S), the tile makes no trip through LDS before the first round
@@ -846,12 +855,15 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_strided(SegArgs<F> a) {
     T fo[2];
     {
         T start = a.scale_on ? a.scale : F::one();
-        if (scale_in) start = pre.get(i);
+        if (scale_in && !gtab) start = pre.get(i);
         const bool trivial = !a.scale_on && !scale_in;
 #pragma unroll
         for (uint32_t q = 0; q < 2; q++) {
-            T f = F::mul(fo_a[q], fo_b[q]);
-            if (!trivial) f = F::mul(f, start);
+            T f = fo_a[q];
+            if (!gtab) {
+                f = F::mul(fo_a[q], fo_b[q]);
+                if (!trivial) f = F::mul(f, start);
+            }
             fo[q] = f;
             if (threadIdx.x + q * NT < D) {
                 if (!ONE_TABLE) twd[kq[q]] = tw_q[q];
