@@ -256,6 +256,7 @@ struct SegDesc {
     uint32_t digest_words = 8;  // 6: Blake3_192 leaves
     bool *fused = nullptr;
     const TableSet *pre;
+    const T *fin_tab = nullptr;  // rows_out, single-pass plan: [blowup][N] input factors h_c^k (FTAB, coset_row_factors); nullptr: rebuilt per tile
     bool pad_traces = false;     // rows_out, unpacked: the lane with a trace's last column zeroes the rest of that row
     bool pad_in_kernel = false;  // rows_out: the last pass also writes the zero padding lanes of the rows
     uint32_t base_cols, total_base_cols, coset0;
@@ -480,6 +481,7 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
         a.dst = d.out;
         a.src_shared = (single && d.rows_out) ? 1 : 0;
         a.pre_on = (single && d.rows_out) ? 1 : 0;
+        a.fin_tab = (single && d.rows_out && !packed) ? d.fin_tab : nullptr;
         a.scale_on = (single && !d.rows_out) ? 1 : 0;
         a.scale = inv_n;
         // Leaf hashing rides on the last pass
@@ -824,6 +826,13 @@ static int evaluate_and_commit(wf_ctx *ctx, hipStream_t st, const wf_params *p, 
     d.coset0 = coset0;
     d.rows_out = true;
     d.pre = cos;
+    // single-pass plans, f128: the coset's input factors h_c^k from a [blowup][N] table (FTAB: a tile otherwise spends one 78-instruction
+    // product per row on them -- the reference's example, 512 x 2^10 x 10: 3 % of its evaluation pass); f64 keeps the per-tile form
+    // (its product is 17 instructions and the same trade measured flat for its strided pass: GTAB1)
+    if (F::BYTES == 16 && !ctx->tune.no_ftab && seg_plan<F>(logR, b.n_seg, ctx->tune.max_digit, ctx->tune.full_tiles).n_pass == 1) {
+        rc = coset_row_factors<F>(ctx, logR, logB, off, olo, ohi, &d.fin_tab);
+        if (rc) return rc;
+    }
     d.base_cols = base_cols;
     d.total_base_cols = b.total_base_cols;
     d.row_width = row_width;

@@ -144,6 +144,7 @@ struct SegArgs {
     uint32_t n_seg;         // segments per coset
     uint32_t n_cosets;
     uint32_t src_shared;    // source indexed by segment only (first pass of an evaluation reads the polys)
+    const T *fin_tab;       // k_seg_last, single-pass evaluation (FTAB): [blowup][N] input factors h_c^k (global, built once per context); nullptr: per tile
     const T *fout_tab;      // k_seg_strided_wide<.., GTAB> (later passes) and k_seg_strided (first pass of an evaluation, GTAB1): [I][D] output factors
                             // w_N^(k i N / (D I)) of this pass (global, built once per context); nullptr: rebuilt per tile
     uint32_t coset_inner;   // strided pass, src_shared: 1 + log2(n_cosets) -- the cosets of 64 neighbouring tiles follow each other on one
@@ -1264,7 +1265,10 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
         const uint32_t k = threadIdx.x + q * NT;  // blockDim >= D / 2
         kq[q] = k < D ? k : D - 1;
         tw_q[q] = a.digit_tw[kq[q]];
-        pin.fetch(kq[q], fi_a[q], fi_b[q]);  // single-pass evaluation: row index = coefficient index
+        if (!PACKED && a.fin_tab)  // FTAB (round 5): the coset's factors h_c^k of a single-pass evaluation from a [coset][N] table in global memory
+            fi_a[q] = fi_b[q] = a.fin_tab[((uint64_t)(a.coset0 + c) << a.logN) + kq[q]];
+        else
+            pin.fetch(kq[q], fi_a[q], fi_b[q]);  // single-pass evaluation: row index = coefficient index
     }
     const uint4 twk0 = park(tw_q[0]), twk1 = park(tw_q[1]);  // (wait in vector registers: as an array they sit in scratch for f128)
     // (no direct first round here, unlike k_seg_strided: the tile is one contiguous 64 KiB run, which 16-byte-per-lane
@@ -1309,7 +1313,7 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_last(SegArgs<F> a) {
     for (uint32_t q = 0; q < 2; q++) {
         if (threadIdx.x + q * NT < D) {
             if (scale_in)
-                aux[kq[q]] = F::mul(fi_a[q], fi_b[q]);  // (in the twiddles' place until the tile is filled)
+                aux[kq[q]] = (!PACKED && a.fin_tab) ? fi_a[q] : F::mul(fi_a[q], fi_b[q]);  // (in the twiddles' place until the tile is filled)
             else
                 twd[kq[q]] = unpark<F>(q == 0 ? twk0 : twk1);
         }

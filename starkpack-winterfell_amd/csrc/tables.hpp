@@ -109,6 +109,36 @@ static int coset_tables(wf_ctx *ctx, uint32_t logR, uint32_t logB, typename F::T
     return 0;
 }
 
+// Input factors of a SINGLE-pass coset evaluation (k_seg_last, FTAB): entry [c][k] = h_c^k, h_c = offset * g^c, k < 2^logR -- what a tile
+// otherwise rebuilds from the two-level coset tables (two reads and one product per row and tile: 78 vector instructions for f128)
+template <class F>
+static int coset_row_factors(wf_ctx *ctx, uint32_t logR, uint32_t logB, typename F::T offset, uint64_t off_lo, uint64_t off_hi,
+                             const typename F::T **out) {
+    auto key = std::make_tuple((int)F::FIELD_ID, (int)logR, 8, (int)logB, off_lo, off_hi);
+    auto it = ctx->tables.find(key);
+    if (it == ctx->tables.end()) {
+        typedef typename F::T T;
+        const T g = f_root_of_unity<F>(logR + logB);
+        const size_t N = (size_t)1 << logR, B = (size_t)1 << logB;
+        std::vector<T> tab(N * B);
+        T h = offset;
+        for (size_t c = 0; c < B; c++) {
+            T acc = F::one();
+            for (size_t k = 0; k < N; k++) {
+                tab[c * N + k] = acc;
+                acc = F::mul(acc, h);
+            }
+            h = F::mul(h, g);
+        }
+        TableSet ts;
+        const int rcu = table_upload(ctx, &ts.lo, tab.data(), tab.size() * sizeof(T));
+        if (rcu) return rcu;
+        it = ctx->tables.emplace(key, ts).first;
+    }
+    *out = (const typename F::T *)it->second.lo;
+    return 0;
+}
+
 // output series for interpolate_poly_with_offset: coefficient k is multiplied by (1/n) * offset^-k
 // (math/src/fft/serial.rs:78-93); 1/n is folded into the lo table
 template <class F>

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 PARITY_CORE = ["WF_EXP_MAX_DIGIT=5", "WF_EXP_NO_FUSED_HASH=1", "WF_EXP_PERSISTENT_ALWAYS=1", "WF_EXP_NO_SPECIALIZED=1"]
 PARITY_ROTATING = ["WF_EXP_MAX_DIGIT=7", "WF_EXP_MAX_DIGIT=5 WF_EXP_WIDE_TI=8", "WF_EXP_MAX_DIGIT=7 WF_EXP_WIDE_TI=1", "WF_EXP_NO_PERSISTENT=1",
                    "WF_EXP_NO_CHUNKED=1", "WF_EXP_NO_CHUNKED=1 WF_EXP_NO_STAGED_CHUNKS=1", "WF_EXP_NO_COSET_INNER=1 WF_EXP_MAX_DIGIT=7",
-                   "WF_EXP_NO_GTAB=1 WF_EXP_MAX_DIGIT=5 WF_EXP_WIDE_TI=8", "WF_EXP_GTAB1_F64=1 WF_EXP_MAX_DIGIT=7", "WF_EXP_NO_GTAB1=1"]
+                   "WF_EXP_NO_GTAB=1 WF_EXP_MAX_DIGIT=5 WF_EXP_WIDE_TI=8", "WF_EXP_GTAB1_F64=1 WF_EXP_MAX_DIGIT=7", "WF_EXP_NO_GTAB1=1 WF_EXP_NO_FTAB=1"]
 RESIDENT_CORE = ["WF_EXP_PIPELINE_MIN_BYTES=0 WF_EXP_MAX_DIGIT=5"]
 RESIDENT_ROTATING = ["WF_EXP_PIPELINE_MIN_BYTES=0", "WF_EXP_NO_PIPELINE=1"]
 ROTATE_PICK = 3
