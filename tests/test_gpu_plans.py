@@ -17,10 +17,13 @@ pytestmark = pytest.mark.gpu
 # names the switch -- unless WF_TEST_ALL_PLANS=1 (every switch: what scripts/random_soak.py and the end-of-round soaks in
 # profiles/ run).  The suite had grown to 14 child suites and 95 s of a 900 s limit; the oracle comparisons of the BASELINE
 # configurations (tests/test_gpu_fullsize.py, test_gpu_production_size.py) are not part of the rotation and always run.
-PARITY_CORE = ["WF_EXP_MAX_DIGIT=5", "WF_EXP_NO_FUSED_HASH=1", "WF_EXP_PERSISTENT_ALWAYS=1", "WF_EXP_NO_SPECIALIZED=1"]
+PARITY_CORE = ["WF_EXP_MAX_DIGIT=5", "WF_EXP_NO_FUSED_HASH=1", "WF_EXP_PERSISTENT_ALWAYS=1", "WF_EXP_NO_SPECIALIZED=1",
+               # the alternatives the round-5 defaults replaced (per-tile factor tables of the f128 passes, a lane walking its own row in the
+               # separate chunk hashing): product code for f64 / odd widths, reached for the other shapes only through these switches
+               "WF_EXP_NO_GTAB1=1 WF_EXP_NO_FTAB=1 WF_EXP_NO_STAGED_CHUNKS=1 WF_EXP_NO_CHUNKED=1"]
 PARITY_ROTATING = ["WF_EXP_MAX_DIGIT=7", "WF_EXP_MAX_DIGIT=5 WF_EXP_WIDE_TI=8", "WF_EXP_MAX_DIGIT=7 WF_EXP_WIDE_TI=1", "WF_EXP_NO_PERSISTENT=1",
-                   "WF_EXP_NO_CHUNKED=1", "WF_EXP_NO_CHUNKED=1 WF_EXP_NO_STAGED_CHUNKS=1", "WF_EXP_NO_COSET_INNER=1 WF_EXP_MAX_DIGIT=7",
-                   "WF_EXP_NO_GTAB=1 WF_EXP_MAX_DIGIT=5 WF_EXP_WIDE_TI=8", "WF_EXP_GTAB1_F64=1 WF_EXP_MAX_DIGIT=7", "WF_EXP_NO_GTAB1=1 WF_EXP_NO_FTAB=1"]
+                   "WF_EXP_NO_CHUNKED=1", "WF_EXP_NO_COSET_INNER=1 WF_EXP_MAX_DIGIT=7",
+                   "WF_EXP_NO_GTAB=1 WF_EXP_MAX_DIGIT=5 WF_EXP_WIDE_TI=8", "WF_EXP_GTAB1_F64=1 WF_EXP_MAX_DIGIT=7"]
 RESIDENT_CORE = ["WF_EXP_PIPELINE_MIN_BYTES=0 WF_EXP_MAX_DIGIT=5"]
 RESIDENT_ROTATING = ["WF_EXP_PIPELINE_MIN_BYTES=0", "WF_EXP_NO_PIPELINE=1"]
 ROTATE_PICK = 3
