@@ -56,6 +56,7 @@ wf_tuning tuning_from_env() {
     t.no_staged_chunks = getenv("WF_EXP_NO_STAGED_CHUNKS") != nullptr;
     t.no_gtab1 = getenv("WF_EXP_NO_GTAB1") != nullptr;
     t.no_ftab = getenv("WF_EXP_NO_FTAB") != nullptr;
+    t.no_gtab1_wide = getenv("WF_EXP_NO_GTAB1_WIDE") != nullptr;
     t.gtab1_f64 = getenv("WF_EXP_GTAB1_F64") != nullptr;
     if (const char *e = getenv("WF_EXP_WIDE_TI")) {
         const int v = atoi(e);

@@ -424,10 +424,20 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
                 if (!first && !a.scale_on && !a.pre_on && a.logD + logI_ <= 19 && !ctx->tune.no_gtab) {
                     rc = pass_factor_table<F>(ctx, d.logN, a.logD, logI_, inverse, &a.fout_tab);
                     if (rc) return rc;
-                    kw = ti == 8 ? (d.rows_out ? (const void *)k_seg_strided_wide<F, 1, 8, true> : (const void *)k_seg_strided_wide<F, 0, 8, true>)
-                       : ti == 4 ? (d.rows_out ? (const void *)k_seg_strided_wide<F, 1, 4, true> : (const void *)k_seg_strided_wide<F, 0, 4, true>)
-                                 : (d.rows_out ? (const void *)k_seg_strided_wide<F, 1, 2, true> : (const void *)k_seg_strided_wide<F, 0, 2, true>);
+                    kw = ti == 8 ? (d.rows_out ? (const void *)k_seg_strided_wide<F, 1, 8, 1> : (const void *)k_seg_strided_wide<F, 0, 8, 1>)
+                       : ti == 4 ? (d.rows_out ? (const void *)k_seg_strided_wide<F, 1, 4, 1> : (const void *)k_seg_strided_wide<F, 0, 4, 1>)
+                                 : (d.rows_out ? (const void *)k_seg_strided_wide<F, 1, 2, 1> : (const void *)k_seg_strided_wide<F, 0, 2, 1>);
                     lds_w = ((size_t)(ti * SegCfg<F>::S + 1) << a.logD) * sizeof(T);
+                }
+                // the FIRST pass of a coset evaluation likewise (round 5): output factors w_N^(k i) from the global table ([I][D]: 32 MiB
+                // for cfg 3's first pass, built once per context), the coset's h_c^i merged into the input factors ([TI][D] in LDS:
+                // h_c^(d I + i)) -- three products per output-table entry and tile gone from a pass that sits at the vector ALU:
+                // cfg 3 33.13 -> 32.81 ms, three interleaved rounds (profiles/r05_gtab1_ab.txt)
+                if (first && d.rows_out && a.pre_on && !a.scale_on && ti == 2 && a.logD + logI_ <= 22 && !ctx->tune.no_gtab1_wide) {
+                    rc = pass_factor_table<F>(ctx, d.logN, a.logD, logI_, inverse, &a.fout_tab);
+                    if (rc) return rc;
+                    kw = (const void *)k_seg_strided_wide<F, 1, 2, 2>;
+                    lds_w = ((size_t)(ti * SegCfg<F>::S + 1 + ti) << a.logD) * sizeof(T);
                 }
                 const uint32_t threads_w = ((1u << a.logD) * ti * SegCfg<F>::S) / 16;
                 if (lds_w > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

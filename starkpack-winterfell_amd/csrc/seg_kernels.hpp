@@ -998,7 +998,9 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_strided(SegArgs<F> a) {
 // factors w_N^(k i N / (D I)) depend on neither coset nor segment nor outer index -- D x I entries, 256 KiB for cfg 3's second pass, built
 // once per context and served from L2) instead of being rebuilt in LDS by every tile.  What that buys is LDS: 17 KiB per work-group
 // instead of 20, i.e. nine work-groups per CU instead of eight for the pass whose waves per CU are what it lives on.
-template <class F, int EVAL, int TI, bool GTAB = false>
+// GTAB: 0 = factor tables rebuilt per tile; 1 = later passes (output factors from the global table, no input factors); 2 = FIRST pass of a coset
+// evaluation with the output factors from the global table and the coset's h_c^i merged into the input factors ([TI][D] in LDS: h_c^(d I + i))
+template <class F, int EVAL, int TI, int GTAB = 0>
 __global__ void __launch_bounds__(1024) k_seg_strided_wide(SegArgs<F> a) {
     static_assert(SegCfg<F>::RADIX16 && TI >= 2 && (TI & (TI - 1)) == 0, "f64 tiles of 2, 4 or 8 inner positions");
     typedef typename F::T T;
@@ -1009,8 +1011,8 @@ __global__ void __launch_bounds__(1024) k_seg_strided_wide(SegArgs<F> a) {
     const uint32_t D = 1u << a.logD, NT = blockDim.x;
     T *x = reinterpret_cast<T *>(smem_raw);
     T *twd = x + (size_t)D * LANES;  // (stays in LDS also with GTAB: read from global memory inside the rounds the pass measured 3 % slower)
-    T *fin = twd + D;    // h_c^(d I): factors of the input rows (first pass of a coset evaluation)
-    T *fout = fin + D;   // [TI][D]: factors of the output rows
+    T *fin = twd + D;    // h_c^(d I): factors of the input rows (first pass of a coset evaluation); GTAB == 2: [TI][D], h_c^(d I + i)
+    T *fout = fin + D;   // [TI][D]: factors of the output rows (GTAB == 0)
 
     uint64_t bid = xcd_group_index(blockIdx.x, gridDim.x);  // 8 neighbouring tiles (8 * TI * 64 contiguous bytes per row) on one XCD
     uint32_t c_in = 0;
@@ -1036,7 +1038,7 @@ __global__ void __launch_bounds__(1024) k_seg_strided_wide(SegArgs<F> a) {
     // prologue: every global read of the tile's setup is issued before the first one is used (as in k_seg_strided)
     const Pow2L<F> pst = scale_in ? pre : a.tw;  // (without input scaling these reads go to the root table and are dropped)
     T fo_a[2], fo_b[2], st_a[2], st_b[2];
-    if constexpr (!GTAB) {
+    if constexpr (GTAB == 0) {
 #pragma unroll
         for (uint32_t q = 0; q < 2; q++) {  // TI * D = 2 NT table entries: entry e = ti * D + k
             const uint32_t e = tid + q * NT, k = e & (D - 1), ti = e >> a.logD;
@@ -1044,12 +1046,18 @@ __global__ void __launch_bounds__(1024) k_seg_strided_wide(SegArgs<F> a) {
             a.tw.fetch(((uint64_t)k * i) << tw_shift, fo_a[q], fo_b[q]);
             pst.fetch(i, st_a[q], st_b[q]);
         }
+    } else if constexpr (GTAB == 2) {
+#pragma unroll
+        for (uint32_t q = 0; q < 2; q++) {  // input factors of row d at inner position i0 + ti: h_c^(d I + i0 + ti)
+            const uint32_t e = tid + q * NT, k = e & (D - 1), ti = e >> a.logD;
+            pst.fetch(((uint64_t)k << logI) + i0 + ti, st_a[q], st_b[q]);
+        }
     }
     const bool has_d = tid < D;  // (NT = D * TI / 2 >= D)
     const uint32_t kd = has_d ? tid : 0;
     const T twv = a.digit_tw[kd];
     T fi_a, fi_b;
-    if constexpr (!GTAB) pst.fetch((uint64_t)kd << logI, fi_a, fi_b);
+    if constexpr (GTAB == 0) pst.fetch((uint64_t)kd << logI, fi_a, fi_b);
     // the thread's radix-16 work item straight from global memory: lane tid % LANES of rows a * D/16 + tid / LANES
     const uint32_t m16 = D >> 4, l16 = tid & (LANES - 1), j16 = tid >> LOGL;
     T vr[16];
@@ -1066,7 +1074,11 @@ __global__ void __launch_bounds__(1024) k_seg_strided_wide(SegArgs<F> a) {
             pr += rstep;
         }
     }
-    if constexpr (!GTAB) {
+    if constexpr (GTAB == 2) {
+#pragma unroll
+        for (uint32_t q = 0; q < 2; q++) fin[tid + q * NT] = F::mul(st_a[q], st_b[q]);
+    }
+    if constexpr (GTAB == 0) {
 #pragma unroll
         for (uint32_t q = 0; q < 2; q++) {
             T f = F::mul(fo_a[q], fo_b[q]);
@@ -1079,15 +1091,19 @@ __global__ void __launch_bounds__(1024) k_seg_strided_wide(SegArgs<F> a) {
     }
     if (has_d) {
         twd[kd] = twv;
-        if constexpr (!GTAB)
+        if constexpr (GTAB == 0)
             if (scale_in) fin[kd] = F::mul(fi_a, fi_b);
     }
     __syncthreads();
-    if constexpr (!GTAB) {
+    if constexpr (GTAB == 0) {
         if (scale_in) {
 #pragma unroll
             for (uint32_t q = 0; q < 16; q++) vr[q] = F::mul(vr[q], fin[q * m16 + j16]);
         }
+    } else if constexpr (GTAB == 2) {
+        const uint32_t tb = (l16 >> LOGS) << a.logD;  // this lane's inner position within the tile
+#pragma unroll
+        for (uint32_t q = 0; q < 16; q++) vr[q] = F::mul(vr[q], fin[tb + q * m16 + j16]);
     }
 #ifndef WF_EXP_SKIP_NTT
     seg_lds_ntt<F, EVAL ? 1 : -1, 0u, LANES>(x, twd, a.logD, NT, vr, true);
@@ -1102,7 +1118,7 @@ __global__ void __launch_bounds__(1024) k_seg_strided_wide(SegArgs<F> a) {
     const T *fo = GTAB ? a.fout_tab + ((i0 + ((2 * prw) >> LOGS)) << a.logD) : fout + (((2 * prw) >> LOGS) << a.logD);
     T *dst_lane = dst + row0 * S + 2 * prw;
     const uint32_t k_shift = logI + LOGS;  // output rows k are I apart
-    if constexpr (GTAB) {  // pstride = D / 8: eight rows per thread, their factors requested together
+    if constexpr (GTAB != 0) {  // pstride = D / 8: eight rows per thread, their factors requested together
         uint32_t kk[8];
         T ff[8];
 #pragma unroll

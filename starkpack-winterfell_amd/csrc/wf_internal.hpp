@@ -69,6 +69,7 @@ struct wf_tuning {
     size_t pipeline_min_bytes = (size_t)1 << 20;  // WF_EXP_PIPELINE_MIN_BYTES
     bool no_tail_pack = false;        // WF_EXP_NO_TAIL_PACK: a half-empty last segment evaluated like the others (not coset-packed)
     bool no_coset_inner = false;      // WF_EXP_NO_COSET_INNER: first strided evaluation pass with the coset as the outermost tile index
+    bool no_gtab1_wide = false;       // WF_EXP_NO_GTAB1_WIDE: the first WIDE strided evaluation pass (three-pass plans) rebuilds its output factors per tile
     bool no_ftab = false;             // WF_EXP_NO_FTAB: single-pass f128 evaluations rebuild their input factors per tile
     bool no_gtab1 = false;            // WF_EXP_NO_GTAB1: the first strided evaluation pass rebuilds its output factors per tile (h_c^i on the output side)
     bool gtab1_f64 = false;           // WF_EXP_GTAB1_F64: ... from the global table for f64 too (default: f128 only, where it measures faster)

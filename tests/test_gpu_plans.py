@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 PARITY_CORE = ["WF_EXP_MAX_DIGIT=5", "WF_EXP_NO_FUSED_HASH=1", "WF_EXP_PERSISTENT_ALWAYS=1", "WF_EXP_NO_SPECIALIZED=1",
                # the alternatives the round-5 defaults replaced (per-tile factor tables of the f128 passes, a lane walking its own row in the
                # separate chunk hashing): product code for f64 / odd widths, reached for the other shapes only through these switches
-               "WF_EXP_NO_GTAB1=1 WF_EXP_NO_FTAB=1 WF_EXP_NO_STAGED_CHUNKS=1 WF_EXP_NO_CHUNKED=1"]
+               "WF_EXP_NO_GTAB1=1 WF_EXP_NO_FTAB=1 WF_EXP_NO_STAGED_CHUNKS=1 WF_EXP_NO_CHUNKED=1 WF_EXP_NO_GTAB1_WIDE=1 WF_EXP_MAX_DIGIT=6"]
 PARITY_ROTATING = ["WF_EXP_MAX_DIGIT=7", "WF_EXP_MAX_DIGIT=5 WF_EXP_WIDE_TI=8", "WF_EXP_MAX_DIGIT=7 WF_EXP_WIDE_TI=1", "WF_EXP_NO_PERSISTENT=1",
                    "WF_EXP_NO_CHUNKED=1", "WF_EXP_NO_COSET_INNER=1 WF_EXP_MAX_DIGIT=7",
                    "WF_EXP_NO_GTAB=1 WF_EXP_MAX_DIGIT=5 WF_EXP_WIDE_TI=8", "WF_EXP_GTAB1_F64=1 WF_EXP_MAX_DIGIT=7"]
