@@ -520,15 +520,18 @@ __device__ __forceinline__ void seg_round4(typename F::T *x, const typename F::T
     const uint32_t st = m * S;
     // cur == 3 (tiles of 2^7 and 2^11 rows): the twiddles are w_8^(jp k) = 2^(24 jp k), jp = 0, 1.  As in seg_round16 a wave
     // (4 lane pairs x 16 items) takes sixteen blocks of one jp, and the products become shifts (or nothing).
-    constexpr bool SHIFT_TW = UNI && F::FIELD_ID == 1 && DIR != 0 && HP == 4;
+    // (HP == 8: the 16-lane rows of the wide strided kernel, 8 lane pairs x 8 items per wave -- also in the generic round loop, which is the
+    // only form those tiles run)
+    constexpr bool SHIFT_TW = F::FIELD_ID == 1 && DIR != 0 && ((UNI && HP == 4) || HP == 8);
+    constexpr uint32_t IPW_LOG = HP == 8 ? 3 : 4;  // log2 of the work items of one wave: 64 / HP
     const bool uni = SHIFT_TW && cur == 3 && logD >= 7;
     for (uint32_t wk = tid; wk < nwork; wk += nthr) {
         const uint32_t lp = wk & (HP - 1), u = wk >> hp_shift;
         uint32_t jp = u & (m - 1), p = u >> mlog;
         if (uni) {
-            const uint32_t wv = u >> 4;
+            const uint32_t wv = u >> IPW_LOG;
             jp = wv & 1u;
-            p = ((wv >> 1) << 4) | (u & 15u);
+            p = ((wv >> 1) << IPW_LOG) | (u & ((1u << IPW_LOG) - 1));
         }
         const uint32_t row0 = (p << cur) + jp;
         // element offsets of rows row0 + k * m
