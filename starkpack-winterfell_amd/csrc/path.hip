@@ -439,6 +439,13 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
                     kw = (const void *)k_seg_strided_wide<F, 1, 2, 2>;
                     lds_w = ((size_t)(ti * SegCfg<F>::S + 1 + ti) << a.logD) * sizeof(T);
                 }
+                // the evaluation passes of the three-pass plans on 2^7 / 2^8-row tiles: tile-size-specialised instantiations (same generic round loop)
+                if (ti == 2 && d.rows_out && !ctx->tune.no_specialized) {
+                    if (kw == (const void *)k_seg_strided_wide<F, 1, 2, 2>)
+                        kw = a.logD == 8 ? (const void *)k_seg_strided_wide<F, 1, 2, 2, 8> : a.logD == 7 ? (const void *)k_seg_strided_wide<F, 1, 2, 2, 7> : kw;
+                    else if (kw == (const void *)k_seg_strided_wide<F, 1, 2, 1>)
+                        kw = a.logD == 8 ? (const void *)k_seg_strided_wide<F, 1, 2, 1, 8> : a.logD == 7 ? (const void *)k_seg_strided_wide<F, 1, 2, 1, 7> : kw;
+                }
                 const uint32_t threads_w = ((1u << a.logD) * ti * SegCfg<F>::S) / 16;
                 if (lds_w > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 void *kargs[] = {&a};

@@ -1003,8 +1003,11 @@ __global__ void WF_TILE_BOUNDS(LOGD, 1024) k_seg_strided(SegArgs<F> a) {
 // instead of 20, i.e. nine work-groups per CU instead of eight for the pass whose waves per CU are what it lives on.
 // GTAB: 0 = factor tables rebuilt per tile; 1 = later passes (output factors from the global table, no input factors); 2 = FIRST pass of a coset
 // evaluation with the output factors from the global table and the coset's h_c^i merged into the input factors ([TI][D] in LDS: h_c^(d I + i))
-template <class F, int EVAL, int TI, int GTAB = 0>
+// LOGD != 0: the tile size as a compile-time constant of the SAME generic round loop (trip counts, strides and LDS offsets fold; round 5:
+// cfg 3's two wide evaluation passes -1.2 % each) -- not the fixed-size round sequences of the narrow kernels, which measured 16 % slower here.
+template <class F, int EVAL, int TI, int GTAB = 0, int LOGD = 0>
 __global__ void __launch_bounds__(1024) k_seg_strided_wide(SegArgs<F> a) {
+    if (LOGD) a.logD = LOGD;
     static_assert(SegCfg<F>::RADIX16 && TI >= 2 && (TI & (TI - 1)) == 0, "f64 tiles of 2, 4 or 8 inner positions");
     typedef typename F::T T;
     typedef Pair<T> P2;
