@@ -330,6 +330,9 @@ static int run_seg_transform(wf_ctx *ctx, hipStream_t st, const SegDesc<F> &d) {
                    tickets_tp < (1ull << 31) &&
                    (ctx->tune.persistent_always || launch_rows >= (1ull << 20));  // (as the ticket kernel's own rule for one trace)
     }
+    // (the work buffer of EVERY caller holds n_cosets * n_seg * N * S elements -- path_buffers sizes it so, with n_cosets the cosets of this call:
+    // all of them, or a rank's share -- and the tail region ends at n_cosets * (nf + 1/2) * N * S <= that; the pipelined upload (phase 1 / 2)
+    // never takes this route: tests/test_gpu_tail_pack.py runs it through the unsharded and the coset-sharded entry points)
     T *work_tail = tailpack ? d.work + (size_t)d.n_cosets * nf * N * S_ : nullptr;  // [coset pair][N][S] behind the full segments
 
     const uint32_t run_cnt = tailpack ? nf : (d.seg_cnt ? d.seg_cnt : d.n_seg);
