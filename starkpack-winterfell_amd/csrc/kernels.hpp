@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256) k_hash_chunks_staged(HashArgs<F> a, uint3
     const uint64_t lrow = rg * 16 + q;
     const T *lp[4];
     uint32_t lcol[4];
-    uint64_t lleft[4];  // elements from this lane's next unit to the end of its chunk (0: nothing more to load)
+    uint32_t lleft[4];  // elements from this lane's next unit to the end of its chunk (0: nothing more to load; at most a chunk's 64 / 128)
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++) {
         const uint64_t c = cg * 4 + k;
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(256) k_hash_chunks_staged(HashArgs<F> a, uint3
         const uint32_t t = live ? (uint32_t)(e0 / a.epr) : 0u;
         lcol[k] = live ? (uint32_t)(e0 - (uint64_t)t * a.epr) : 0u;
         lp[k] = a.lde + (uint64_t)t * a.trace_elems + (live ? lrow : 0) * a.row_width;
-        lleft[k] = live ? cend - e0 : 0;
+        lleft[k] = live ? (uint32_t)(cend - e0) : 0u;
     }
     auto fetch = [&](uint32_t k) -> uint4 {  // this lane's 16 bytes of the current block of slot k, then on to the next block
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -338,13 +338,18 @@ __global__ void __launch_bounds__(256) k_hash_chunks_staged(HashArgs<F> a, uint3
         __builtin_amdgcn_wave_barrier();  // (the region is rewritten by the next step)
         if (b < nblocks) {
             uint32_t m[16];
+            if (celems - b * EPB >= EPB) {  // a whole block (every block but the last one of a row's last chunk): no per-word selects
 #pragma unroll
-            for (uint32_t e = 0; e < EPB; e++) {
-                if (b * EPB + e < celems) {
-                    elem_words<F>(ev[e], &m[e * WPE]);
-                } else {
+                for (uint32_t e = 0; e < EPB; e++) elem_words<F>(ev[e], &m[e * WPE]);
+            } else {
 #pragma unroll
-                    for (uint32_t w = 0; w < WPE; w++) m[e * WPE + w] = 0;
+                for (uint32_t e = 0; e < EPB; e++) {
+                    if (b * EPB + e < celems) {
+                        elem_words<F>(ev[e], &m[e * WPE]);
+                    } else {
+#pragma unroll
+                        for (uint32_t w = 0; w < WPE; w++) m[e * WPE + w] = 0;
+                    }
                 }
             }
             const uint32_t blen = clen - b * 64 < 64 ? clen - b * 64 : 64;
